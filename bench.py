@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the batched PVDER-v0 hot path on N MI355X (contract: task statement).
+
+Workload (BASELINE.json configs[2], the configuration the north_star target is quoted on; with
+--gpus N it is the per-GPU shard of configs[3] = weak scaling): 65 536 parallel PVDER-v0 envs per
+GPU, PVDER-v0 default kwargs (n = 15 sim time steps of 1/60 s per env step, discrete
+voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32 fixed-step RK4
+(4096 micro-steps per sim time step), uniform random actions resident on the device, auto-reset.
+A "step" is one batched env transition (one fused HIP launch over all local envs); for N > 1 each
+step ends with ONE RCCL all-gather of the [13, N_local] output block (11 obs + reward + done).
+
+Prints ONE JSON line on rank 0.  `value` counts env transitions of all ranks / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
+BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, three-phase fp32
+FLOP_PER_RK4_STEP = 1434          # DESIGN.md "Kernels": counted from the gfx950 ISA of the inner loop
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--n-sub", type=int, default=15)
+    ap.add_argument("--micro", type=int, default=4096)
+    ap.add_argument("--integrator", default="rk4", choices=["rk4", "rk45"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
+    return ap.parse_args()
+
+
+def events_on_spec():
+    from gym_PVDER_amd.vec_env import default_events_spec
+    s = default_events_spec()
+    s["insolation"]["ENABLE"] = True          # update_env_events([{'insolation': {'ENABLE': True}}])
+    return s
+
+
+def cpu_baseline(seconds: float):
+    """The oracle (fp64 SciPy-odeint restatement of the reference's step path, "port") timed on
+    one host core the way the reference times itself: wall time around step (PVDER_env.py:140,193)."""
+    from oracle.pvder_oracle_env import OraclePVDER
+    import numpy as np
+    env = OraclePVDER(solver="reference", seed=1)      # PVDER-v0 defaults, voltage events on
+    env.reset()
+    rng = np.random.default_rng(0)
+    n, t_used = 0, 0.0
+    while t_used < seconds:
+        a = int(rng.integers(0, 5))
+        t0 = time.time()
+        _, _, done, _ = env.step(a)
+        t_used += time.time() - t0
+        n += 1
+        if done:
+            env.reset()
+    return {"value": n / t_used, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d env steps of 1 env, PVDER-v0 defaults (n=15, LSODA rtol=atol=1e-4, hmax=1/120), "
+                      "random actions, %.1f s of CPU" % (n, t_used)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from gym_PVDER_amd.vec_env import PVDERVec
+    N = args.envs
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=args.n_sub, micro_steps=args.micro,
+                   integrator=args.integrator, seed=2024, env_id_base=rank * N, events_spec=events_on_spec(),
+                   auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    total = args.warmup + args.steps
+    actions = torch.randint(0, 5, (total, N), generator=gen, device=dev, dtype=torch.uint8)
+    gathered = torch.empty((world, 13, N), dtype=env.out.dtype, device=dev) if world > 1 else None
+
+    def one_step(i):
+        env.step(actions[i])
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, env.out)     # ONE collective per step (RCCL/xGMI)
+
+    for i in range(args.warmup):
+        one_step(i)
+    env.kernel_timing(True)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        one_step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = env.kernel_times_ms()
+    st = env.step_stats()
+
+    if rank == 0:
+        value = world * N * args.steps / elapsed
+        avg_kern_s = (sum(kern_ms) / len(kern_ms)) * 1e-3 if kern_ms else float("nan")
+        bytes_step = BYTES_PER_ENV_STEP_F32 if args.integrator == "rk4" else 533
+        achieved = bytes_step * N / avg_kern_s
+        flops = FLOP_PER_RK4_STEP * args.micro * args.n_sub * N / avg_kern_s
+        out = {
+            "metric": "env-steps/sec (batched PVDER-v0)", "value": value, "unit": "env-steps/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.integrator == "rk4" else "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
+                                   "per env step, voltage+insolation events on, %s, random actions, auto-reset"
+                                   % (N, args.n_sub, ("fp32 fixed-step RK4, %d micro-steps per 1/60 s" % args.micro)
+                                      if args.integrator == "rk4" else "fp64 adaptive RK45"),
+                       "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro,
+                       "integrator": args.integrator,
+                       "collective": "all_gather_into_tensor [13, N_local] per step" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "step_rk4_kernel<float,3>" if args.integrator == "rk4" else "step_rk45_kernel<double,3>",
+                         "kernel_avg_ms": avg_kern_s * 1e3, "algorithmic_bytes_per_env_step": bytes_step},
+            # the binding roof of this path is the fp32 VALU, not HBM
+            "valu_roofline": {"bound": "valu_f32", "achieved": flops / 1e12, "peak": VALU_PEAK_F32 / 1e12,
+                              "unit": "TFLOP/s", "frac": flops / VALU_PEAK_F32,
+                              "flop_per_rk4_step": FLOP_PER_RK4_STEP} if args.integrator == "rk4" else None,
+            "last_step_stats": st,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""gym_PVDER_amd -- MI355X-native batched PVDER-v0 (drop-in for ``gym_PVDER``'s step path).
+
+``make('PVDER-v0', **kwargs)`` mirrors ``gym.make`` with the registration of the reference
+(/root/reference/gym_PVDER/__init__.py:3-10): same id, same default kwargs, TimeLimit of 500
+steps.  ``gym`` / ``gymnasium`` are optional: when one is importable the id is also registered
+there; otherwise the built-in registry below serves ``make``/``spec``.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+ENV_ID = 'PVDER-v0'
+DEFAULT_KWARGS = {'n_sim_time_steps_per_env_step': 15, 'max_sim_time': 40.0, 'DISCRETE_REWARD': True,
+                  'goals_list': ['voltage_regulation']}            # gym_PVDER/__init__.py:6-9
+MAX_EPISODE_STEPS = 500                                             # gym_PVDER/__init__.py:10
+
+_registry = {ENV_ID: SimpleNamespace(id=ENV_ID, entry_point='gym_PVDER_amd.envs:PVDER',
+                                     kwargs=dict(DEFAULT_KWARGS), max_episode_steps=MAX_EPISODE_STEPS)}
+
+
+def spec(env_id: str):
+    if env_id not in _registry:
+        raise KeyError("No registered env with id: %s" % env_id)
+    return _registry[env_id]
+
+
+def make(env_id: str = ENV_ID, **kwargs):
+    """Create the single-env ``PVDER`` (old-gym API).  For N envs use :class:`PVDERVec`."""
+    from .envs import PVDER
+    s = spec(env_id)
+    kw = dict(s.kwargs)
+    kw.update(kwargs)
+    env = PVDER(**kw)
+    env.spec = s
+    return env
+
+
+def make_vec(num_envs: int, env_id: str = ENV_ID, **kwargs):
+    """Create a batched :class:`PVDERVec` with the registered default kwargs."""
+    from .vec_env import PVDERVec
+    kw = dict(spec(env_id).kwargs)
+    kw.update(kwargs)
+    return PVDERVec(num_envs, **kw)
+
+
+def _register_with_gym():
+    for mod in ("gym", "gymnasium"):
+        try:
+            reg = __import__(mod + ".envs.registration", fromlist=["register"])
+            reg.register(id=ENV_ID, entry_point='gym_PVDER_amd.envs:PVDER', kwargs=dict(DEFAULT_KWARGS),
+                         max_episode_steps=MAX_EPISODE_STEPS)
+        except Exception:
+            pass
+
+
+_register_with_gym()
+
+__all__ = ["make", "make_vec", "spec", "ENV_ID", "DEFAULT_KWARGS"]

@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI in include/pvder_hip.h (libpvder_hip.so, built in-tree by hipcc).
+
+There is NO fallback: if the shared library is missing or does not export every symbol the header
+declares, importing the env's compute path raises.  PyTorch is only the owner of device memory
+and streams; pointers cross the boundary as integers (``tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(HERE)                       # gym-solarpvder-environment_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+CSRC = os.path.join(PKG_ROOT, "csrc")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
+
+EINVAL = -10001
+ABI_VERSION = 1
+
+# every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
+SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
+           "pvder_reset_masked_f64", "pvder_step_rk4_f32", "pvder_step_rk45_f64"]
+
+
+class StepCfg(C.Structure):
+    """``struct pvder_step_cfg`` (include/pvder_hip.h)."""
+    _fields_ = [("n_sub", C.c_int32), ("micro", C.c_int32), ("max_ksub", C.c_int32),
+                ("max_steps", C.c_int32), ("goal", C.c_int32), ("discrete", C.c_int32),
+                ("ev_s0", C.c_int32), ("ev_ds", C.c_int32), ("ev_count", C.c_int32),
+                ("reserved", C.c_int32), ("del_qref", C.c_double), ("del_vdcref", C.c_double),
+                ("inv_max_sim_time", C.c_double), ("p_target", C.c_double), ("q_target", C.c_double),
+                ("rtol", C.c_double), ("atol", C.c_double)]
+
+
+class EventSpec(C.Structure):
+    """``struct pvder_event_spec`` (include/pvder_hip.h)."""
+    _fields_ = [("ev_count", C.c_int32), ("enable_voltage", C.c_int32), ("enable_insol", C.c_int32),
+                ("reserved", C.c_int32), ("v_min", C.c_float), ("v_max", C.c_float),
+                ("s_min", C.c_float), ("s_max", C.c_float)]
+
+
+def hipcc_path() -> str:
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into gym_PVDER_amd/lib/libpvder_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(INCLUDE, "pvder_hip.h"))
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + INCLUDE, "-I" + CSRC, "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libpvder_hip.so (after torch, so that torch's libamdhip64 is the one HIP runtime of
+    the process) and set the prototypes.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "native library %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the PVDER step path"
+            % LIB_PATH)
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so first: single HIP runtime)
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise ImportError("libpvder_hip.so lacks symbols: %s" % missing)
+    if L.pvder_version() != ABI_VERSION:
+        raise ImportError("libpvder_hip.so ABI %d != expected %d" % (L.pvder_version(), ABI_VERSION))
+    vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+    dp = C.POINTER(C.c_double)
+    for name in ("pvder_reset_masked_f32", "pvder_reset_masked_f64"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [dp, dp, C.POINTER(StepCfg), C.POINTER(EventSpec), vp, vp, vp, vp, vp, vp, u64, i64,
+                      i32, i32, vp]
+    L.pvder_step_rk4_f32.restype = i32
+    L.pvder_step_rk4_f32.argtypes = [dp, C.POINTER(StepCfg), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.pvder_step_rk45_f64.restype = i32
+    L.pvder_step_rk45_f64.argtypes = [dp, C.POINTER(StepCfg), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == EINVAL:
+        raise ValueError("%s: invalid argument (PVDER_EINVAL)" % what)
+    raise RuntimeError("%s: HIP error %d" % (what, -rc))

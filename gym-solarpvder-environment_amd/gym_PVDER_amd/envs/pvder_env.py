@@ -1,0 +1,208 @@
+"""Single-environment ``PVDER`` with the reference's old-gym API, running on the HIP kernels.
+
+Drop-in for /root/reference/gym_PVDER/envs/PVDER_env.py ``class PVDER`` (:39): same constructor
+arguments (:104-105), ``reset() -> np.ndarray(11,)`` (:316-334), ``step(action) -> (obs, reward,
+done, {})`` (:138-196) with a Python ``int`` reward when DISCRETE_REWARD else ``float``
+(:301; gym_PVDER/tests/test_gym_PVDER.py:66,81) and a Python ``bool`` done (test :35),
+``render(mode)`` for ``metadata['render.modes']`` (:42, :336-364), ``close()``,
+``update_env_events`` (:413-438), ``steps`` (env_utilities.py:48-52) and the ``env.sim`` /
+``env.sim.PV_model`` attribute surface the tests and examples touch (test :108, :124;
+examples/gym_PVDER_environment_import_test.py:38).  It is a PVDERVec with num_envs = 1 -- the same
+fused launch, no separate code path.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import der_model
+from ..spaces import make_spaces
+from ..vec_env import EnvSpecMixin, PVDERVec, SIM_TIME_STEP, OBSERVED_QUANTITIES
+
+logger = logging.getLogger("gym_PVDER_amd")
+
+
+class _EventsView:
+    """``env.sim.simulation_events`` -- exposes ``_events_spec`` (test_gym_PVDER.py:124)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def _events_spec(self):
+        return self._env.env_events_spec
+
+    def update_events_spec(self, events_spec):
+        self._env.update_env_events([{k: dict(v)} for k, v in events_spec.items()])
+
+
+class _PVModelView:
+    """``env.sim.PV_model`` -- the attributes PVDER_env.py reads back (:225-299, :339-348, :535-539)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.Sbase, self.Vdcbase = der_model.SBASE, der_model.VDCBASE
+        self.Vrms_ref = float(env._vec.par[der_model.IDX["VRMS_REF"]])
+
+    def _o(self, k):
+        return float(self._env._vec.out[k, 0])
+
+    @property
+    def Q_ref(self):
+        return float(self._env._vec.Q_ref[0])
+
+    @Q_ref.setter
+    def Q_ref(self, v):
+        self._env._vec.Q_ref[0] = v
+
+    @property
+    def Vdc_ref(self):
+        return float(self._env._vec.Vdc_ref[0])
+
+    @Vdc_ref.setter
+    def Vdc_ref(self, v):
+        self._env._vec.Vdc_ref[0] = v
+
+    ia = property(lambda s: complex(s._o(0), s._o(1)))
+    va = property(lambda s: complex(s._o(2), s._o(3)))
+    S_PCC = property(lambda s: complex(s._o(4), s._o(5)))
+    Vdc = property(lambda s: s._o(6))
+    Ppv = property(lambda s: s._o(7))
+
+
+class _SimView:
+    """``env.sim`` -- tStart/tStop/tInc/Sbase/Vbase/Ibase/name (PVDER_env.py:143-196, :340-349)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.tInc = SIM_TIME_STEP                                     # :396
+        self.Sbase, self.Vbase, self.Ibase = der_model.SBASE, der_model.VBASE, der_model.IBASE
+        self.name = 'sim_' + env.name
+        self.simulation_events = _EventsView(env)
+        self.PV_model = _PVModelView(env)
+        self.SOLVER_CONVERGENCE = True
+        self.jacFlag = False        # explicit integrator: no Jacobian (reference sets True, :386)
+
+    @property
+    def tStart(self):
+        return float(self._env._vec.istate[0, 0]) * SIM_TIME_STEP
+
+    @property
+    def tStop(self):
+        return self.tStart
+
+
+class PVDER(EnvSpecMixin):
+    """Old-gym style single env; see module docstring."""
+
+    count = 0
+    metadata = {'render.modes': ['vector', 'human']}                 # :42
+    observed_quantities = OBSERVED_QUANTITIES
+    action_space, observation_space = make_spaces()                  # :50-51
+    reward_range = (-float('inf'), float('inf'))
+    spec = None
+
+    def __init__(self, goals_list=('voltage_regulation',), n_sim_time_steps_per_env_step=15,
+                 max_sim_time=40.0, DISCRETE_REWARD=True, verbosity='INFO', device="cuda",
+                 integrator="rk4", micro_steps=None, seed=0, model_type='model_2'):
+        PVDER.count += 1                                             # :117
+        self.name = 'GymDER_' + str(PVDER.count)
+        self.verbosity = verbosity
+        kw = {} if micro_steps is None else {"micro_steps": micro_steps}
+        self._vec = PVDERVec(1, goals_list=goals_list,
+                             n_sim_time_steps_per_env_step=n_sim_time_steps_per_env_step,
+                             max_sim_time=max_sim_time, DISCRETE_REWARD=DISCRETE_REWARD, device=device,
+                             integrator=integrator, auto_reset=False, seed=seed, model_type=model_type,
+                             env_id_base=PVDER.count - 1, **kw)
+        self.max_sim_time_user = max_sim_time
+        self.env_events_spec = self._vec.env_events_spec
+        self._reward = 0
+        self.done = False
+        self._step_time = 0.0
+        self._time_stats = {'step': [], 'step_time': []}
+        self._reward_stats = {'step': [], 'reward': []}
+        self._action_stats = {i: 0 for i in range(5)}
+        self.CONVERGENCE_FAILURE = False
+        self.RUNTIME_ERROR = False
+        logger.info('%s:Environment created!', self.name)            # :132
+
+    # -- mirrors of the reference's validated properties (:544-620) --------------------------------
+    n_sim_time_steps_per_env_step = property(lambda s: s._vec.n_sim_time_steps_per_env_step)
+    max_sim_time = property(lambda s: s._vec.max_sim_time)
+    goals_list = property(lambda s: s._vec.goals_list)
+    DISCRETE_REWARD = property(lambda s: s._vec.DISCRETE_REWARD)
+    unwrapped = property(lambda s: s)
+    env = property(lambda s: s)            # examples use env.env.sim (gym TimeLimit wrapper idiom)
+
+    @property
+    def steps(self):                                                 # env_utilities.py:48-52
+        return int(self._vec.istate[1, 0]) if hasattr(self, 'sim') else 0
+
+    @property
+    def state(self):                                                 # :531-542
+        return tuple(float(v) for v in self._vec.out[:11, 0].tolist())
+
+    def reset(self):                                                 # :316-334
+        self._vec.reset()
+        self.sim = _SimView(self)
+        self._reward, self.done = 0, False
+        self.CONVERGENCE_FAILURE = self.RUNTIME_ERROR = False
+        self._time_stats = {'step': [], 'step_time': []}
+        self._reward_stats = {'step': [], 'reward': []}
+        self._action_stats = {i: 0 for i in range(5)}
+        return np.array(self.state)
+
+    def step(self, action):                                          # :138-196
+        t0 = time.time()
+        if not hasattr(self, 'sim'):
+            raise RuntimeError("call reset() before step()")
+        assert action in self.action_space, \
+            'The action "{}" is not available in the environment action space!'.format(action)   # :201
+        if self.done:                                                # :145-152: stale tuple
+            logger.warning('%s:Simulation completed - Reset environment to start new simulation!', self.name)
+            return np.array(self.state), self._reward, self.done, {}
+        self._action_stats[int(action)] += 1                         # :209
+        a = torch.tensor([int(action)], dtype=torch.uint8, device=self._vec.device)
+        _, reward, done, _ = self._vec.step(a)
+        r = float(reward[0])
+        self.done = bool(done[0])
+        status = int(self._vec.istate[3, 0])
+        self.CONVERGENCE_FAILURE = status == 2
+        self._reward = int(round(r)) if (self.DISCRETE_REWARD and status != 2) else r   # :301 / :172
+        self._reward_stats['step'].append(self.steps)
+        self._reward_stats['reward'].append(self._reward)
+        self._step_time = time.time() - t0                           # :193
+        self._time_stats['step'].append(self.steps)
+        self._time_stats['step_time'].append(self._step_time)
+        return np.array(self.state), self._reward, self.done, {}
+
+    def render(self, mode='vector'):                                 # :336-364
+        pv, sim = self.sim.PV_model, self.sim
+        obs = {'ia': pv.ia * sim.Ibase, 'Vdc': pv.Vdc * pv.Vdcbase, 'va': pv.va * sim.Vbase,
+               'Ppv': pv.Ppv * sim.Sbase, 'S_PCC': pv.S_PCC * sim.Sbase, 'Q_ref': pv.Q_ref * sim.Sbase,
+               'Vdc_ref': pv.Vdc_ref * pv.Vdcbase, 'tStart': sim.tStart}
+        line = " ".join('{}:{:.2f},'.format(k, v) for k, v in obs.items())
+        print(line)
+        print('Reward:{:.5f}'.format(self._reward))
+        print('Time for step:{:.3f}'.format(self._step_time))        # env_utilities.py:54-57
+        # mode == 'human' plots trajectories in the reference (:358-364); plotting is host-side
+        # cosmetics outside the hot path -- the vector line is printed
+        return line
+
+    def update_env_events(self, event_spec_list):                    # :413-438
+        self._vec.update_env_events(event_spec_list)
+        self.env_events_spec = self._vec.env_events_spec
+
+    def seed(self, seed=None):
+        self._vec.seed = int(seed or 0)
+        return [self._vec.seed]
+
+    def close(self):
+        self._vec.close()
+
+    def show_step_time(self):
+        print('Time for step:{:.3f}'.format(self._step_time))

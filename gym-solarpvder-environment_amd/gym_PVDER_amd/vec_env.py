@@ -1,0 +1,389 @@
+"""PVDERVec -- N independent PVDER-v0 environments stepped by ONE fused HIP launch per step.
+
+Batched host-side mirror of the reference env class
+(/root/reference/gym_PVDER/envs/PVDER_env.py:39 ``class PVDER``): same constructor arguments and
+validation (:104-125, setters :561-620), same class-level specs (:56-93), same semantics of
+``step`` (:138-196), ``action_calc`` (:198-229), ``reward_calc`` (:231-301), ``state`` (:531-542),
+``reset`` (:316-334) and ``update_env_events`` (:413-438) -- but ``actions`` is a ``[N]`` device
+tensor and observations/rewards/dones come back as device tensors.  All arithmetic of the step
+runs in csrc/pvder_kernels.hip through the C ABI of include/pvder_hip.h; this file only owns
+buffers, validates arguments and launches.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import logging
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native, der_model
+
+logger = logging.getLogger("gym_PVDER_amd")
+
+SIM_TIME_STEP = 1.0 / 60.0               # env_sim_spec['sim_time_step'], PVDER_env.py:63
+MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
+DEFAULT_MICRO = 4096                     # RK4 micro-steps per sim time step (h = 4.07 us)
+
+OBSERVED_QUANTITIES = ['iaR', 'iaI', 'vaR', 'vaI', 'P_PCC', 'Q_PCC', 'Vdc', 'Ppv', 'Vdc_ref', 'Q_ref',
+                       'tStart']         # PVDER_env.py:44-49
+
+GOAL_IDS = {'voltage_regulation': 0, 'power_regulation': 1, 'Q_regulation': 2}
+
+
+def default_events_spec() -> Dict[str, dict]:
+    """env_events_spec, PVDER_env.py:60-61 (dict order matters: insolation first)."""
+    return {'insolation': {'t_events_start': 1.0, 't_events_stop': 39.0, 't_events_step': 1.0,
+                           'min': 85.0, 'max': 100.0, 'ENABLE': False},
+            'voltage': {'t_events_start': 1.0, 't_events_stop': 39.0, 't_events_step': 1.0,
+                        'min': 0.98, 'max': 1.02, 'ENABLE': True}}
+
+
+class EnvSpecMixin:
+    """Argument validation + class-level specs shared by PVDERVec and the single-env PVDER."""
+
+    env_model_spec = {'model_1': {'DERModelType': 'SinglePhase', 'derId': '10'},
+                      'model_2': {'DERModelType': 'ThreePhaseUnbalanced', 'derId': '50'}}   # :56-58
+    env_sim_spec = {'sim_time_step': SIM_TIME_STEP,
+                    'n_sim_time_steps_per_env_step': {'default': 60, 'min': 1},
+                    'min_sim_time': 1.0}                                                  # :63-65
+    env_reward_spec = {'reward_list': {'default': ['voltage_error'],
+                                       'valid': ['voltage_error', 'power_error', 'Q_error', 'Vdc_error']},
+                       'reference_values': {'P_ref': 45.4e3, 'Q_ref': 5.5e3},
+                       'DISCRETE_REWARD': True}                                           # :67-71
+    env_action_spec = {'action_list': {'default': ['Q_control'], 'valid': ['Q_control', 'Vdc_control']},
+                       'delQref': 25, 'delVdcref': 0.02}                                  # :73-75
+    env_goal_spec = {'voltage_regulation': {'reward': {'required': ['voltage_error']},
+                                            'action': {'required': ['Q_control']}},
+                     'power_regulation': {'reward': {'required': ['power_error']},
+                                          'action': {'required': ['Vdc_control']}},
+                     'Q_regulation': {'reward': {'required': ['Q_error']},
+                                      'action': {'required': ['Q_control']}}}             # :78-93
+    default_goals = ['voltage_regulation']                                                # :95
+    max_episode_steps = MAX_EPISODE_STEPS
+
+    # -- validating setters (PVDER_env.py:561-620); same error behaviour ----------------------
+    def _set_n(self, n):
+        if n is None:
+            n = self.env_sim_spec['n_sim_time_steps_per_env_step']['default']
+        elif isinstance(n, bool) or not isinstance(n, int):
+            raise ValueError("n_sim_time_steps_per_env_step must be an integer!")          # :614
+        elif n < self.env_sim_spec['n_sim_time_steps_per_env_step']['min']:
+            logger.warning('n_sim_time_steps_per_env_step should be greater than %s!',
+                           self.env_sim_spec['n_sim_time_steps_per_env_step']['min'])     # :612
+            n = self.env_sim_spec['n_sim_time_steps_per_env_step']['min']
+        self._n = int(n)
+        self._sim_time_per_env_step = self.env_sim_spec['sim_time_step'] * self._n        # :616
+        self._delQref = self.env_action_spec['delQref'] * self._n                         # :617
+        self._delVdcref = self.env_action_spec['delVdcref'] * self._n                     # :618
+
+    def _set_max_sim_time(self, max_sim_time):
+        cap = self.max_episode_steps * self._sim_time_per_env_step
+        if max_sim_time is None:
+            t = cap                                                                       # :565
+        elif isinstance(max_sim_time, (int, float)) and not isinstance(max_sim_time, bool):
+            if max_sim_time < self.env_sim_spec['min_sim_time']:
+                t = self.env_sim_spec['min_sim_time']                                     # :568
+            elif max_sim_time > cap:
+                logger.warning('User specifed maximum simulation time is %s s, but allowable '
+                               'simulation time is only %s s!', max_sim_time, cap)        # :570
+                t = cap
+            else:
+                t = max_sim_time
+        else:
+            raise ValueError("max_sim_time must be a float!")                             # :575
+        self._max_sim_time = float(t)
+
+    def _set_goals(self, goals_list):
+        if goals_list is None:
+            goals_list = list(self.default_goals)       # the reference raises AttributeError here
+        elif not set(goals_list).issubset(self.env_goal_spec.keys()):
+            raise ValueError('Goal list:{} contains invalid elements, available elements are:{}'.format(
+                goals_list, self.env_goal_spec.keys()))                                   # :586
+        if len(goals_list) == 0:
+            raise ValueError('goals_list must name at least one goal')
+        self._goals_list = list(goals_list)
+
+    def _set_discrete(self, flag):
+        if flag is None:
+            flag = self.env_reward_spec['DISCRETE_REWARD']
+        elif not isinstance(flag, bool):
+            raise ValueError("DISCRETE_REWARD must be a boolean!")                        # :598
+        self._discrete = flag
+
+
+class PVDERVec(EnvSpecMixin):
+    """``num_envs`` PVDER-v0 environments on one MI355X.
+
+    Args (first four as the reference's ``PVDER.__init__``, PVDER_env.py:104-105):
+        goals_list, n_sim_time_steps_per_env_step, max_sim_time, DISCRETE_REWARD
+        num_envs:   N
+        device:     torch device (a ROCm GPU)
+        integrator: 'rk4' (fp32 fixed-step, default) or 'rk45' (fp64 adaptive Dormand-Prince)
+        micro_steps: RK4 steps per 1/60 s sim time step
+        auto_reset: reset finished envs inside ``step`` (their returned obs is the reset obs)
+        model_type: 'model_2' (three phase, derId 50, the PVDER-v0 default) or 'model_1'
+        seed / env_id_base: key of the on-device event generator (env_id_base = global index of
+                    env 0: results do not depend on how envs are sharded over GPUs)
+    """
+
+    observed_quantities = OBSERVED_QUANTITIES
+
+    def __init__(self, num_envs: int, goals_list=('voltage_regulation',),
+                 n_sim_time_steps_per_env_step: int = 15, max_sim_time: float = 40.0,
+                 DISCRETE_REWARD: bool = True, device="cuda", integrator: str = "rk4",
+                 micro_steps: int = DEFAULT_MICRO, auto_reset: bool = True, model_type: str = 'model_2',
+                 seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
+                 events_spec: Optional[dict] = None):
+        if not isinstance(num_envs, int) or num_envs < 1:
+            raise ValueError("num_envs must be a positive integer")
+        if integrator not in ("rk4", "rk45"):
+            raise ValueError("integrator must be 'rk4' or 'rk45'")
+        if model_type not in self.env_model_spec:
+            raise ValueError("model_type must be one of %s" % list(self.env_model_spec))
+        self.num_envs = num_envs
+        self._set_n(n_sim_time_steps_per_env_step)
+        self.max_sim_time_user = max_sim_time
+        self._set_max_sim_time(max_sim_time)
+        self._set_goals(list(goals_list) if goals_list is not None else None)
+        self._set_discrete(DISCRETE_REWARD)
+        self.integrator = integrator
+        self.micro_steps = int(micro_steps)
+        self.auto_reset = bool(auto_reset)
+        self.seed = int(seed)
+        self.env_id_base = int(env_id_base)
+        self.rtol, self.atol = float(rtol), float(atol)
+        self.env_events_spec = copy.deepcopy(events_spec) if events_spec else default_events_spec()
+        self.der_id = self.env_model_spec[model_type]['derId']
+        self.par = der_model.param_vector(self.der_id)
+        self.phases = int(self.par[0])
+        self.ns = 6 * self.phases + 5
+        self.y0 = der_model.steady_state(self.par, self.der_id)
+
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("PVDERVec runs on a ROCm GPU only (device=%s); there is no CPU path" % device)
+        self._lib = _native.lib()
+        self.fdtype = torch.float32 if integrator == "rk4" else torch.float64
+        N = num_envs
+        self._alloc_event_tables()
+        self.fstate = torch.zeros((self.ns + 2, N), dtype=self.fdtype, device=self.device)
+        self.istate = torch.zeros((4, N), dtype=torch.int32, device=self.device)
+        self.out = torch.zeros((13, N), dtype=self.fdtype, device=self.device)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator == "rk45" else None
+        self._par_c = (C.c_double * len(self.par))(*self.par)
+        self._y0_c = (C.c_double * len(self.y0))(*self.y0)
+        self._needs_reset = True
+
+    # -- properties mirroring the reference (PVDER_env.py:544-558, env_utilities.py:48-52) -------
+    @property
+    def n_sim_time_steps_per_env_step(self):
+        return self._n
+
+    @property
+    def max_sim_time(self):
+        return self._max_sim_time
+
+    @property
+    def goals_list(self):
+        return self._goals_list
+
+    @property
+    def DISCRETE_REWARD(self):
+        return self._discrete
+
+    @property
+    def steps(self) -> torch.Tensor:
+        return self.istate[1]
+
+    @property
+    def tStart(self) -> torch.Tensor:
+        return self.istate[0].to(torch.float64) * SIM_TIME_STEP
+
+    @property
+    def obs(self) -> torch.Tensor:
+        """[N, 11] view of the SoA output block (valid until the next step/reset)."""
+        return self.out[:11].t()
+
+    @property
+    def Q_ref(self) -> torch.Tensor:
+        return self.fstate[self.ns]
+
+    @property
+    def Vdc_ref(self) -> torch.Tensor:
+        return self.fstate[self.ns + 1]
+
+    # -- events ---------------------------------------------------------------------------------
+    def _event_grid(self):
+        v = self.env_events_spec['voltage']       # grid always from the 'voltage' entry (:408-410)
+        times = np.arange(v['t_events_start'], v['t_events_stop'], v['t_events_step'])
+        s0 = v['t_events_start'] * 60.0
+        ds = v['t_events_step'] * 60.0
+        if len(times) and (abs(s0 - round(s0)) > 1e-6 or abs(ds - round(ds)) > 1e-6 or round(ds) < 1):
+            logger.warning('event times are not multiples of 1/60 s: they are applied at the next '
+                           'sim time step boundary')
+        return len(times), int(math.ceil(s0 - 1e-6)), max(1, int(round(ds)))
+
+    def _alloc_event_tables(self):
+        K, s0, ds = self._event_grid()
+        self.ev_count, self.ev_s0, self.ev_ds = K, s0, ds
+        N = self.num_envs
+        self.ev_vg = torch.ones((K + 1, N), dtype=torch.float32, device=self.device)
+        self.ev_si = torch.full((K + 1, N), float(self.par[der_model.IDX["SINSOL0"]]), dtype=torch.float32,
+                                device=self.device)
+
+    def update_env_events(self, event_spec_list: List[dict]):
+        """PVDER_env.py:413-438: mutate the event spec; new random events take effect at the next
+        reset (and immediately for running episodes' tables, as the reference regenerates)."""
+        assert isinstance(event_spec_list, list), 'event_spec_list should be a list!'
+        for event_spec in event_spec_list:
+            assert isinstance(event_spec, dict), 'Event spec should be a dictionary!'
+            assert len(event_spec.keys()) == 1, 'Only one event type should be specified at at time!'
+            event_type = list(event_spec)[0]
+            if event_type not in self.env_events_spec:
+                raise ValueError('{} is not a valid event!'.format(event_type))
+            for key, val in event_spec[event_type].items():
+                if key not in self.env_events_spec[event_type]:
+                    raise ValueError('{} is not a valid paramter for {} event!'.format(key, event_type))
+                self.env_events_spec[event_type][key] = val
+        K, s0, ds = self._event_grid()
+        if (K, s0, ds) != (self.ev_count, self.ev_s0, self.ev_ds):
+            self._alloc_event_tables()
+            self._needs_reset = True
+
+    def set_event_tables(self, vgrid: torch.Tensor, sinsol: torch.Tensor):
+        """Explicit per-env event tables [K+1, N] (row 0 = nominal) -- parity runs share them
+        with the oracle.  Kept across resets until :meth:`clear_event_tables`."""
+        assert vgrid.shape == self.ev_vg.shape and sinsol.shape == self.ev_si.shape
+        self.ev_vg.copy_(vgrid)
+        self.ev_si.copy_(sinsol)
+        self._keep_events = True
+
+    def clear_event_tables(self):
+        self._keep_events = False
+
+    _keep_events = False
+
+    # -- launch plumbing --------------------------------------------------------------------------
+    def _cfg(self) -> _native.StepCfg:
+        c = _native.StepCfg()
+        c.n_sub = self._n
+        c.micro = self.micro_steps
+        c.max_ksub = int(math.ceil(self._max_sim_time * 60.0 - 1e-6))
+        c.max_steps = self.max_episode_steps
+        c.goal = GOAL_IDS[self._goals_list[0]]                 # only the first goal counts (:234)
+        c.discrete = 1 if self._discrete else 0
+        c.ev_s0, c.ev_ds, c.ev_count = self.ev_s0, self.ev_ds, self.ev_count
+        c.del_qref = self._delQref / der_model.SBASE           # :225
+        c.del_vdcref = self._delVdcref / der_model.VDCBASE     # :229
+        c.inv_max_sim_time = 1.0 / self._max_sim_time
+        c.p_target = self.env_reward_spec['reference_values']['P_ref'] / der_model.SBASE   # :245
+        c.q_target = self.env_reward_spec['reference_values']['Q_ref'] / der_model.SBASE   # :241
+        c.rtol, c.atol = self.rtol, self.atol
+        return c
+
+    def _spec(self) -> _native.EventSpec:
+        s = _native.EventSpec()
+        s.ev_count = self.ev_count
+        s.enable_voltage = 1 if self.env_events_spec['voltage']['ENABLE'] else 0
+        s.enable_insol = 1 if self.env_events_spec['insolation']['ENABLE'] else 0
+        s.v_min, s.v_max = self.env_events_spec['voltage']['min'], self.env_events_spec['voltage']['max']
+        s.s_min, s.s_max = self.env_events_spec['insolation']['min'], self.env_events_spec['insolation']['max']
+        return s
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _reset_launch(self, mask: Optional[torch.Tensor]):
+        fn = self._lib.pvder_reset_masked_f32 if self.fdtype == torch.float32 else self._lib.pvder_reset_masked_f64
+        cfg, spec = self._cfg(), self._spec()
+        rc = fn(self._par_c, self._y0_c, C.byref(cfg), C.byref(spec), self.fstate.data_ptr(),
+                self.istate.data_ptr(), self.ev_vg.data_ptr(), self.ev_si.data_ptr(),
+                mask.data_ptr() if mask is not None else None, self.out.data_ptr(),
+                C.c_uint64(self.seed & (2 ** 64 - 1)), C.c_int64(self.env_id_base),
+                1 if self._keep_events else 0, self.num_envs, self._stream())
+        _native.check(rc, "pvder_reset_masked")
+
+    # -- Gym-like API (batched) ---------------------------------------------------------------------
+    def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Reset all envs (or those with ``mask[e] != 0``); returns the [N, 11] observation view."""
+        with torch.cuda.device(self.device):
+            if mask is not None:
+                mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+                assert mask.shape == (self.num_envs,)
+            self._reset_launch(mask)
+            if self.hstep is not None:
+                if mask is None:
+                    self.hstep.zero_()
+                else:
+                    self.hstep.masked_fill_(mask.bool(), 0.0)
+        self._needs_reset = False
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        """One transition of every env.  ``actions``: [N] integer tensor with values in 0..4
+        (Discrete(5), PVDER_env.py:50).  Returns (obs[N,11], reward[N], done[N] bool, info)."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before step()")
+        if actions.shape != (self.num_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.num_envs)
+        if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        cfg = self._cfg()
+        with torch.cuda.device(self.device):
+            if self._timing:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()          # same stream the kernel is launched on (torch's current stream)
+            if self.integrator == "rk4":
+                rc = self._lib.pvder_step_rk4_f32(self._par_c, C.byref(cfg), self.fstate.data_ptr(),
+                                                  self.istate.data_ptr(), self.ev_vg.data_ptr(),
+                                                  self.ev_si.data_ptr(), actions.data_ptr(),
+                                                  self.out.data_ptr(), self.stats.data_ptr(), 1,
+                                                  self.num_envs, self._stream())
+            else:
+                rc = self._lib.pvder_step_rk45_f64(self._par_c, C.byref(cfg), self.fstate.data_ptr(),
+                                                   self.istate.data_ptr(), self.ev_vg.data_ptr(),
+                                                   self.ev_si.data_ptr(), actions.data_ptr(),
+                                                   self.out.data_ptr(), self.hstep.data_ptr(),
+                                                   self.stats.data_ptr(), 1, self.num_envs, self._stream())
+            if self._timing:
+                ev1.record()
+                self._events.append((ev0, ev1))
+            _native.check(rc, "pvder_step")
+            reward = self.out[11].clone()
+            done = self.out[12] != 0
+            if self.auto_reset:
+                # same-step auto-reset of finished envs (old-gym VectorEnv behaviour): their row of
+                # the output block is overwritten with the reset observation, reward/done keep the
+                # values of the transition that ended the episode
+                self._reset_launch(done.to(torch.uint8))
+                if self.hstep is not None:
+                    self.hstep.masked_fill_(done, 0.0)
+        return self.obs, reward, done, {}
+
+    def step_stats(self) -> Dict[str, float]:
+        """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,
+        #invalid actions -- the batched counterpart of update_reward_stats (env_utilities.py:32-38)."""
+        s = self.stats.tolist()
+        return {"reward_sum": s[0], "n_done": int(s[1]), "n_nonfinite": int(s[2]), "n_bad_action": int(s[3])}
+
+    # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------
+    _timing = False
+
+    def kernel_timing(self, on: bool = True):
+        """Bracket every step-kernel launch with HIP events on the launch stream."""
+        self._timing = bool(on)
+        self._events = []
+
+    def kernel_times_ms(self) -> List[float]:
+        """Durations of the step-kernel launches recorded since kernel_timing(True) (host sync)."""
+        torch.cuda.synchronize(self.device)
+        return [a.elapsed_time(b) for a, b in getattr(self, "_events", [])]
+
+    def close(self):
+        pass

@@ -1,0 +1,161 @@
+/* pvder_hip.h -- C ABI of the MI355X (gfx950) batched PVDER-v0 hot path.
+ *
+ * The reference (sibyjackgrove/gym-SolarPVDER-environment) is pure Python and has no FFI of
+ * its own; the boundary it offers is the Gym Env API of `PVDER-v0`
+ * (gym_PVDER/envs/PVDER_env.py:138 step, :316 reset) and, inside it, the `self.sim` /
+ * `self.sim.PV_model` attribute surface of the third-party `pvder` package.
+ * This header is what a ctypes stub inside the reference's `PVDER` class binds in place of
+ * `self.sim.run_simulation()` + `reward_calc()` + `state`.
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers are raw `void*`-compatible pointers obtained from
+ *     `tensor.data_ptr()`; `stream` is a `hipStream_t` passed as `void*` (NULL = default stream);
+ *   - every entry point is asynchronous on `stream`, performs no allocation and no host sync
+ *     (graph-capturable), and returns 0 or a negative `hipError_t`; argument errors return
+ *     PVDER_EINVAL before anything is launched;
+ *   - the caller owns every buffer.  All per-env arrays are structure-of-arrays with the env
+ *     index fastest:  row r of an [R][n_env] array starts at  base + r*n_env.
+ */
+#ifndef PVDER_HIP_H
+#define PVDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVDER_ABI_VERSION 1
+#define PVDER_EINVAL (-10001)
+
+/* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
+ * Filled by the host from config_der.json (reference: config_der.json:2-21 for derId "50",
+ * :66-84 for "10") with pvder's base values; shared by all envs of a launch (kernel argument
+ * -> SGPRs). */
+enum pvder_par {
+    PVDER_PAR_PHASES = 0, /* 3 (ThreePhaseUnbalanced, PVDER_env.py:57) or 1 (SinglePhase, :56) */
+    PVDER_PAR_RF, PVDER_PAR_LF, PVDER_PAR_C,
+    PVDER_PAR_KVG_RE, PVDER_PAR_KVG_IM, /* v_p = kvg*vg_p + kvi*i_p (stand-alone PCC-LV voltage) */
+    PVDER_PAR_KVI_RE, PVDER_PAR_KVI_IM,
+    PVDER_PAR_KP_GCC, PVDER_PAR_KI_GCC, PVDER_PAR_KP_DC, PVDER_PAR_KI_DC, PVDER_PAR_KP_Q,
+    PVDER_PAR_KI_Q, PVDER_PAR_WP, PVDER_PAR_KP_PLL, PVDER_PAR_KI_PLL, PVDER_PAR_M_LIMIT,
+    PVDER_PAR_IREF_LIMIT, PVDER_PAR_WBASE, PVDER_PAR_VG_SCALE, PVDER_PAR_VDCBASE, PVDER_PAR_SBASE,
+    PVDER_PAR_NP, PVDER_PAR_ISCR, PVDER_PAR_IRS, PVDER_PAR_PV_VT,
+    PVDER_PAR_VRMS_REF,   /* Vrmsrated/Vbase (reward, PVDER_env.py:280) */
+    PVDER_PAR_VDC_REF0,   /* Vdcmpp0/Vdcbase: Vdc_ref after reset */
+    PVDER_PAR_SINSOL0,    /* insolation before the first solar event */
+    PVDER_PAR_COUNT
+};
+
+/* ---- float state rows  [PVDER_FROWS(ns)][n_env] ------------------------------------------------
+ * rows 0..ns-1 : ODE states in pvder order (per phase iR,iI,xR,xI,uR,uI; Vdc,xDC,xQ,xPLL,delta)
+ *                where delta = wte - wbase*t is the PLL angle relative to the grid angle;
+ * row  ns      : Q_ref   (PV_model.Q_ref,   PVDER_env.py:225)
+ * row  ns+1    : Vdc_ref (PV_model.Vdc_ref, PVDER_env.py:229)
+ * ns = 23 (three phase) or 11 (single phase). */
+#define PVDER_NS(phases) (6 * (phases) + 5)
+#define PVDER_FROWS(phases) (PVDER_NS(phases) + 2)
+
+/* ---- int32 state rows  [PVDER_IROWS][n_env] */
+enum pvder_irow {
+    PVDER_I_KSUB = 0, /* sim time steps since reset: tStart = ksub/60 s (PVDER_env.py:63,180) */
+    PVDER_I_STEPS,    /* env.steps (env_utilities.py:48-52) */
+    PVDER_I_EPISODE,  /* episodes started (keys the event generator) */
+    PVDER_I_STATUS,   /* 0 running, 1 time limit reached (done), 2 non-finite state (done, reward -100) */
+    PVDER_IROWS
+};
+
+/* ---- output block  [PVDER_OROWS][n_env] float ---------------------------------------------------
+ * rows 0..10 = the 11 observations of PVDER.state (PVDER_env.py:531-542, names :44-49),
+ * row 11 = reward (PVDER_env.py:231-301), row 12 = done as 0.0/1.0.  One contiguous block so a
+ * rank's whole per-step output is one RCCL all-gather message. */
+#define PVDER_OBS_DIM 11
+#define PVDER_O_REWARD 11
+#define PVDER_O_DONE 12
+#define PVDER_OROWS 13
+
+enum pvder_goal { /* goals_list[0], PVDER_env.py:78-93, :234 */
+    PVDER_GOAL_VOLTAGE = 0, /* voltage_regulation -> voltage_error */
+    PVDER_GOAL_POWER = 1,   /* power_regulation   -> power_error   */
+    PVDER_GOAL_Q = 2        /* Q_regulation       -> Q_error       */
+};
+
+/* ---- per-launch step configuration (host struct, passed by pointer, copied at launch) */
+typedef struct pvder_step_cfg {
+    int32_t n_sub;        /* n_sim_time_steps_per_env_step (PVDER_env.py:603-620) */
+    int32_t micro;        /* RK4 micro-steps per 1/60 s sim time step (h = 1/(60*micro)) */
+    int32_t max_ksub;     /* done when ksub >= max_ksub  (tStop >= max_sim_time, :183) */
+    int32_t max_steps;    /* TimeLimit max_episode_steps (gym_PVDER/__init__.py:10); 0 = none */
+    int32_t goal;         /* enum pvder_goal */
+    int32_t discrete;     /* DISCRETE_REWARD (:253, :265, :278, :291) */
+    int32_t ev_s0;        /* ksub of the first event  (t_events_start*60) */
+    int32_t ev_ds;        /* ksub between events      (t_events_step*60)  */
+    int32_t ev_count;     /* K events; event tables have K+1 rows (row 0 = nominal) */
+    int32_t reserved;
+    double del_qref;      /* _delQref/Sbase   per env step (:617, :225) */
+    double del_vdcref;    /* _delVdcref/Vdcbase per env step (:618, :229) */
+    double inv_max_sim_time; /* obs[10] = tStart/max_sim_time (:540) */
+    double p_target;      /* P_ref/Sbase (:245) */
+    double q_target;      /* Q_ref/Sbase (:241) */
+    double rtol, atol;    /* RK45 only */
+} pvder_step_cfg;
+
+/* ---- event generator spec for reset (PVDER_env.py:60-61, :400-411) */
+typedef struct pvder_event_spec {
+    int32_t ev_count;        /* K */
+    int32_t enable_voltage;  /* env_events_spec['voltage']['ENABLE'] */
+    int32_t enable_insol;    /* env_events_spec['insolation']['ENABLE'] */
+    int32_t reserved;
+    float v_min, v_max;      /* U[min,max] pu */
+    float s_min, s_max;      /* U[min,max] insolation */
+} pvder_event_spec;
+
+int pvder_version(void);
+int pvder_par_count(void);
+
+/* Masked reset (PVDER.reset / setup_PVDER_simulation, PVDER_env.py:316-334, :366-398).
+ * For every env with mask[e] != 0 (mask == NULL: all):
+ *   fstate <- y0 (host, ns doubles, steady state in delta form), Q_ref <- 0, Vdc_ref <- par,
+ *   istate: ksub = steps = status = 0, episode += 1,
+ *   event tables ev_vg/ev_si [K+1][n_env] refilled from the counter generator keyed
+ *   (seed, env_id_base + e, episode, k) unless `keep_events` != 0 (explicit tables for parity),
+ *   out block <- reset observation (reward 0, done 0)  when `out` != NULL. */
+int pvder_reset_masked_f32(const double *par, const double *y0, const pvder_step_cfg *cfg,
+                           const pvder_event_spec *spec, float *fstate, int32_t *istate,
+                           float *ev_vg, float *ev_si, const uint8_t *mask, float *out,
+                           uint64_t seed, int64_t env_id_base, int keep_events, int n_env,
+                           void *stream);
+int pvder_reset_masked_f64(const double *par, const double *y0, const pvder_step_cfg *cfg,
+                           const pvder_event_spec *spec, double *fstate, int32_t *istate,
+                           float *ev_vg, float *ev_si, const uint8_t *mask, double *out,
+                           uint64_t seed, int64_t env_id_base, int keep_events, int n_env,
+                           void *stream);
+
+/* One env transition for n_env envs (PVDER.step, PVDER_env.py:138-196): action_calc ->
+ * integrate n_sub sim time steps -> reward_calc -> done -> state, one fused launch.
+ * fp32 fixed-step classic RK4 (cfg->micro steps per 1/60 s, Kahan-compensated state update).
+ * action: [n_env] uint8 in 0..4 (values > 4 are treated as 0 and flagged in stats[3]).
+ * Envs whose status != 0 on entry are not advanced (stale tuple, :145-152).
+ * stats (device, 4 floats, may be NULL): [0] sum of rewards, [1] #done, [2] #non-finite,
+ * [3] #invalid actions -- produced by a wave-level reduction + one atomic per wave; the
+ * caller zeroes it (or lets pvder_step_* do it: zero_stats != 0 enqueues a memset first). */
+int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, float *fstate,
+                       int32_t *istate, const float *ev_vg, const float *ev_si,
+                       const uint8_t *action, float *out, float *stats, int zero_stats,
+                       int n_env, void *stream);
+
+/* Same transition, fp64 adaptive Dormand-Prince RK45 (cfg->rtol/atol), per-env step size kept
+ * in hstep [n_env] doubles (in/out; 0 = pick an initial step). */
+int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, double *fstate,
+                        int32_t *istate, const float *ev_vg, const float *ev_si,
+                        const uint8_t *action, double *out, double *hstep, float *stats,
+                        int zero_stats, int n_env, void *stream);
+
+/* Threads per workgroup of the step kernels (bench.py reports it with the roofline). */
+int pvder_block_size(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVDER_HIP_H */
