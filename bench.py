@@ -105,7 +105,7 @@ def main():
     def one_step(i):
         env.step(actions[i])
         if dist is not None:
-            dist.all_gather_into_tensor(gathered, env.out)     # ONE collective per step (RCCL/xGMI)
+            dist.all_gather_into_tensor(gathered.view(world * 13, N), env.out)     # ONE collective per step (RCCL/xGMI)
 
     for i in range(args.warmup):
         one_step(i)
@@ -158,7 +158,10 @@ def main():
             "last_step_stats": st,
         }
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            except Exception as exc:      # the baseline is a reported side number: never lose the GPU line
+                out["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -105,7 +105,7 @@ class ModelOptions:
     rtol: float = 1e-4                # U6: LSODA tolerances of the "reference-settings" run
     atol: float = 1e-4
     hmax: float = 1.0 / 120.0
-    mxstep: int = 50
+    mxstep: int = 5000               # pvder passes mxstep=50 [recollection]; 50 aborts after some events
     wte0: float = 2.0 * math.pi       # PLL angle at reset
 
 

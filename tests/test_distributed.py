@@ -1,0 +1,60 @@
+"""CPU tests (-m "not gpu"): the N>1 path on gloo, world_size 2 -- sharding and output collation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gym_PVDER_amd.distributed import gather_outputs, global_view, shard_range
+    first, n_local = shard_range(total, rank, world)
+    # synthetic output block: entry [r, e] encodes (row, GLOBAL env id)
+    gid = torch.arange(first, first + n_local, dtype=torch.float32)
+    out_local = torch.stack([gid * 100 + r for r in range(13)])          # [13, n_local]
+    gathered = gather_outputs(out_local)
+    g = global_view(gathered)                                             # [total, 13]
+    ok = gathered.shape == (world, 13, n_local) and g.shape == (total, 13)
+    want = torch.arange(total, dtype=torch.float32)[:, None] * 100 + torch.arange(13, dtype=torch.float32)[None, :]
+    ok = ok and torch.equal(g, want)
+    # event tables keyed by GLOBAL env id: the shard's tables equal the slice of the unsharded ones
+    from helpers_dist import tables_for
+    vg_local = tables_for(first, n_local)
+    vg_all = tables_for(0, total)
+    ok = ok and np.array_equal(vg_local, vg_all[:, first:first + n_local])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gather_and_sharding(tmp_path):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 64, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_shard_range():
+    sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
+    from gym_PVDER_amd.distributed import shard_range
+    assert shard_range(524288, 3, 8) == (3 * 65536, 65536)
+    assert [shard_range(64, r, 4) for r in range(4)] == [(0, 16), (16, 16), (32, 16), (48, 16)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)

@@ -1,0 +1,165 @@
+"""-m gpu: HIP kernels against the committed golden trajectories (tests/golden/*.npz), the
+single-env API contract of the reference's own tests, and size-independent properties at
+BASELINE.json's full size (65 536 envs)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(f)[5:-4] for f in glob.glob(os.path.join(GOLD, "traj_*.npz")))
+
+FP32_TOL = 1e-4      # north_star tolerance (fp64 -> fp32): rel-L2 of the observation trajectory
+FP64_TOL = 2e-6
+
+
+def run_case(name, device, integrator, copies=64, **kw):
+    from gym_PVDER_amd.vec_env import PVDERVec
+    g = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
+    n, goal, discrete = int(g["n"]), str(g["goal"]), bool(g["discrete"])
+    env = PVDERVec(copies, device=device, n_sim_time_steps_per_env_step=n, goals_list=[goal],
+                   DISCRETE_REWARD=discrete, integrator=integrator, auto_reset=False, **kw)
+    K1 = env.ev_vg.shape[0]
+    assert K1 == len(g["vgrid"])
+    env.set_event_tables(torch.as_tensor(g["vgrid"], dtype=torch.float32, device=device)[:, None].expand(K1, copies).contiguous(),
+                         torch.as_tensor(g["sinsol"], dtype=torch.float32, device=device)[:, None].expand(K1, copies).contiguous())
+    obs = [env.reset().cpu().numpy().astype(np.float64)]
+    rew, done = [], []
+    for a in g["actions"]:
+        o, r, d, _ = env.step(torch.full((copies,), int(a), dtype=torch.uint8, device=device))
+        obs.append(o.cpu().numpy().astype(np.float64)); rew.append(r.cpu().numpy()); done.append(d.cpu().numpy())
+    return g, np.stack(obs), np.stack(rew), np.stack(done), env
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_rk4_f32_vs_golden(gpu_device, name):
+    g, obs, rew, done, env = run_case(name, gpu_device, "rk4")
+    assert np.array_equal(obs[:, :1].repeat(obs.shape[1], 1), obs)      # identical envs -> identical outputs
+    err = rel_l2(obs[:, 0], g["obs"])
+    assert err < FP32_TOL, "rel-L2 %.3e" % err
+    assert np.array_equal(done[:, 0], g["done"])
+    if bool(g["discrete"]):
+        # exact except when the golden sits within 1e-6 (relative) of a reward threshold
+        bad = rew[:, 0] != g["reward"]
+        assert bad.mean() <= 0.05, (name, np.nonzero(bad)[0])
+    else:
+        assert np.abs(rew[:, 0] - g["reward"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["random_both_n4", "qup_volt_n15"])
+def test_rk45_f64_vs_golden(gpu_device, name):
+    g, obs, rew, done, env = run_case(name, gpu_device, "rk45", copies=64, rtol=1e-8, atol=1e-11)
+    err = rel_l2(obs[:, 0], g["obs"])
+    assert err < FP64_TOL, "rel-L2 %.3e" % err
+    assert np.array_equal(rew[:, 0], g["reward"]) and np.array_equal(done[:, 0], g["done"])
+
+
+# ---- the reference's own tests (gym_PVDER/tests/test_gym_PVDER.py), on the HIP-backed single env
+def test_make_and_env_contract(gpu_device):
+    import gym_PVDER_amd as gp
+    from gym_PVDER_amd.envs import PVDER
+    env = gp.make('PVDER-v0')
+    assert env.spec.id == 'PVDER-v0' and isinstance(env.unwrapped, PVDER)          # test :11-14
+    ob = env.reset()
+    assert env.observation_space.contains(ob.astype(np.float32)) and ob.shape == (11,)
+    a = env.action_space.sample()
+    ob, reward, done, info = env.step(a)
+    assert env.observation_space.contains(ob.astype(np.float32))
+    assert np.isscalar(reward) and isinstance(done, bool) and info == {}            # test :34-35
+    for mode in env.metadata.get('render.modes', []):
+        env.render(mode=mode)
+    assert isinstance(env.env.sim.PV_model.Q_ref, float)                             # examples/...import_test.py:38
+    with pytest.raises(AssertionError):
+        env.step(7)                                                                  # PVDER_env.py:201
+    env.close()
+
+
+def test_reward_python_types(gpu_device):
+    import gym_PVDER_amd as gp
+    env = gp.make('PVDER-v0', DISCRETE_REWARD=True, goals_list=['voltage_regulation'])
+    env.reset()
+    for _ in range(3):
+        _, r, _, _ = env.step(env.action_space.sample())
+        assert isinstance(r, int)                                                    # test :66
+    env = gp.make('PVDER-v0', DISCRETE_REWARD=False, goals_list=['voltage_regulation'])
+    env.reset()
+    for _ in range(3):
+        _, r, _, _ = env.step(env.action_space.sample())
+        assert isinstance(r, float)                                                  # test :81
+
+
+def test_time_steps_known_answer(gpu_device):
+    """test_gym_PVDER.py:87-111 -- n=10, max_sim_time=25: exactly 150 steps, last obs[10] == 1."""
+    import gym_PVDER_amd as gp
+    env = gp.make('PVDER-v0', n_sim_time_steps_per_env_step=10, max_sim_time=25.0)
+    ob = env.reset()
+    assert env.n_sim_time_steps_per_env_step == 10 and env.max_sim_time == 25.0
+    done, steps = False, 0
+    while not done:
+        ob, r, done, _ = env.step(env.action_space.sample())
+        steps += 1
+        assert steps <= 500
+    assert steps == 150
+    assert round(env.steps * env.n_sim_time_steps_per_env_step * env.sim.tInc, 6) == round(env.max_sim_time, 6)
+    assert round(ob[-1] * env.max_sim_time, 6) == round(env.max_sim_time, 6)
+    ob2, r2, d2, _ = env.step(0)
+    assert d2 and np.array_equal(ob2, ob) and r2 == r                                # stale tuple (:145-152)
+
+
+def test_update_env_events(gpu_device):
+    """test_gym_PVDER.py:114-133."""
+    import gym_PVDER_amd as gp
+    env = gp.make('PVDER-v0')
+    env.update_env_events(event_spec_list=[{'voltage': {'min': 0.95}}])
+    env.reset()
+    assert env.env_events_spec['voltage']['min'] == 0.95
+    assert env.sim.simulation_events._events_spec['voltage']['min'] == 0.95
+    vg = env._vec.ev_vg.cpu().numpy()
+    assert vg[1:].min() < 0.98 and vg.min() >= 0.95
+    with pytest.raises(ValueError):
+        env.update_env_events([{'voltage': {'bogus': 1}}])
+    with pytest.raises(ValueError):
+        env.update_env_events([{'wind': {'min': 1}}])
+
+
+# ---- full-size properties (BASELINE configs[2]: 65 536 envs, events on)
+def test_full_size_properties(gpu_device):
+    from gym_PVDER_amd.vec_env import PVDERVec, default_events_spec
+    spec = default_events_spec()
+    spec['insolation']['ENABLE'] = True
+    spec['voltage']['t_events_start'] = spec['insolation']['t_events_start'] = 0.1
+    N, n_sub, micro = 65536, 6, 4096
+    kw = dict(n_sim_time_steps_per_env_step=n_sub, micro_steps=micro, seed=99, events_spec=spec, max_sim_time=1.0)
+    full = PVDERVec(N, device=gpu_device, **kw)
+    half = [PVDERVec(N // 2, device=gpu_device, env_id_base=b, **kw) for b in (0, N // 2)]
+    full.reset(); [h.reset() for h in half]
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(5)
+    n_done = 0
+    for t in range(12):
+        a = torch.randint(0, 5, (N,), generator=gen, device=gpu_device, dtype=torch.uint8)
+        obs, rew, done, _ = full.step(a)
+        outs = [h.step(a[i * N // 2:(i + 1) * N // 2].contiguous()) for i, h in enumerate(half)]
+        # sharding invariance: two shards keyed by global env id == the unsharded batch, bit for bit
+        assert torch.equal(obs, torch.cat([o[0] for o in outs]))
+        assert torch.equal(rew, torch.cat([o[1] for o in outs])) and torch.equal(done, torch.cat([o[2] for o in outs]))
+        st = full.step_stats()
+        # wave-level reduction == plain reduction (integers: exact in fp32)
+        assert st["reward_sum"] == float(rew.sum()) and st["n_done"] == int(done.sum())
+        assert st["n_nonfinite"] == 0 and st["n_bad_action"] == 0
+        assert bool(torch.isfinite(obs).all()) and float(obs.abs().max()) < 10.0     # Box(-10, 10)
+        n_done += int(done.sum())
+    # max_sim_time = 1 s = 60 sim steps = 10 env steps: every env finished exactly once and was auto-reset
+    assert n_done == N
+    assert int(full.istate[2].min()) == 2 and int(full.istate[2].max()) == 2         # episode counters
+    assert int(full.steps.max()) == 2
+    # envs differ (independent event streams) ...
+    assert float(obs[:, 2].std()) > 0
+    # ... and an invalid action is counted, not executed
+    a = torch.zeros(N, dtype=torch.uint8, device=gpu_device); a[:7] = 9
+    full.step(a)
+    assert full.step_stats()["n_bad_action"] == 7

@@ -1,0 +1,136 @@
+"""CPU tests (-m "not gpu"): host logic of the env mirror, the C ABI surface, the registry."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_param_vector_matches_oracle():
+    from gym_PVDER_amd import der_model
+    from oracle import bridge, pvder_model as pm
+    for der in ("50", "10"):
+        m = pm.build_model(der)
+        par = der_model.param_vector(der)
+        assert np.array_equal(par[:27], bridge.pack_params(m))
+        assert par[der_model.IDX["VRMS_REF"]] == m.Vrms_ref and par[der_model.IDX["VDC_REF0"]] == m.Vdc_ref0
+        y0 = der_model.steady_state(par, der)
+        assert np.abs(y0 - pm.steady_state(m)).max() < 1e-12
+    with pytest.raises(ValueError):
+        der_model.param_vector("999")
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "pvder_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pvder_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports exactly what include/pvder_hip.h declares."""
+    import torch  # noqa: F401  (same load order as the product: torch's HIP runtime first)
+    from gym_PVDER_amd import _native
+    path = _native.build_native()
+    L = ctypes.CDLL(path)
+    declared = header_functions()
+    assert declared == sorted(_native.SYMBOLS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.pvder_version() == 1
+    from gym_PVDER_amd import der_model
+    assert L.pvder_par_count() == len(der_model.PAR)
+    assert L.pvder_block_size() % 64 == 0
+
+
+def test_ctypes_structs_match_header_layout(tmp_path):
+    """sizeof/offsetof of the two host structs as gcc sees the header == the ctypes mirrors."""
+    from gym_PVDER_amd import _native
+    src = tmp_path / "lay.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pvder_hip.h"\nint main(){'
+                   'printf("%zu %zu %zu %zu %zu %zu %d\\n", sizeof(pvder_step_cfg), offsetof(pvder_step_cfg, del_qref),'
+                   'offsetof(pvder_step_cfg, atol), sizeof(pvder_event_spec), offsetof(pvder_event_spec, v_min),'
+                   'offsetof(pvder_event_spec, s_max), (int)PVDER_PAR_COUNT);return 0;}')
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    S, E = _native.StepCfg, _native.EventSpec
+    assert vals[:6] == [ctypes.sizeof(S), S.del_qref.offset, S.atol.offset, ctypes.sizeof(E), E.v_min.offset, E.s_max.offset]
+    from gym_PVDER_amd import der_model
+    assert vals[6] == len(der_model.PAR)
+
+
+def test_argument_validation_mirrors_reference_setters():
+    """PVDER_env.py:561-620: ValueError for bad kwargs, clamps with the same bounds."""
+    from gym_PVDER_amd.vec_env import EnvSpecMixin, PVDERVec
+
+    class E(EnvSpecMixin):
+        pass
+    e = E()
+    e._set_n(15)
+    assert e._sim_time_per_env_step == pytest.approx(0.25) and e._delQref == 375 and e._delVdcref == pytest.approx(0.3)
+    e._set_max_sim_time(40.0)
+    assert e._max_sim_time == 40.0
+    e._set_max_sim_time(1e9)
+    assert e._max_sim_time == pytest.approx(500 * 0.25)          # :569-571
+    e._set_max_sim_time(0.1)
+    assert e._max_sim_time == 1.0                                 # :567-568
+    e._set_max_sim_time(None)
+    assert e._max_sim_time == pytest.approx(125.0)               # :565
+    e._set_n(0)
+    assert e._n == 1                                              # clamped with a warning (:608-612)
+    e._set_n(None)
+    assert e._n == 60                                             # class default (:64, :606)
+    for bad in (1.5, "3", True):
+        with pytest.raises(ValueError):
+            e._set_n(bad)                                         # :614
+    with pytest.raises(ValueError):
+        e._set_max_sim_time("40")                                 # :575
+    with pytest.raises(ValueError):
+        e._set_discrete(1)                                        # :598
+    with pytest.raises(ValueError):
+        e._set_goals(["voltage_regulation", "fly"])               # :586
+    e._set_goals(None)
+    assert e._goals_list == ["voltage_regulation"]
+    # PVDERVec validates BEFORE touching the device; without a GPU it then refuses to fall back
+    with pytest.raises(ValueError):
+        PVDERVec(0)
+    with pytest.raises(ValueError):
+        PVDERVec(4, integrator="euler")
+    with pytest.raises(ValueError):
+        PVDERVec(4, DISCRETE_REWARD="yes")
+    with pytest.raises(RuntimeError):
+        PVDERVec(4, device="cpu")                                 # no CPU fallback for the step path
+
+
+def test_registry_mirrors_gym_registration():
+    import gym_PVDER_amd as g
+    s = g.spec("PVDER-v0")
+    assert s.id == "PVDER-v0" and s.max_episode_steps == 500      # gym_PVDER/__init__.py:4,10
+    assert s.kwargs == {'n_sim_time_steps_per_env_step': 15, 'max_sim_time': 40.0, 'DISCRETE_REWARD': True,
+                        'goals_list': ['voltage_regulation']}       # gym_PVDER/__init__.py:6-9
+    with pytest.raises(KeyError):
+        g.spec("PVDER-v1")
+
+
+def test_spaces_fallback():
+    from gym_PVDER_amd.spaces import Box, Discrete
+    d, b = Discrete(5, seed=0), Box(-10, 10, (11,), np.float32)
+    assert all(d.contains(d.sample()) for _ in range(20)) and not d.contains(5) and not d.contains(1.0) and 3 in d
+    assert b.contains(np.zeros(11, dtype=np.float32)) and not b.contains(np.full(11, 11.0)) and not b.contains(np.zeros(10))
+    assert not b.contains(np.full(11, np.nan))
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "gym-solarpvder-environment_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "scipy" not in txt, f
