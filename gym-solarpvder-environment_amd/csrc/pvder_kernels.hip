@@ -11,9 +11,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "pvder_hip.h"
 #include "pvder_model.hpp"
+#include "pvder_model_pk.hpp"
 
 namespace {
 
@@ -205,6 +207,135 @@ __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
     // ---- wave-level reduction of the step statistics, one atomic per wave
     if (stats) {
         const float r = wave_sum(run ? (float)reward : 0.f);
+        const float d = wave_sum(run && status != 0 ? 1.f : 0.f);
+        const float nf = wave_sum(nonfinite);
+        const float ba = wave_sum(live ? bad_action : 0.f);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats[0], r);
+            if (d != 0.f) atomicAdd(&stats[1], d);
+            if (nf != 0.f) atomicAdd(&stats[2], nf);
+            if (ba != 0.f) atomicAdd(&stats[3], ba);
+        }
+    }
+}
+
+// =============================================================================================
+// fused env transition, fixed-step RK4, three-phase fp32, packed-VALU formulation (the hot kernel)
+// =============================================================================================
+__global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
+    const ModelK<float> P, const StepK<float> C, float *__restrict__ fstate, int32_t *__restrict__ istate,
+    const float *__restrict__ ev_vg, const float *__restrict__ ev_si,
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
+    using pvder::v2;
+    constexpr int NS = 23, NP = pvder::NP;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = e < n_env;
+    const int ec = live ? e : n_env - 1;
+    const size_t N = (size_t)n_env;
+
+    int ksub = istate[PVDER_I_KSUB * N + ec];
+    int steps = istate[PVDER_I_STEPS * N + ec];
+    int status = istate[PVDER_I_STATUS * N + ec];
+    const bool run = live && status == 0;
+
+    v2 y[NP], comp[NP];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        y[k] = pvder::mk2(fstate[(size_t)(2 * k) * N + ec], fstate[(size_t)(2 * k + 1) * N + ec]);
+        comp[k] = pvder::bc2(0.f);
+    }
+    y[11] = pvder::mk2(fstate[(size_t)22 * N + ec], 0.f);
+    comp[11] = pvder::bc2(0.f);
+    float qref = fstate[(size_t)NS * N + ec];
+    float vdcref = fstate[(size_t)(NS + 1) * N + ec];
+
+    const int a = action[ec];
+    float bad_action = 0.f;
+    if (a == 1) qref += C.dq;
+    else if (a == 2) qref -= C.dq;
+    else if (a == 3) vdcref += C.dv;
+    else if (a == 4) vdcref -= C.dv;
+    else if (a != 0) bad_action = 1.f;
+
+    const float h = (float)(1.0 / 60.0) / (float)C.micro;
+    const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+    const v2 two = pvder::bc2(2.f);
+    const float tq = 2.f / (float)C.micro;
+    const pvder::PkConst K = pvder::make_pkconst(P);
+
+    pvder::SubPk S;
+    if (run) {
+        for (int s = 0; s < C.n_sub; ++s) {
+            const int row = event_row(ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            pvder::make_sub_pk(P, ev_vg[(size_t)row * N + ec], ev_si[(size_t)row * N + ec], S);
+            for (int j = 0; j < C.micro; ++j) {
+                v2 k[NP], ks[NP], yt[NP];
+                const float t0 = (float)j * tq, t1 = ((float)j + 0.5f) * tq, t2 = ((float)j + 1.f) * tq;
+                pvder::rhs_pk(P, K, S, y, t0, qref, vdcref, k);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { ks[q] = k[q]; yt[q] = pvder::fma2(h2, k[q], y[q]); }
+                pvder::rhs_pk(P, K, S, yt, t1, qref, vdcref, k);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { ks[q] = pvder::fma2(two, k[q], ks[q]); yt[q] = pvder::fma2(h2, k[q], y[q]); }
+                pvder::rhs_pk(P, K, S, yt, t1, qref, vdcref, k);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { ks[q] = pvder::fma2(two, k[q], ks[q]); yt[q] = pvder::fma2(h1, k[q], y[q]); }
+                pvder::rhs_pk(P, K, S, yt, t2, qref, vdcref, k);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    // Kahan-compensated update (DESIGN.md "fp32 hazards")
+                    const v2 inc = pvder::fma2(h6, ks[q] + k[q], -comp[q]);
+                    const v2 tsum = y[q] + inc;
+                    comp[q] = (tsum - y[q]) - inc;
+                    y[q] = tsum;
+                }
+            }
+        }
+        ksub += C.n_sub;
+        steps += 1;
+    }
+
+    // ---- epilogue (scalar form, once per step)
+    float ys[NS];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { ys[2 * k] = y[k].x; ys[2 * k + 1] = y[k].y; }
+    ys[22] = y[11].x;
+    SubK<float, 3> S1;
+    {
+        const int row = event_row(ksub, C.ev_s0, C.ev_ds, C.ev_count);
+        pvder::make_sub<float, 3>(P, ev_vg[(size_t)row * N + ec], ev_si[(size_t)row * N + ec], S1);
+    }
+    float iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
+    pvder::outputs<float, 3>(P, S1, ys, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
+    float reward = reward_of<float>(C, P, vrms, Ppcc, Qpcc);
+    float chk = 0.f;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) chk += fabsf(ys[q]);
+    float nonfinite = 0.f;
+    if (run) {
+        if (!(chk < 1e30f)) {
+            status = 2; reward = -100.f; nonfinite = 1.f;
+        } else if (ksub >= C.max_ksub || (C.max_steps > 0 && steps >= C.max_steps)) {
+            status = 1;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) fstate[(size_t)q * N + e] = ys[q];
+        fstate[(size_t)NS * N + e] = qref;
+        fstate[(size_t)(NS + 1) * N + e] = vdcref;
+        istate[PVDER_I_KSUB * N + e] = ksub;
+        istate[PVDER_I_STEPS * N + e] = steps;
+        istate[PVDER_I_STATUS * N + e] = status;
+        out[0 * N + e] = iaR;   out[1 * N + e] = iaI;
+        out[2 * N + e] = vaR;   out[3 * N + e] = vaI;
+        out[4 * N + e] = Ppcc;  out[5 * N + e] = Qpcc;
+        out[6 * N + e] = ys[18];     out[7 * N + e] = ppv;
+        out[8 * N + e] = vdcref;     out[9 * N + e] = qref;
+        out[10 * N + e] = (float)ksub * (float)(1.0 / 60.0) * C.inv_tmax;
+        out[PVDER_O_REWARD * N + e] = reward;
+        out[PVDER_O_DONE * N + e] = status != 0 ? 1.f : 0.f;
+    }
+    if (stats) {
+        const float r = wave_sum(run ? reward : 0.f);
         const float d = wave_sum(run && status != 0 ? 1.f : 0.f);
         const float nf = wave_sum(nonfinite);
         const float ba = wave_sum(live ? bad_action : 0.f);
@@ -569,7 +700,12 @@ int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, float *fsta
         if (e != hipSuccess) return hip_rc(e);
     }
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    if (ph == 3)
+    // PVDER_RK4_VARIANT=generic selects the un-packed template (A/B runs); default = packed kernel
+    static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
+    if (ph == 3 && !generic)
+        hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si, action, out,
+                           stats, n_env);
+    else if (ph == 3)
         hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si,
                            action, out, stats, n_env);
     else
