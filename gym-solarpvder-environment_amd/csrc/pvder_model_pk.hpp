@@ -86,26 +86,29 @@ __device__ __forceinline__ void rhs_pk(const ModelK<float> &P, const PkConst &K,
     Math<float>::sincos_turns(th2t + dturn, s2, c2);
     const v2 sb = ib + ic, db = ib - ic;
     const v2 base = fma2(bc2(-0.5f), sb, ia);
-    const v2 rdb = jmul(db) * bc2(kHalfSqrt3);
+    const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);      // j*s3 as a lane-sign pattern on the swapped operand
+    const v2 rdb = swp(db) * jh3;
     const v2 i1 = base + rdb, i2 = base - rdb;                          // 3*I1, 3*I2
-    v2 V1 = fma2(bc2(P.kvi3R), i1, S.A0); V1 = fma2(bc2(P.kvi3I), jmul(i1), V1);
-    v2 V2 = bc2(P.kvi3R) * i2;            V2 = fma2(bc2(P.kvi3I), jmul(i2), V2);
+    const v2 jk3 = mk2(-P.kvi3I, P.kvi3I);
+    v2 V1 = fma2(bc2(P.kvi3R), i1, S.A0); V1 = fma2(jk3, swp(i1), V1);
+    // conj(V2) = conj(kvi/3) conj(3 I2), formed directly so that no lane needs a sign flip
+    v2 V2c = mk2(P.kvi3R, -P.kvi3R) * i2; V2c = fma2(bc2(-P.kvi3I), swp(i2), V2c);
     const v2 t1 = V1 * mk2(c1, s1);
-    const v2 t2 = fma2(V2, mk2(c2, -s2), t1);
+    const v2 t2 = fma2(V2c, mk2(c2, s2), t1);         // Re(V1 e^{-j d}) + Re(conj(V2) e^{-j(2th+d)})
     const float vd = t2.x + t2.y;
     const float dw = P.KpP * vd + xPLL;               // we - wbase
     const float wr = 1.0f + dw * P.iwb;
     // filter currents
     const v2 cm = bc2(K.hiLf * Vdc);
-    const float ZI = K.zi0 + wr;
-    const v2 zv = mk2(ZI, -ZI), nzr = bc2(-K.ZR);
+    const v2 zv = fma2(bc2(wr), mk2(1.f, -1.f), mk2(K.zi0, -K.zi0));   // (Im Z, -Im Z)
+    const v2 nzr = bc2(-K.ZR);
     v2 da = fma2(cm, ma, S.D[0]); da = fma2(nzr, ia, da); da = fma2(zv, swp(ia), da);
     v2 dbb = fma2(cm, mb, S.D[1]); dbb = fma2(nzr, ib, dbb); dbb = fma2(zv, swp(ib), dbb);
     v2 dc = fma2(cm, mc, S.D[2]); dc = fma2(nzr, ic, dc); dc = fma2(zv, swp(ic), dc);
     // current controller
     const v2 wra = mk2(P.wp * iarR, P.wp * iarI);
     const v2 hw = bc2(-0.5f) * wra;
-    const v2 jw = jmul(wra) * bc2(kHalfSqrt3);        // j*s3*wra
+    const v2 jw = swp(wra) * jh3;                     // j*s3*wra
     const v2 wrb = hw - jw;                           // wra * e^{-j120}
     const v2 wrc = hw + jw;                           // wra * e^{+j120}
     const v2 nwp = bc2(-P.wp), kig = bc2(P.KiG);
