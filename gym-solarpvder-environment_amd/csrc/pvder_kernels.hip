@@ -2,16 +2,24 @@
 // PVDER-v0 hot path.  One env per lane; structure-of-arrays state in HBM (env index fastest, so
 // every global access of a wave is one fully coalesced 256-byte row segment); model constants in
 // SGPRs (kernel argument); the whole env transition
-//     action_calc -> n_sub x micro RK4 steps -> reward_calc -> done -> state
-// (PVDER_env.py:138-196, :198-229, :231-301, :531-542) is ONE launch with the 23 states held in
-// registers for the entire step; wave-level DPP reduction + one atomic per wave for the
+//     action_calc -> integrate n_sub sim time steps -> reward_calc -> done -> state [-> auto-reset]
+// (PVDER_env.py:138-196, :198-229, :231-301, :531-542, :316-334) is ONE launch with the 23 states
+// held in registers for the entire step; wave-level reduction + one atomic per wave for the
 // reward-sum / done-count statistics (env_utilities.py:32-38 aggregate).
+//
+// Integrators (fixed per launch, selected by the entry point):
+//   step_etdrk4_kernel   fp32  exponential-time-differencing RK4 (Krogstad): the stiff current
+//                              loop (i_p,u_p) is propagated exactly, everything else is classic RK4
+//   step_rk4_pk_kernel   fp32  classic RK4 micro-stepping, packed-VALU three-phase form
+//   step_rk4_kernel<T,PH>      classic RK4 micro-stepping, generic (single phase / A-B reference)
+//   step_rk45_kernel<T,PH> fp64 adaptive Dormand-Prince 5(4)
 //
 // No MFMA: there is no dense contraction in this path (per-env 23-state nonlinear ODE).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <complex>
 
 #include "pvder_hip.h"
 #include "pvder_model.hpp"
@@ -21,13 +29,23 @@ namespace {
 
 using pvder::ModelK;
 using pvder::SubK;
+using pvder::v2;
 
 constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
 
 template <typename T>
 struct StepK {
-    int n_sub, micro, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count;
+    int n_sub, micro, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it;
     T dq, dv, inv_tmax, p_t, q_t, rtol, atol;
+};
+
+// in-kernel (auto-)reset arguments (by value; y0 in double so both precisions share it)
+struct ResetK {
+    int enabled, keep_events;
+    uint64_t seed;
+    int64_t env_id_base;
+    pvder_event_spec spec;
+    double y0[23];
 };
 
 // ---- counter-based event generator: bit-identical to oracle/pvder_model.py::counter_uniform
@@ -54,6 +72,30 @@ __device__ __forceinline__ float lerp_unfused(float lo, float hi, float u) {
     return lo + p;
 }
 
+// create_random_events (PVDER_env.py:400-411): one event per grid time, type drawn from the ENABLEd
+// list (dict order: insolation, voltage -- :60-61), value U[min,max]; rows k = 0..K of env e
+__device__ __forceinline__ void fill_events(const pvder_event_spec &spec, float sinsol0, uint64_t seed,
+                                         uint64_t gid, uint64_t episode, float *__restrict__ ev_vg,
+                                         float *__restrict__ ev_si, size_t N, int e) {
+    float vg = 1.0f, si = sinsol0;
+    ev_vg[e] = vg;
+    ev_si[e] = si;
+    const int n_en = (spec.enable_insol != 0) + (spec.enable_voltage != 0);
+    for (int k = 1; k <= spec.ev_count; ++k) {
+        if (n_en > 0) {
+            const float ut = counter_uniform(seed, gid, episode, k, 0);
+            const float uv = counter_uniform(seed, gid, episode, k, 1);
+            int pick = (int)(ut * (float)n_en);
+            if (pick > n_en - 1) pick = n_en - 1;
+            const bool is_insol = spec.enable_insol && (pick == 0);
+            if (is_insol) si = lerp_unfused(spec.s_min, spec.s_max, uv);
+            else vg = lerp_unfused(spec.v_min, spec.v_max, uv);
+        }
+        ev_vg[(size_t)k * N + e] = vg;
+        ev_si[(size_t)k * N + e] = si;
+    }
+}
+
 // event-table row active at sim-time-step g (events at ksub = s0 + j*ds, j = 0..K-1; an event
 // at exactly g is already active: grid_events(t) returns the latest event with T <= t)
 __device__ __forceinline__ int event_row(int g, int s0, int ds, int K) {
@@ -62,7 +104,7 @@ __device__ __forceinline__ int event_row(int g, int s0, int ds, int K) {
     return j > K ? K : j;
 }
 
-// ---- wave64 sum via DPP row/bank shifts (no LDS), result valid in lane 63 -> broadcast by readlane
+// ---- wave64 all-reduce sum by butterfly shuffles (no LDS allocation, no barrier)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -90,67 +132,165 @@ __device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T 
     return err <= lo ? (T)1 : (err >= hi ? (T)-5 : (T)-1);
 }
 
+// ---- per-lane bookkeeping shared by every step kernel
+template <typename T>
+struct Lane {
+    int e, ec;
+    bool live, run;
+    int ksub, steps, status;
+    T qref, vdcref;
+    float bad_action;
+};
+
+template <typename T, int NS>
+__device__ __forceinline__ void prologue(const StepK<T> &C, const T *__restrict__ fstate,
+                                         const int32_t *__restrict__ istate,
+                                         const uint8_t *__restrict__ action, int n_env, Lane<T> &L, T *y) {
+    const size_t N = (size_t)n_env;
+    L.e = blockIdx.x * kBlock + threadIdx.x;
+    L.live = L.e < n_env;
+    L.ec = L.live ? L.e : n_env - 1;               // clamp: tail lanes recompute env n-1, never store
+    L.ksub = istate[PVDER_I_KSUB * N + L.ec];
+    L.steps = istate[PVDER_I_STEPS * N + L.ec];
+    L.status = istate[PVDER_I_STATUS * N + L.ec];
+    L.run = L.live && L.status == 0;               // finished envs return the stale tuple (:145-152)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) y[k] = fstate[(size_t)k * N + L.ec];
+    L.qref = fstate[(size_t)NS * N + L.ec];
+    L.vdcref = fstate[(size_t)(NS + 1) * N + L.ec];
+    // ---- action_calc (PVDER_env.py:198-229)
+    const int a = action[L.ec];
+    L.bad_action = 0.f;
+    if (a == 1) L.qref += C.dq;
+    else if (a == 2) L.qref -= C.dq;
+    else if (a == 3) L.vdcref += C.dv;
+    else if (a == 4) L.vdcref -= C.dv;
+    else if (a != 0) L.bad_action = 1.f;
+}
+
+template <typename T>
+__device__ __forceinline__ void write_obs(T *__restrict__ out, size_t N, int e, T iaR, T iaI, T vaR, T vaI,
+                                          T Ppcc, T Qpcc, T Vdc, T ppv, T vdcref, T qref, T tfrac) {
+    out[0 * N + e] = iaR;   out[1 * N + e] = iaI;
+    out[2 * N + e] = vaR;   out[3 * N + e] = vaI;
+    out[4 * N + e] = Ppcc;  out[5 * N + e] = Qpcc;
+    out[6 * N + e] = Vdc;   out[7 * N + e] = ppv;
+    out[8 * N + e] = vdcref; out[9 * N + e] = qref;
+    out[10 * N + e] = tfrac;                       // tStart/max_sim_time (:540)
+}
+
+// epilogue: reward_calc / done / state at (y(tStop), tStop); optional same-step auto-reset of the
+// envs that just finished (PVDER.reset, :316-334); stores; wave-reduced statistics
+template <typename T, int PH, bool AR = true>
+__device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, const ResetK &R, Lane<T> &L,
+                                         T *y, T *__restrict__ fstate, int32_t *__restrict__ istate,
+                                         float *__restrict__ ev_vg, float *__restrict__ ev_si,
+                                         T *__restrict__ out, float *__restrict__ stats, int n_env) {
+    constexpr int NS = 6 * PH + 5;
+    const size_t N = (size_t)n_env;
+    const int ec = L.ec;
+    SubK<T, PH> S;
+    {
+        const int row = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count);
+        pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + ec], (T)ev_si[(size_t)row * N + ec], S);
+    }
+    T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
+    pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
+    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc);
+    T chk = (T)0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) chk += fabs(y[q]);
+    float nonfinite = 0.f, done_f = 0.f;
+    if (L.run) {
+        if (!(chk < (T)1e30)) {                    // NaN/Inf: CONVERGENCE_FAILURE branch (:169-172)
+            L.status = 2; reward = (T)-100; nonfinite = 1.f;
+        } else if (L.ksub >= C.max_ksub || (C.max_steps > 0 && L.steps >= C.max_steps)) {
+            L.status = 1;                          // tStop >= max_sim_time (:183) / TimeLimit
+        }
+        const int e = L.e;
+        done_f = L.status != 0 ? 1.f : 0.f;
+        T Vdc = y[6 * PH];
+        T tfrac = (T)L.ksub * (T)(1.0 / 60.0) * C.inv_tmax;
+        if (AR && R.enabled && L.status != 0) {
+            // same-step auto-reset: reward/done rows keep the transition that ended the episode,
+            // the observation rows and the carried state restart from the steady state
+            const int episode = istate[PVDER_I_EPISODE * N + e] + 1;
+            istate[PVDER_I_EPISODE * N + e] = episode;
+            if (!R.keep_events)
+                fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + e), (uint64_t)episode,
+                            ev_vg, ev_si, N, e);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) y[q] = (T)R.y0[q];
+            L.qref = (T)0;
+            L.vdcref = P.vdc_ref0;
+            L.ksub = 0; L.steps = 0; L.status = 0;
+            pvder::make_sub<T, PH>(P, (T)ev_vg[e], (T)ev_si[e], S);
+            pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
+            Vdc = y[6 * PH];
+            tfrac = (T)0;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) fstate[(size_t)q * N + e] = y[q];
+        fstate[(size_t)NS * N + e] = L.qref;
+        fstate[(size_t)(NS + 1) * N + e] = L.vdcref;
+        istate[PVDER_I_KSUB * N + e] = L.ksub;
+        istate[PVDER_I_STEPS * N + e] = L.steps;
+        istate[PVDER_I_STATUS * N + e] = L.status;
+        write_obs<T>(out, N, e, iaR, iaI, vaR, vaI, Ppcc, Qpcc, Vdc, ppv, L.vdcref, L.qref, tfrac);
+        out[PVDER_O_REWARD * N + e] = reward;
+        out[PVDER_O_DONE * N + e] = (T)done_f;
+    }
+    // ---- wave-level reduction of the step statistics, one atomic per wave
+    if (stats) {
+        const float r = wave_sum(L.run ? (float)reward : 0.f);
+        const float d = wave_sum(done_f);
+        const float nf = wave_sum(nonfinite);
+        const float ba = wave_sum(L.live ? L.bad_action : 0.f);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats[0], r);
+            if (d != 0.f) atomicAdd(&stats[1], d);
+            if (nf != 0.f) atomicAdd(&stats[2], nf);
+            if (ba != 0.f) atomicAdd(&stats[3], ba);
+        }
+    }
+}
+
 // =============================================================================================
-// fused env transition, fixed-step classic RK4 with Kahan-compensated state update
+// classic RK4 micro-stepping, generic template (single phase; A/B reference of the packed form)
 // =============================================================================================
 template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
-    const ModelK<T> P, const StepK<T> C, T *__restrict__ fstate, int32_t *__restrict__ istate,
-    const float *__restrict__ ev_vg, const float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, T *__restrict__ out, float *__restrict__ stats, int n_env) {
+    const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
+    float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
+    T *__restrict__ out, float *__restrict__ stats, int n_env) {
     constexpr int NS = 6 * PH + 5;
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = e < n_env;
-    const int ec = live ? e : n_env - 1;           // clamp: tail lanes recompute env n-1, never store
     const size_t N = (size_t)n_env;
-
-    int ksub = istate[PVDER_I_KSUB * N + ec];
-    int steps = istate[PVDER_I_STEPS * N + ec];
-    int status = istate[PVDER_I_STATUS * N + ec];
-    const bool run = live && status == 0;          // finished envs return the stale tuple (:145-152)
-
+    Lane<T> L;
     T y[NS], comp[NS];
+    prologue<T, NS>(C, fstate, istate, action, n_env, L, y);
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        y[k] = fstate[(size_t)k * N + ec];
-        comp[k] = (T)0;
-    }
-    T qref = fstate[(size_t)NS * N + ec];
-    T vdcref = fstate[(size_t)(NS + 1) * N + ec];
-
-    // ---- action_calc (PVDER_env.py:198-229)
-    const int a = action[ec];
-    float bad_action = 0.f;
-    if (a == 1) qref += C.dq;
-    else if (a == 2) qref -= C.dq;
-    else if (a == 3) vdcref += C.dv;
-    else if (a == 4) vdcref -= C.dv;
-    else if (a != 0) bad_action = 1.f;
-
+    for (int k = 0; k < NS; ++k) comp[k] = (T)0;
     const T h = (T)(1.0 / 60.0) / (T)C.micro;
     const T h2 = (T)0.5 * h, h6 = h * (T)(1.0 / 6.0);
     const T tq = (T)2 / (T)C.micro;                // 2*theta advances 2 turns per 1/60 s
-
-    SubK<T, PH> S;
-    if (run) {
+    if (L.run) {
+        SubK<T, PH> S;
         for (int s = 0; s < C.n_sub; ++s) {
-            const int row = event_row(ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
-            const T vgm = (T)ev_vg[(size_t)row * N + ec];
-            const T sin_ = (T)ev_si[(size_t)row * N + ec];
-            pvder::make_sub<T, PH>(P, vgm, sin_, S);
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + L.ec], (T)ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < C.micro; ++j) {
                 T k[NS], ks[NS], yt[NS];
                 const T t0 = (T)j * tq, t1 = ((T)j + (T)0.5) * tq, t2 = ((T)j + (T)1) * tq;
-                pvder::rhs<T, PH>(P, S, y, t0, qref, vdcref, k);
+                pvder::rhs<T, PH>(P, S, y, t0, L.qref, L.vdcref, k);
 #pragma unroll
                 for (int q = 0; q < NS; ++q) { ks[q] = k[q]; yt[q] = y[q] + h2 * k[q]; }
-                pvder::rhs<T, PH>(P, S, yt, t1, qref, vdcref, k);
+                pvder::rhs<T, PH>(P, S, yt, t1, L.qref, L.vdcref, k);
 #pragma unroll
                 for (int q = 0; q < NS; ++q) { ks[q] += (T)2 * k[q]; yt[q] = y[q] + h2 * k[q]; }
-                pvder::rhs<T, PH>(P, S, yt, t1, qref, vdcref, k);
+                pvder::rhs<T, PH>(P, S, yt, t1, L.qref, L.vdcref, k);
 #pragma unroll
                 for (int q = 0; q < NS; ++q) { ks[q] += (T)2 * k[q]; yt[q] = y[q] + h * k[q]; }
-                pvder::rhs<T, PH>(P, S, yt, t2, qref, vdcref, k);
+                pvder::rhs<T, PH>(P, S, yt, t2, L.qref, L.vdcref, k);
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
                     // Kahan: with h ~ 4 us the increment is below ulp(y)/2 in fp32 and plain
@@ -162,232 +302,343 @@ __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
                 }
             }
         }
-        ksub += C.n_sub;
-        steps += 1;
+        L.ksub += C.n_sub;
+        L.steps += 1;
     }
+    epilogue<T, PH>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+}
 
-    // ---- epilogue: reward_calc / done / state at (y(tStop), tStop)
-    {
-        const int row = event_row(ksub, C.ev_s0, C.ev_ds, C.ev_count);
-        const T vgm = (T)ev_vg[(size_t)row * N + ec];
-        const T sin_ = (T)ev_si[(size_t)row * N + ec];
-        pvder::make_sub<T, PH>(P, vgm, sin_, S);
-    }
-    T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
-    pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc);
-    T chk = (T)0;
+// ---- packed pair layout <-> pvder state order
+__device__ __forceinline__ void to_pairs(const float *ys, v2 *y) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) chk += fabs(y[q]);
-    float nonfinite = 0.f;
-    if (run) {
-        if (!(chk < (T)1e30)) {                    // NaN/Inf: CONVERGENCE_FAILURE branch (:169-172)
-            status = 2; reward = (T)-100; nonfinite = 1.f;
-        } else if (ksub >= C.max_ksub || (C.max_steps > 0 && steps >= C.max_steps)) {
-            status = 1;                            // tStop >= max_sim_time (:183) / TimeLimit
-        }
-    }
-    if (run) {
+    for (int k = 0; k < 11; ++k) y[k] = pvder::mk2(ys[2 * k], ys[2 * k + 1]);
+    y[11] = pvder::mk2(ys[22], 0.f);
+}
+__device__ __forceinline__ void from_pairs(const v2 *y, float *ys) {
 #pragma unroll
-        for (int q = 0; q < NS; ++q) fstate[(size_t)q * N + e] = y[q];
-        fstate[(size_t)NS * N + e] = qref;
-        fstate[(size_t)(NS + 1) * N + e] = vdcref;
-        istate[PVDER_I_KSUB * N + e] = ksub;
-        istate[PVDER_I_STEPS * N + e] = steps;
-        istate[PVDER_I_STATUS * N + e] = status;
-        out[0 * N + e] = iaR;   out[1 * N + e] = iaI;
-        out[2 * N + e] = vaR;   out[3 * N + e] = vaI;
-        out[4 * N + e] = Ppcc;  out[5 * N + e] = Qpcc;
-        out[6 * N + e] = y[6 * PH];  out[7 * N + e] = ppv;
-        out[8 * N + e] = vdcref;     out[9 * N + e] = qref;
-        out[10 * N + e] = (T)ksub * (T)(1.0 / 60.0) * C.inv_tmax;      // tStart/max_sim_time (:540)
-        out[PVDER_O_REWARD * N + e] = reward;
-        out[PVDER_O_DONE * N + e] = status != 0 ? (T)1 : (T)0;
-    }
-    // ---- wave-level reduction of the step statistics, one atomic per wave
-    if (stats) {
-        const float r = wave_sum(run ? (float)reward : 0.f);
-        const float d = wave_sum(run && status != 0 ? 1.f : 0.f);
-        const float nf = wave_sum(nonfinite);
-        const float ba = wave_sum(live ? bad_action : 0.f);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[0], r);
-            if (d != 0.f) atomicAdd(&stats[1], d);
-            if (nf != 0.f) atomicAdd(&stats[2], nf);
-            if (ba != 0.f) atomicAdd(&stats[3], ba);
+    for (int k = 0; k < 11; ++k) { ys[2 * k] = y[k].x; ys[2 * k + 1] = y[k].y; }
+    ys[22] = y[11].x;
+}
+
+// nsteps classic RK4 steps of size h on the packed state (Kahan-compensated, u pairs plain);
+// 2*theta (turns) at step j, stage c is  tq0 + (j + c)*tq
+__device__ __forceinline__ void rk4_pk_steps(const ModelK<float> &P, const pvder::PkConst &K,
+                                             const pvder::SubPk &S, v2 *y, v2 *comp, int nsteps, float h,
+                                             float tq0, float tq, float qref, float vdcref) {
+    constexpr int NP = pvder::NP;
+    const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+    const v2 two = pvder::bc2(2.f);
+    for (int j = 0; j < nsteps; ++j) {
+        v2 k[NP], ks[NP], yt[NP];
+        const float t0 = tq0 + (float)j * tq, t1 = tq0 + ((float)j + 0.5f) * tq, t2 = tq0 + ((float)j + 1.f) * tq;
+        pvder::rhs_pk(P, K, S, y, t0, qref, vdcref, k);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { ks[q] = k[q]; yt[q] = pvder::fma2(h2, k[q], y[q]); }
+        pvder::rhs_pk(P, K, S, yt, t1, qref, vdcref, k);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { ks[q] = pvder::fma2(two, k[q], ks[q]); yt[q] = pvder::fma2(h2, k[q], y[q]); }
+        pvder::rhs_pk(P, K, S, yt, t1, qref, vdcref, k);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { ks[q] = pvder::fma2(two, k[q], ks[q]); yt[q] = pvder::fma2(h1, k[q], y[q]); }
+        pvder::rhs_pk(P, K, S, yt, t2, qref, vdcref, k);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (q == 2 || q == 5 || q == 8) {
+                // u_p: |u| ~ 1e-6 and du/dt is large -> increments are far above ulp(u)/2
+                y[q] = pvder::fma2(h6, ks[q] + k[q], y[q]);
+            } else {
+                const v2 inc = pvder::fma2(h6, ks[q] + k[q], -comp[q]);
+                const v2 tsum = y[q] + inc;
+                comp[q] = (tsum - y[q]) - inc;
+                y[q] = tsum;
+            }
         }
     }
 }
 
 // =============================================================================================
-// fused env transition, fixed-step RK4, three-phase fp32, packed-VALU formulation (the hot kernel)
+// classic RK4 micro-stepping, three-phase fp32, packed-VALU formulation
 // =============================================================================================
 __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
-    const ModelK<float> P, const StepK<float> C, float *__restrict__ fstate, int32_t *__restrict__ istate,
-    const float *__restrict__ ev_vg, const float *__restrict__ ev_si,
+    const ModelK<float> P, const StepK<float> C, const ResetK R, float *__restrict__ fstate,
+    int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
     const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
-    using pvder::v2;
     constexpr int NS = 23, NP = pvder::NP;
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = e < n_env;
-    const int ec = live ? e : n_env - 1;
     const size_t N = (size_t)n_env;
-
-    int ksub = istate[PVDER_I_KSUB * N + ec];
-    int steps = istate[PVDER_I_STEPS * N + ec];
-    int status = istate[PVDER_I_STATUS * N + ec];
-    const bool run = live && status == 0;
-
-    v2 y[NP], comp[NP];
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
+    if (L.run) {
+        v2 y[NP], comp[NP];
+        to_pairs(ys, y);
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        y[k] = pvder::mk2(fstate[(size_t)(2 * k) * N + ec], fstate[(size_t)(2 * k + 1) * N + ec]);
-        comp[k] = pvder::bc2(0.f);
-    }
-    y[11] = pvder::mk2(fstate[(size_t)22 * N + ec], 0.f);
-    comp[11] = pvder::bc2(0.f);
-    float qref = fstate[(size_t)NS * N + ec];
-    float vdcref = fstate[(size_t)(NS + 1) * N + ec];
-
-    const int a = action[ec];
-    float bad_action = 0.f;
-    if (a == 1) qref += C.dq;
-    else if (a == 2) qref -= C.dq;
-    else if (a == 3) vdcref += C.dv;
-    else if (a == 4) vdcref -= C.dv;
-    else if (a != 0) bad_action = 1.f;
-
-    const float h = (float)(1.0 / 60.0) / (float)C.micro;
-    const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
-    const v2 two = pvder::bc2(2.f);
-    const float tq = 2.f / (float)C.micro;
-    const pvder::PkConst K = pvder::make_pkconst(P);
-
-    pvder::SubPk S;
-    if (run) {
+        for (int k = 0; k < NP; ++k) comp[k] = pvder::bc2(0.f);
+        const float h = (float)(1.0 / 60.0) / (float)C.micro;
+        const float tq = 2.f / (float)C.micro;
+        const pvder::PkConst K = pvder::make_pkconst(P);
+        pvder::SubPk S;
         for (int s = 0; s < C.n_sub; ++s) {
-            const int row = event_row(ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
-            pvder::make_sub_pk(P, ev_vg[(size_t)row * N + ec], ev_si[(size_t)row * N + ec], S);
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
+            rk4_pk_steps(P, K, S, y, comp, C.micro, h, 0.f, tq, L.qref, L.vdcref);
+        }
+        from_pairs(y, ys);
+        L.ksub += C.n_sub;
+        L.steps += 1;
+    }
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+}
+
+// =============================================================================================
+// ETDRK4 (Krogstad 2005): exponential time differencing for the stiff current loop.
+//
+// Per phase the pair z_p = (i_p, u_p) obeys  dz_p/dt = Lz z_p + N_p(y)  with the CONSTANT complex
+// 2x2 matrix  Lz = [[-Z0, c0 Kp_GCC], [-wp, -wp]]  (Z0 = (kvi+Rf)/Lf + j, c0 = Vdc_ref0/(2 Lf)):
+// its eigenvalues -1e5 +- j5.8e5 1/s are what forces classic RK4 down to h ~ 4 us.  Everything
+// else (x_p, Vdc, xDC, xQ, xPLL, delta: poles <= 90 1/s) has Lz = 0, for which ETDRK4 *is* classic
+// RK4.  With  N_i = cm x + D + (cm-c0) Kp_GCC u - j (winv/wbase - 1) i,  N_u = wp iref_p  the scheme
+//   U2 = E2 z + P1 N1;   U3 = E2 z + A1 N1 + A2 N2;   U4 = E z + B1 N1 + B3 N3
+//   z+ = E z + C1 N1 + C2 (N2+N3) + C4 N4
+// propagates the fast loop exactly (E = exp(h Lz), phi-function matrices folded on the host in
+// fp64) and h is set by the slow dynamics: 8 steps per 1/60 s instead of 4096.
+// While a duty cycle is near its limit the conditional-integration anti-windup changes the fast
+// dynamics; such (rare) steps are redone by classic RK4 micro-steps from the saved state.
+// =============================================================================================
+struct EtdK {
+    float m[10][16];        // E2,E,P1,A1,A2,B1,B3,C1,C2,C4: per entry (re,re),(-im,im) for 11,12,21,22
+    float c0kp;             // c0 * Kp_GCC  (for N_i)
+    float sat2;             // guard: (0.97*m_limit)^2
+    int rk4_sub;            // classic RK4 micro-steps replacing one ETD step in the fallback
+};
+enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
+
+typedef float v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4 lds_v4;     // LDS-resident coefficient entries
+
+// one complex matrix entry c = (re, re, -im, im):  acc += c * z
+__device__ __forceinline__ v2 cmac(v2 acc, v4 c, v2 z) {
+    acc = pvder::fma2(pvder::mk2(c.x, c.y), z, acc);
+    return pvder::fma2(pvder::mk2(c.z, c.w), pvder::swp(z), acc);
+}
+struct Mat4 { v4 e[4]; };      // entries 11, 12, 21, 22
+__device__ __forceinline__ Mat4 load_mat(const lds_v4 *M, int k) {
+    Mat4 m;
+    m.e[0] = M[4 * k + 0]; m.e[1] = M[4 * k + 1]; m.e[2] = M[4 * k + 2]; m.e[3] = M[4 * k + 3];   // ds_read_b128 x4
+    return m;
+}
+// (oi, ou) += M * (ni, nu)
+__device__ __forceinline__ void matvec(const Mat4 &M, v2 ni, v2 nu, v2 &oi, v2 &ou) {
+    oi = cmac(oi, M.e[0], ni);
+    oi = cmac(oi, M.e[1], nu);
+    ou = cmac(ou, M.e[2], ni);
+    ou = cmac(ou, M.e[3], nu);
+}
+
+// N(y): fast part nf[2p] = N_i of phase p, nf[2p+1] = N_u; slow part ns[0..2] = dx_p,
+// ns[3] = d(Vdc,xDC), ns[4] = d(xQ,xPLL), ns[5] = d(delta,0).  Returns max_p |m_p|^2.
+__device__ __forceinline__ float etd_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
+                                          const pvder::SubPk &S, const v2 *__restrict__ y, float th2t,
+                                          float qref, float vdcref, v2 *__restrict__ nf, v2 *__restrict__ ns) {
+    using namespace pvder;
+    const float Vdc = y[9].x, xDC = y[9].y, xQ = y[10].x, xPLL = y[10].y, delta = y[11].x;
+    const v2 ia = y[0], xa = y[1], ua = y[2], ib = y[3], xb = y[4], ub = y[5], ic = y[6], xc = y[7], uc = y[8];
+    const v2 kpg = bc2(P.KpG);
+    const v2 ma = fma2(kpg, ua, xa), mb = fma2(kpg, ub, xb), mc = fma2(kpg, uc, xc);
+    v2 aP = ma * ia; aP = fma2(mb, ib, aP); aP = fma2(mc, ic, aP);
+    v2 aQ = S.Asw[0] * ia; aQ = fma2(S.Asw[1], ib, aQ); aQ = fma2(S.Asw[2], ic, aQ);
+    v2 aI = ia * ia; aI = fma2(ib, ib, aI); aI = fma2(ic, ic, aI);
+    const float Pt = aP.x + aP.y;
+    const float Q = 0.5f * (aQ.x + aQ.y) + K.qk * (aI.x + aI.y);
+    const float qerr = qref - Q;
+    const float iarR = xDC + P.KpDC * (vdcref - Vdc);
+    const float iarI = xQ - P.KpQ * qerr;
+    float s1, c1, s2, c2;
+    const float dturn = delta * (float)(1.0 / kTwoPi);
+    Math<float>::sincos_turns(dturn, s1, c1);
+    Math<float>::sincos_turns(th2t + dturn, s2, c2);
+    const v2 sb = ib + ic, db = ib - ic;
+    const v2 base = fma2(bc2(-0.5f), sb, ia);
+    const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);
+    const v2 rdb = swp(db) * jh3;
+    const v2 i1 = base + rdb, i2 = base - rdb;
+    const v2 jk3 = mk2(-P.kvi3I, P.kvi3I);
+    v2 V1 = fma2(bc2(P.kvi3R), i1, S.A0); V1 = fma2(jk3, swp(i1), V1);
+    v2 V2c = mk2(P.kvi3R, -P.kvi3R) * i2; V2c = fma2(bc2(-P.kvi3I), swp(i2), V2c);
+    const v2 t1 = V1 * mk2(c1, s1);
+    const v2 t2 = fma2(V2c, mk2(c2, s2), t1);
+    const float vd = t2.x + t2.y;
+    const float dw = P.KpP * vd + xPLL;
+    const float dwr = dw * P.iwb;                               // winv/wbase - 1
+    // N_i = cm x + D + (cm - c0) Kp u - j dwr i
+    const float cmf = K.hiLf * Vdc;
+    const v2 cm = bc2(cmf);
+    const v2 dck = bc2(cmf * P.KpG - Ec.c0kp);
+    const v2 jd = mk2(dwr, -dwr);                               // -j*dwr*(iR + j iI) = (dwr iI, -dwr iR)
+    v2 n;
+    n = fma2(cm, xa, S.D[0]); n = fma2(dck, ua, n); nf[0] = fma2(jd, swp(ia), n);
+    n = fma2(cm, xb, S.D[1]); n = fma2(dck, ub, n); nf[2] = fma2(jd, swp(ib), n);
+    n = fma2(cm, xc, S.D[2]); n = fma2(dck, uc, n); nf[4] = fma2(jd, swp(ic), n);
+    // N_u = wp * iref_p
+    const v2 wra = mk2(P.wp * iarR, P.wp * iarI);
+    const v2 hw = bc2(-0.5f) * wra;
+    const v2 jw = swp(wra) * jh3;
+    nf[1] = wra; nf[3] = hw - jw; nf[5] = hw + jw;
+    const v2 kig = bc2(P.KiG);
+    ns[0] = kig * ua; ns[1] = kig * ub; ns[2] = kig * uc;
+    const float ppv = ppv_of(P, S.pv1, Vdc);
+    const float ReS = 0.25f * Vdc * Pt;
+    const float dVdc = (ppv - ReS) * Math<float>::rcp(Vdc) * P.iC;
+    float dxDC = P.KiDC * (vdcref - Vdc);
+    float dxQ = -P.KiQ * qerr;
+    if (iarR * iarR + iarI * iarI > P.ilim2) {
+        dxDC = (dxDC * xDC > 0.f) ? 0.f : dxDC;
+        dxQ = (dxQ * xQ > 0.f) ? 0.f : dxQ;
+    }
+    ns[3] = mk2(dVdc, dxDC);
+    ns[4] = mk2(dxQ, P.KiP * vd);
+    ns[5] = mk2(dw, 0.f);
+    const v2 mma = ma * ma, mmb = mb * mb, mmc = mc * mc;
+    return fmaxf(fmaxf(mma.x + mma.y, mmb.x + mmb.y), mmc.x + mmc.y);
+}
+
+__device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
+    using namespace pvder;
+    const v2 kpg = bc2(P.KpG);
+    const v2 ma = fma2(kpg, y[2], y[1]), mb = fma2(kpg, y[5], y[4]), mc = fma2(kpg, y[8], y[7]);
+    const v2 a = ma * ma, b = mb * mb, c = mc * mc;
+    return fmaxf(fmaxf(a.x + a.y, b.x + b.y), c.x + c.y);
+}
+
+__global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
+    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
+    int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
+    constexpr int NS = 23, NP = pvder::NP;
+    const size_t N = (size_t)n_env;
+    // The 10 coefficient matrices (160 floats) do not fit the scalar register file next to the
+    // model constants (they would be spilled to VGPR lanes and read back with v_readlane in the
+    // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
+    // the same address: conflict-free, no VALU issue slot).
+    __shared__ __attribute__((aligned(16))) float Mlds[10 * 16];
+    if (threadIdx.x < 10 * 16) Mlds[threadIdx.x] = (&Ec.m[0][0])[threadIdx.x];
+    __syncthreads();
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
+    if (L.run) {
+        v2 y[NP], comp[NP];
+        to_pairs(ys, y);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) comp[k] = pvder::bc2(0.f);
+        const float h = (float)(1.0 / 60.0) / (float)C.micro;
+        const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+        const v2 two = pvder::bc2(2.f);
+        const float tq = 2.f / (float)C.micro;
+        const pvder::PkConst K = pvder::make_pkconst(P);
+        // slow pairs of the packed layout: x_a, x_b, x_c, (Vdc,xDC), (xQ,xPLL), (delta,0)
+        constexpr int SL[6] = {1, 4, 7, 9, 10, 11};
+        pvder::SubPk S;
+        for (int s = 0; s < C.n_sub; ++s) {
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < C.micro; ++j) {
-                v2 k[NP], ks[NP], yt[NP];
+                // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
+                // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
+                const lds_v4 *Mq = (const lds_v4 *)Mlds;
+                asm volatile("" : "+v"(Mq));
                 const float t0 = (float)j * tq, t1 = ((float)j + 0.5f) * tq, t2 = ((float)j + 1.f) * tq;
-                pvder::rhs_pk(P, K, S, y, t0, qref, vdcref, k);
+                v2 n1f[6], nf[6], nsl[6], ks[6], yt[NP], n23[6];
+                v2 u3[6], u4[6], zn[6];    // running sums of U3, U4, z+   (index 2p = i_p, 2p+1 = u_p)
+                const float m2a = etd_eval(P, K, Ec, S, y, t0, L.qref, L.vdcref, n1f, nsl);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { ks[q] = k[q]; yt[q] = pvder::fma2(h2, k[q], y[q]); }
-                pvder::rhs_pk(P, K, S, yt, t1, qref, vdcref, k);
+                for (int p = 0; p < 3; ++p) {
+                    const v2 zi = y[3 * p], zu = y[3 * p + 2];
+                    v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
+                    matvec(load_mat(Mq, EM_E2), zi, zu, e2i, e2u);                    // E2 z
+                    matvec(load_mat(Mq, EM_E), zi, zu, ei, eu);                       // E z
+                    v2 ai = e2i, au = e2u;
+                    matvec(load_mat(Mq, EM_P1), n1f[2 * p], n1f[2 * p + 1], ai, au);  // U2
+                    yt[3 * p] = ai; yt[3 * p + 2] = au;
+                    u3[2 * p] = e2i; u3[2 * p + 1] = e2u;
+                    matvec(load_mat(Mq, EM_A1), n1f[2 * p], n1f[2 * p + 1], u3[2 * p], u3[2 * p + 1]);
+                    u4[2 * p] = ei; u4[2 * p + 1] = eu;
+                    matvec(load_mat(Mq, EM_B1), n1f[2 * p], n1f[2 * p + 1], u4[2 * p], u4[2 * p + 1]);
+                    zn[2 * p] = ei; zn[2 * p + 1] = eu;
+                    matvec(load_mat(Mq, EM_C1), n1f[2 * p], n1f[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                }
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { ks[q] = pvder::fma2(two, k[q], ks[q]); yt[q] = pvder::fma2(h2, k[q], y[q]); }
-                pvder::rhs_pk(P, K, S, yt, t1, qref, vdcref, k);
+                for (int q = 0; q < 6; ++q) { ks[q] = nsl[q]; yt[SL[q]] = pvder::fma2(h2, nsl[q], y[SL[q]]); }
+                etd_eval(P, K, Ec, S, yt, t1, L.qref, L.vdcref, nf, nsl);             // N2
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { ks[q] = pvder::fma2(two, k[q], ks[q]); yt[q] = pvder::fma2(h1, k[q], y[q]); }
-                pvder::rhs_pk(P, K, S, yt, t2, qref, vdcref, k);
+                for (int p = 0; p < 3; ++p) {
+                    n23[2 * p] = nf[2 * p]; n23[2 * p + 1] = nf[2 * p + 1];
+                    v2 ai = u3[2 * p], au = u3[2 * p + 1];
+                    matvec(load_mat(Mq, EM_A2), nf[2 * p], nf[2 * p + 1], ai, au);    // U3
+                    yt[3 * p] = ai; yt[3 * p + 2] = au;
+                }
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    if (q == 2 || q == 5 || q == 8) {
-                        // u_p: |u| ~ 1e-6 and du/dt is large -> increments are far above ulp(u)/2
-                        y[q] = pvder::fma2(h6, ks[q] + k[q], y[q]);
-                    } else {
-                        // Kahan-compensated update (DESIGN.md "fp32 hazards")
-                        const v2 inc = pvder::fma2(h6, ks[q] + k[q], -comp[q]);
-                        const v2 tsum = y[q] + inc;
-                        comp[q] = (tsum - y[q]) - inc;
-                        y[q] = tsum;
+                for (int q = 0; q < 6; ++q) { ks[q] = pvder::fma2(two, nsl[q], ks[q]); yt[SL[q]] = pvder::fma2(h2, nsl[q], y[SL[q]]); }
+                etd_eval(P, K, Ec, S, yt, t1, L.qref, L.vdcref, nf, nsl);             // N3
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    n23[2 * p] += nf[2 * p]; n23[2 * p + 1] += nf[2 * p + 1];
+                    v2 ai = u4[2 * p], au = u4[2 * p + 1];
+                    matvec(load_mat(Mq, EM_B3), nf[2 * p], nf[2 * p + 1], ai, au);    // U4
+                    yt[3 * p] = ai; yt[3 * p + 2] = au;
+                    matvec(load_mat(Mq, EM_C2), n23[2 * p], n23[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { ks[q] = pvder::fma2(two, nsl[q], ks[q]); yt[SL[q]] = pvder::fma2(h1, nsl[q], y[SL[q]]); }
+                etd_eval(P, K, Ec, S, yt, t2, L.qref, L.vdcref, nf, nsl);             // N4
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    matvec(load_mat(Mq, EM_C4), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                    yt[3 * p] = zn[2 * p]; yt[3 * p + 2] = zn[2 * p + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) yt[SL[q]] = pvder::fma2(h6, ks[q] + nsl[q], y[SL[q]]);   // x_p candidate
+                const float m2b = max_m2(P, yt);
+                if (fmaxf(m2a, m2b) > Ec.sat2) {
+                    // duty cycle near its limit: anti-windup may switch the fast dynamics -> redo
+                    // this step with classic RK4 micro-steps (rare; PVDER-v0 episodes never get here)
+                    rk4_pk_steps(P, K, S, y, comp, Ec.rk4_sub, h / (float)Ec.rk4_sub, t0, tq / (float)Ec.rk4_sub,
+                                 L.qref, L.vdcref);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) { y[3 * p] = yt[3 * p]; y[3 * p + 2] = yt[3 * p + 2]; }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const int g = SL[q];
+                        const v2 inc = pvder::fma2(h6, ks[q] + nsl[q], -comp[g]);
+                        const v2 tsum = y[g] + inc;
+                        comp[g] = (tsum - y[g]) - inc;
+                        y[g] = tsum;
                     }
                 }
             }
         }
-        ksub += C.n_sub;
-        steps += 1;
+        from_pairs(y, ys);
+        L.ksub += C.n_sub;
+        L.steps += 1;
     }
-
-    // ---- epilogue (scalar form, once per step)
-    float ys[NS];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) { ys[2 * k] = y[k].x; ys[2 * k + 1] = y[k].y; }
-    ys[22] = y[11].x;
-    SubK<float, 3> S1;
-    {
-        const int row = event_row(ksub, C.ev_s0, C.ev_ds, C.ev_count);
-        pvder::make_sub<float, 3>(P, ev_vg[(size_t)row * N + ec], ev_si[(size_t)row * N + ec], S1);
-    }
-    float iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
-    pvder::outputs<float, 3>(P, S1, ys, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-    float reward = reward_of<float>(C, P, vrms, Ppcc, Qpcc);
-    float chk = 0.f;
-#pragma unroll
-    for (int q = 0; q < NS; ++q) chk += fabsf(ys[q]);
-    float nonfinite = 0.f;
-    if (run) {
-        if (!(chk < 1e30f)) {
-            status = 2; reward = -100.f; nonfinite = 1.f;
-        } else if (ksub >= C.max_ksub || (C.max_steps > 0 && steps >= C.max_steps)) {
-            status = 1;
-        }
-#pragma unroll
-        for (int q = 0; q < NS; ++q) fstate[(size_t)q * N + e] = ys[q];
-        fstate[(size_t)NS * N + e] = qref;
-        fstate[(size_t)(NS + 1) * N + e] = vdcref;
-        istate[PVDER_I_KSUB * N + e] = ksub;
-        istate[PVDER_I_STEPS * N + e] = steps;
-        istate[PVDER_I_STATUS * N + e] = status;
-        out[0 * N + e] = iaR;   out[1 * N + e] = iaI;
-        out[2 * N + e] = vaR;   out[3 * N + e] = vaI;
-        out[4 * N + e] = Ppcc;  out[5 * N + e] = Qpcc;
-        out[6 * N + e] = ys[18];     out[7 * N + e] = ppv;
-        out[8 * N + e] = vdcref;     out[9 * N + e] = qref;
-        out[10 * N + e] = (float)ksub * (float)(1.0 / 60.0) * C.inv_tmax;
-        out[PVDER_O_REWARD * N + e] = reward;
-        out[PVDER_O_DONE * N + e] = status != 0 ? 1.f : 0.f;
-    }
-    if (stats) {
-        const float r = wave_sum(run ? reward : 0.f);
-        const float d = wave_sum(run && status != 0 ? 1.f : 0.f);
-        const float nf = wave_sum(nonfinite);
-        const float ba = wave_sum(live ? bad_action : 0.f);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[0], r);
-            if (d != 0.f) atomicAdd(&stats[1], d);
-            if (nf != 0.f) atomicAdd(&stats[2], nf);
-            if (ba != 0.f) atomicAdd(&stats[3], ba);
-        }
-    }
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
 }
 
 // =============================================================================================
-// fused env transition, adaptive Dormand-Prince RK45 (per-lane step size; fp64 tolerance-match path)
+// adaptive Dormand-Prince RK45 (per-lane step size; fp64 tolerance-match path)
 // =============================================================================================
 template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
-    const ModelK<T> P, const StepK<T> C, T *__restrict__ fstate, int32_t *__restrict__ istate,
-    const float *__restrict__ ev_vg, const float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, T *__restrict__ out, T *__restrict__ hstep,
-    float *__restrict__ stats, int n_env) {
+    const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
+    float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
+    T *__restrict__ out, T *__restrict__ hstep, float *__restrict__ stats, int n_env) {
     constexpr int NS = 6 * PH + 5;
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = e < n_env;
-    const int ec = live ? e : n_env - 1;
     const size_t N = (size_t)n_env;
-
-    int ksub = istate[PVDER_I_KSUB * N + ec];
-    int steps = istate[PVDER_I_STEPS * N + ec];
-    int status = istate[PVDER_I_STATUS * N + ec];
-    const bool run = live && status == 0;
-
+    Lane<T> L;
     T y[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) y[k] = fstate[(size_t)k * N + ec];
-    T qref = fstate[(size_t)NS * N + ec];
-    T vdcref = fstate[(size_t)(NS + 1) * N + ec];
-    T hn = hstep[ec];
+    prologue<T, NS>(C, fstate, istate, action, n_env, L, y);
+    T hn = hstep[L.ec];
     if (!(hn > (T)0)) hn = (T)1e-6;
-
-    const int a = action[ec];
-    float bad_action = 0.f;
-    if (a == 1) qref += C.dq;
-    else if (a == 2) qref -= C.dq;
-    else if (a == 3) vdcref += C.dv;
-    else if (a == 4) vdcref -= C.dv;
-    else if (a != 0) bad_action = 1.f;
 
     // Dormand-Prince 5(4) tableau
     constexpr T c2 = 1. / 5, c3 = 3. / 10, c4 = 4. / 5, c5 = 8. / 9;
@@ -401,44 +652,44 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
     const T Tend = (T)(1.0 / 60.0);
     const T tq = (T)120;                            // 2*theta in turns = 120 t
 
-    SubK<T, PH> S;
-    if (run) {
+    if (L.run) {
+        SubK<T, PH> S;
         for (int s = 0; s < C.n_sub; ++s) {
-            const int row = event_row(ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
-            pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + ec], (T)ev_si[(size_t)row * N + ec], S);
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + L.ec], (T)ev_si[(size_t)row * N + L.ec], S);
             T t = (T)0;
             T k1[NS];
-            pvder::rhs<T, PH>(P, S, y, (T)0, qref, vdcref, k1);
-            // bounded: a lane can take at most kMaxIter attempts per 1/60 s (h >= ~1e-9 s)
-            for (int it = 0; it < 20000000 && t < Tend * (T)(1.0 - 1e-14); ++it) {
+            pvder::rhs<T, PH>(P, S, y, (T)0, L.qref, L.vdcref, k1);
+            // bounded: every lane leaves after at most 2e7 attempts per 1/60 s (h >= ~1e-9 s)
+            for (int it = 0; it < C.max_it && t < Tend * (T)(1.0 - 1e-14); ++it) {
                 T h = hn;
                 bool last = false;
                 if (t + h >= Tend) { h = Tend - t; last = true; }
                 T k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], yt[NS];
 #pragma unroll
                 for (int q = 0; q < NS; ++q) yt[q] = y[q] + h * (a21 * k1[q]);
-                pvder::rhs<T, PH>(P, S, yt, (t + c2 * h) * tq, qref, vdcref, k2);
+                pvder::rhs<T, PH>(P, S, yt, (t + c2 * h) * tq, L.qref, L.vdcref, k2);
 #pragma unroll
                 for (int q = 0; q < NS; ++q) yt[q] = y[q] + h * (a31 * k1[q] + a32 * k2[q]);
-                pvder::rhs<T, PH>(P, S, yt, (t + c3 * h) * tq, qref, vdcref, k3);
+                pvder::rhs<T, PH>(P, S, yt, (t + c3 * h) * tq, L.qref, L.vdcref, k3);
 #pragma unroll
                 for (int q = 0; q < NS; ++q) yt[q] = y[q] + h * (a41 * k1[q] + a42 * k2[q] + a43 * k3[q]);
-                pvder::rhs<T, PH>(P, S, yt, (t + c4 * h) * tq, qref, vdcref, k4);
+                pvder::rhs<T, PH>(P, S, yt, (t + c4 * h) * tq, L.qref, L.vdcref, k4);
 #pragma unroll
                 for (int q = 0; q < NS; ++q)
                     yt[q] = y[q] + h * (a51 * k1[q] + a52 * k2[q] + a53 * k3[q] + a54 * k4[q]);
-                pvder::rhs<T, PH>(P, S, yt, (t + c5 * h) * tq, qref, vdcref, k5);
+                pvder::rhs<T, PH>(P, S, yt, (t + c5 * h) * tq, L.qref, L.vdcref, k5);
 #pragma unroll
                 for (int q = 0; q < NS; ++q)
                     yt[q] = y[q] + h * (a61 * k1[q] + a62 * k2[q] + a63 * k3[q] + a64 * k4[q] + a65 * k5[q]);
-                pvder::rhs<T, PH>(P, S, yt, (t + h) * tq, qref, vdcref, k6);
+                pvder::rhs<T, PH>(P, S, yt, (t + h) * tq, L.qref, L.vdcref, k6);
                 T errv[NS];
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
                     yt[q] = y[q] + h * (b1 * k1[q] + b3 * k3[q] + b4 * k4[q] + b5 * k5[q] + b6 * k6[q]);
                     errv[q] = e1 * k1[q] + e3 * k3[q] + e4 * k4[q] + e5 * k5[q] + e6 * k6[q];
                 }
-                pvder::rhs<T, PH>(P, S, yt, (t + h) * tq, qref, vdcref, k2);   // k7 (reuses k2)
+                pvder::rhs<T, PH>(P, S, yt, (t + h) * tq, L.qref, L.vdcref, k2);   // k7 (reuses k2)
                 T err = (T)0;
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
@@ -462,79 +713,39 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
                 if (ok && last) break;
             }
         }
-        ksub += C.n_sub;
-        steps += 1;
+        L.ksub += C.n_sub;
+        L.steps += 1;
     }
-
-    {
-        const int row = event_row(ksub, C.ev_s0, C.ev_ds, C.ev_count);
-        pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + ec], (T)ev_si[(size_t)row * N + ec], S);
-    }
-    T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
-    pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc);
-    T chk = (T)0;
-#pragma unroll
-    for (int q = 0; q < NS; ++q) chk += fabs(y[q]);
-    float nonfinite = 0.f;
-    if (run) {
-        if (!(chk < (T)1e30)) {
-            status = 2; reward = (T)-100; nonfinite = 1.f;
-        } else if (ksub >= C.max_ksub || (C.max_steps > 0 && steps >= C.max_steps)) {
-            status = 1;
-        }
-#pragma unroll
-        for (int q = 0; q < NS; ++q) fstate[(size_t)q * N + e] = y[q];
-        fstate[(size_t)NS * N + e] = qref;
-        fstate[(size_t)(NS + 1) * N + e] = vdcref;
-        hstep[e] = hn;
-        istate[PVDER_I_KSUB * N + e] = ksub;
-        istate[PVDER_I_STEPS * N + e] = steps;
-        istate[PVDER_I_STATUS * N + e] = status;
-        out[0 * N + e] = iaR;   out[1 * N + e] = iaI;
-        out[2 * N + e] = vaR;   out[3 * N + e] = vaI;
-        out[4 * N + e] = Ppcc;  out[5 * N + e] = Qpcc;
-        out[6 * N + e] = y[6 * PH];  out[7 * N + e] = ppv;
-        out[8 * N + e] = vdcref;     out[9 * N + e] = qref;
-        out[10 * N + e] = (T)ksub * (T)(1.0 / 60.0) * C.inv_tmax;
-        out[PVDER_O_REWARD * N + e] = reward;
-        out[PVDER_O_DONE * N + e] = status != 0 ? (T)1 : (T)0;
-    }
-    if (stats) {
-        const float r = wave_sum(run ? (float)reward : 0.f);
-        const float d = wave_sum(run && status != 0 ? 1.f : 0.f);
-        const float nf = wave_sum(nonfinite);
-        const float ba = wave_sum(live ? bad_action : 0.f);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[0], r);
-            if (d != 0.f) atomicAdd(&stats[1], d);
-            if (nf != 0.f) atomicAdd(&stats[2], nf);
-            if (ba != 0.f) atomicAdd(&stats[3], ba);
-        }
-    }
+    const bool ran = L.run;
+    // no in-kernel auto-reset here: this kernel sits at the 256-VGPR + AGPR limit; the launcher
+    // enqueues reset_kernel<..., true> (reset where status != 0) right behind it instead
+    epilogue<T, PH, false>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+    if (ran) hstep[L.e] = (L.status != 0) ? (T)0 : hn;       // a finished env restarts the controller
 }
 
 // =============================================================================================
 // masked reset: steady state broadcast + event-table refill + reset observation
 // =============================================================================================
-template <int NSMAX>
-struct Y0K { double v[NSMAX]; };
-
-template <typename T, int PH>
+// FINISHED = true: auto-reset pass behind a step kernel -- resets the envs whose status != 0 and
+// leaves the reward/done rows (the transition that ended the episode) untouched
+template <typename T, int PH, bool FINISHED = false>
 __global__ __launch_bounds__(kBlock) void reset_kernel(
-    const ModelK<T> P, const StepK<T> C, const Y0K<23> Y0, const pvder_event_spec spec,
-    T *__restrict__ fstate, int32_t *__restrict__ istate, float *__restrict__ ev_vg,
-    float *__restrict__ ev_si, const uint8_t *__restrict__ mask, T *__restrict__ out, uint64_t seed,
-    int64_t env_id_base, int keep_events, int n_env) {
+    const ModelK<T> P, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
+    float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ mask,
+    T *__restrict__ out, int n_env) {
     constexpr int NS = 6 * PH + 5;
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_env) return;
-    if (mask && mask[e] == 0) return;
     const size_t N = (size_t)n_env;
+    if (FINISHED) {
+        if (istate[PVDER_I_STATUS * N + e] == 0) return;
+    } else if (mask && mask[e] == 0) {
+        return;
+    }
     T y[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        y[k] = (T)Y0.v[k];
+        y[k] = (T)R.y0[k];
         fstate[(size_t)k * N + e] = y[k];
     }
     const T qref = (T)0, vdcref = P.vdc_ref0;
@@ -545,40 +756,19 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(
     istate[PVDER_I_STEPS * N + e] = 0;
     istate[PVDER_I_STATUS * N + e] = 0;
     istate[PVDER_I_EPISODE * N + e] = episode;
-    if (!keep_events) {
-        // create_random_events (PVDER_env.py:400-411): one event per grid time, type drawn from
-        // the ENABLEd list (dict order: insolation, voltage -- :60-61), value U[min,max]
-        float vg = 1.0f, si = (float)P.sinsol0;
-        ev_vg[e] = vg;
-        ev_si[e] = si;
-        const int n_en = (spec.enable_insol != 0) + (spec.enable_voltage != 0);
-        for (int k = 1; k <= spec.ev_count; ++k) {
-            if (n_en > 0) {
-                const float ut = counter_uniform(seed, (uint64_t)(env_id_base + e), (uint64_t)episode, k, 0);
-                const float uv = counter_uniform(seed, (uint64_t)(env_id_base + e), (uint64_t)episode, k, 1);
-                int pick = (int)(ut * (float)n_en);
-                if (pick > n_en - 1) pick = n_en - 1;
-                const bool is_insol = spec.enable_insol && (pick == 0);
-                if (is_insol) si = lerp_unfused(spec.s_min, spec.s_max, uv);
-                else vg = lerp_unfused(spec.v_min, spec.v_max, uv);
-            }
-            ev_vg[(size_t)k * N + e] = vg;
-            ev_si[(size_t)k * N + e] = si;
-        }
-    }
+    if (!R.keep_events)
+        fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + e), (uint64_t)episode, ev_vg,
+                    ev_si, N, e);
     if (out) {
         SubK<T, PH> S;
         pvder::make_sub<T, PH>(P, (T)ev_vg[e], (T)ev_si[e], S);
         T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
         pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-        out[0 * N + e] = iaR;   out[1 * N + e] = iaI;
-        out[2 * N + e] = vaR;   out[3 * N + e] = vaI;
-        out[4 * N + e] = Ppcc;  out[5 * N + e] = Qpcc;
-        out[6 * N + e] = y[6 * PH];  out[7 * N + e] = ppv;
-        out[8 * N + e] = vdcref;     out[9 * N + e] = qref;
-        out[10 * N + e] = (T)0;
-        out[PVDER_O_REWARD * N + e] = (T)0;
-        out[PVDER_O_DONE * N + e] = (T)0;
+        write_obs<T>(out, N, e, iaR, iaI, vaR, vaI, Ppcc, Qpcc, y[6 * PH], ppv, vdcref, qref, (T)0);
+        if (!FINISHED) {
+            out[PVDER_O_REWARD * N + e] = (T)0;
+            out[PVDER_O_DONE * N + e] = (T)0;
+        }
     }
 }
 
@@ -625,9 +815,24 @@ StepK<T> fold_cfg(const pvder_step_cfg *c) {
     C.n_sub = c->n_sub; C.micro = c->micro; C.max_ksub = c->max_ksub; C.max_steps = c->max_steps;
     C.goal = c->goal; C.discrete = c->discrete; C.ev_s0 = c->ev_s0; C.ev_ds = c->ev_ds;
     C.ev_count = c->ev_count;
+    C.max_it = c->reserved > 0 ? c->reserved : 20000000;   // RK45: attempts per sim time step
     C.dq = (T)c->del_qref; C.dv = (T)c->del_vdcref; C.inv_tmax = (T)c->inv_max_sim_time;
     C.p_t = (T)c->p_target; C.q_t = (T)c->q_target; C.rtol = (T)c->rtol; C.atol = (T)c->atol;
     return C;
+}
+
+int fold_reset(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, ResetK &R) {
+    R.enabled = 0; R.keep_events = 1; R.seed = 0; R.env_id_base = 0;
+    R.spec = pvder_event_spec{};
+    for (int k = 0; k < 23; ++k) R.y0[k] = 0.0;
+    if (!ar) return 0;
+    if (!ar->y0) return PVDER_EINVAL;
+    if (ar->spec.ev_count != cfg->ev_count) return PVDER_EINVAL;
+    const int ns = PVDER_NS((int)par[PVDER_PAR_PHASES]);
+    R.enabled = ar->enabled; R.keep_events = ar->keep_events; R.seed = ar->seed; R.env_id_base = ar->env_id_base;
+    R.spec = ar->spec;
+    for (int k = 0; k < ns; ++k) R.y0[k] = ar->y0[k];
+    return 0;
 }
 
 int check_common(const double *par, const pvder_step_cfg *cfg, int n_env) {
@@ -642,27 +847,94 @@ int check_common(const double *par, const pvder_step_cfg *cfg, int n_env) {
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 
+int zero_stats_if(float *stats, int zero_stats, hipStream_t st) {
+    if (stats && zero_stats) return hip_rc(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+    return 0;
+}
+
+// ---- ETDRK4 coefficient matrices: functions of the constant 2x2 complex Lz, by the Lagrange
+// (Sylvester) formula  f(L) = f(l1)(L - l2 I)/(l1-l2) + f(l2)(L - l1 I)/(l2-l1)   (fp64, host)
+typedef std::complex<double> cd;
+struct M2 { cd a, b, c, d; };
+M2 fun2(const M2 &L, cd l1, cd l2, cd f1, cd f2) {
+    const cd w1 = f1 / (l1 - l2), w2 = f2 / (l2 - l1);
+    return M2{w1 * (L.a - l2) + w2 * (L.a - l1), (w1 + w2) * L.b, (w1 + w2) * L.c,
+              w1 * (L.d - l2) + w2 * (L.d - l1)};
+}
+cd phi(int k, cd z) {
+    if (k == 0) return std::exp(z);
+    if (k == 1) return (std::exp(z) - 1.0) / z;
+    if (k == 2) return (std::exp(z) - 1.0 - z) / (z * z);
+    return (std::exp(z) - 1.0 - z - 0.5 * z * z) / (z * z * z);
+}
+M2 lin(double s1, const M2 &A, double s2, const M2 &B, double s3, const M2 &Cm) {
+    return M2{s1 * A.a + s2 * B.a + s3 * Cm.a, s1 * A.b + s2 * B.b + s3 * Cm.b, s1 * A.c + s2 * B.c + s3 * Cm.c,
+              s1 * A.d + s2 * B.d + s3 * Cm.d};
+}
+void pack_m2(const M2 &M, float *o) {
+    const cd e[4] = {M.a, M.b, M.c, M.d};
+    for (int k = 0; k < 4; ++k) {
+        o[4 * k + 0] = (float)e[k].real(); o[4 * k + 1] = (float)e[k].real();
+        o[4 * k + 2] = (float)(-e[k].imag()); o[4 * k + 3] = (float)e[k].imag();
+    }
+}
+EtdK make_etd(const double *par, int micro) {
+    const double iLf = 1.0 / par[PVDER_PAR_LF];
+    const cd kvi(par[PVDER_PAR_KVI_RE], par[PVDER_PAR_KVI_IM]);
+    const cd Z0 = iLf * (kvi + par[PVDER_PAR_RF]) + cd(0.0, 1.0);
+    const double c0 = iLf * par[PVDER_PAR_VDC_REF0] / 2.0;
+    const double wp = par[PVDER_PAR_WP], kp = par[PVDER_PAR_KP_GCC];
+    const M2 L{-Z0, cd(c0 * kp, 0), cd(-wp, 0), cd(-wp, 0)};
+    const cd tr = L.a + L.d, det = L.a * L.d - L.b * L.c;
+    const cd disc = std::sqrt(tr * tr - 4.0 * det);
+    const cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
+    const double h = 1.0 / (60.0 * micro);
+    M2 ph[4], pf[4];      // phi_k(h L/2), phi_k(h L)
+    for (int k = 0; k < 4; ++k) {
+        ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
+        pf[k] = fun2(L, l1, l2, phi(k, h * l1), phi(k, h * l2));
+    }
+    EtdK E;
+    const M2 Z{};
+    pack_m2(ph[0], E.m[EM_E2]);
+    pack_m2(pf[0], E.m[EM_E]);
+    pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), E.m[EM_P1]);
+    pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), E.m[EM_A1]);
+    pack_m2(lin(h, ph[2], 0, Z, 0, Z), E.m[EM_A2]);
+    pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), E.m[EM_B1]);
+    pack_m2(lin(2 * h, pf[2], 0, Z, 0, Z), E.m[EM_B3]);
+    pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), E.m[EM_C1]);
+    pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), E.m[EM_C2]);
+    pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), E.m[EM_C4]);
+    E.c0kp = (float)(c0 * kp);
+    const double g = 0.97 * par[PVDER_PAR_M_LIMIT];
+    E.sat2 = (float)(g * g);
+    // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
+    E.rk4_sub = (4096 + micro - 1) / micro;
+    if (E.rk4_sub < 1) E.rk4_sub = 1;
+    return E;
+}
+
 template <typename T>
-int reset_impl(const double *par, const double *y0, const pvder_step_cfg *cfg, const pvder_event_spec *spec,
-               T *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *mask, T *out,
-               uint64_t seed, int64_t env_id_base, int keep_events, int n_env, void *stream) {
+int reset_impl(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, T *fstate,
+               int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *mask, T *out, int n_env,
+               void *stream) {
     int rc = check_common(par, cfg, n_env);
     if (rc) return rc;
-    if (!y0 || !spec || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
-    if (spec->ev_count != cfg->ev_count) return PVDER_EINVAL;
+    if (!ar || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
+    ResetK R;
+    rc = fold_reset(par, cfg, ar, R);
+    if (rc) return rc;
     const int ph = (int)par[PVDER_PAR_PHASES];
     const ModelK<T> P = fold_params<T>(par, sizeof(T) == 4);
-    const StepK<T> C = fold_cfg<T>(cfg);
-    Y0K<23> Y0;
-    for (int k = 0; k < 23; ++k) Y0.v[k] = k < PVDER_NS(ph) ? y0[k] : 0.0;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     if (ph == 3)
-        hipLaunchKernelGGL((reset_kernel<T, 3>), grid, block, 0, st, P, C, Y0, *spec, fstate, istate, ev_vg,
-                           ev_si, mask, out, seed, env_id_base, keep_events, n_env);
+        hipLaunchKernelGGL((reset_kernel<T, 3>), grid, block, 0, st, P, R, fstate, istate, ev_vg, ev_si, mask, out,
+                           n_env);
     else
-        hipLaunchKernelGGL((reset_kernel<T, 1>), grid, block, 0, st, P, C, Y0, *spec, fstate, istate, ev_vg,
-                           ev_si, mask, out, seed, env_id_base, keep_events, n_env);
+        hipLaunchKernelGGL((reset_kernel<T, 1>), grid, block, 0, st, P, R, fstate, istate, ev_vg, ev_si, mask, out,
+                           n_env);
     return hip_rc(hipGetLastError());
 }
 
@@ -674,73 +946,101 @@ int pvder_version(void) { return PVDER_ABI_VERSION; }
 int pvder_par_count(void) { return PVDER_PAR_COUNT; }
 int pvder_block_size(void) { return kBlock; }
 
-int pvder_reset_masked_f32(const double *par, const double *y0, const pvder_step_cfg *cfg,
-                           const pvder_event_spec *spec, float *fstate, int32_t *istate, float *ev_vg,
-                           float *ev_si, const uint8_t *mask, float *out, uint64_t seed,
-                           int64_t env_id_base, int keep_events, int n_env, void *stream) {
-    return reset_impl<float>(par, y0, cfg, spec, fstate, istate, ev_vg, ev_si, mask, out, seed, env_id_base,
-                             keep_events, n_env, stream);
+int pvder_reset_masked_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                           float *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *mask,
+                           float *out, int n_env, void *stream) {
+    return reset_impl<float>(par, cfg, ar, fstate, istate, ev_vg, ev_si, mask, out, n_env, stream);
 }
 
-int pvder_reset_masked_f64(const double *par, const double *y0, const pvder_step_cfg *cfg,
-                           const pvder_event_spec *spec, double *fstate, int32_t *istate, float *ev_vg,
-                           float *ev_si, const uint8_t *mask, double *out, uint64_t seed,
-                           int64_t env_id_base, int keep_events, int n_env, void *stream) {
-    return reset_impl<double>(par, y0, cfg, spec, fstate, istate, ev_vg, ev_si, mask, out, seed, env_id_base,
-                              keep_events, n_env, stream);
+int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                           double *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *mask,
+                           double *out, int n_env, void *stream) {
+    return reset_impl<double>(par, cfg, ar, fstate, istate, ev_vg, ev_si, mask, out, n_env, stream);
 }
 
-int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, float *fstate, int32_t *istate,
-                       const float *ev_vg, const float *ev_si, const uint8_t *action, float *out,
+int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, float *fstate,
+                       int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action, float *out,
                        float *stats, int zero_stats, int n_env, void *stream) {
     int rc = check_common(par, cfg, n_env);
     if (rc) return rc;
     if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
+    ResetK R;
+    rc = fold_reset(par, cfg, ar, R);
+    if (rc) return rc;
     const int ph = (int)par[PVDER_PAR_PHASES];
     const ModelK<float> P = fold_params<float>(par, true);
     const StepK<float> C = fold_cfg<float>(cfg);
     hipStream_t st = (hipStream_t)stream;
-    if (stats && zero_stats) {
-        hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(float), st);
-        if (e != hipSuccess) return hip_rc(e);
-    }
+    rc = zero_stats_if(stats, zero_stats, st);
+    if (rc) return rc;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     // PVDER_RK4_VARIANT=generic selects the un-packed template (A/B runs); default = packed kernel
     static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
     if (ph == 3 && !generic)
-        hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si, action, out,
-                           stats, n_env);
+        hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si, action,
+                           out, stats, n_env);
     else if (ph == 3)
-        hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
                            action, out, stats, n_env);
     else
-        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
                            action, out, stats, n_env);
     return hip_rc(hipGetLastError());
 }
 
-int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, double *fstate, int32_t *istate,
-                        const float *ev_vg, const float *ev_si, const uint8_t *action, double *out,
+int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                          float *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action,
+                          float *out, float *stats, int zero_stats, int n_env, void *stream) {
+    int rc = check_common(par, cfg, n_env);
+    if (rc) return rc;
+    if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
+    if ((int)par[PVDER_PAR_PHASES] != 3) return PVDER_EINVAL;     // three-phase model only
+    ResetK R;
+    rc = fold_reset(par, cfg, ar, R);
+    if (rc) return rc;
+    const ModelK<float> P = fold_params<float>(par, true);
+    const StepK<float> C = fold_cfg<float>(cfg);
+    const EtdK E = make_etd(par, cfg->micro);
+    hipStream_t st = (hipStream_t)stream;
+    rc = zero_stats_if(stats, zero_stats, st);
+    if (rc) return rc;
+    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action, out,
+                       stats, n_env);
+    return hip_rc(hipGetLastError());
+}
+
+int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, double *fstate,
+                        int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action, double *out,
                         double *hstep, float *stats, int zero_stats, int n_env, void *stream) {
     int rc = check_common(par, cfg, n_env);
     if (rc) return rc;
     if (!fstate || !istate || !ev_vg || !ev_si || !action || !out || !hstep) return PVDER_EINVAL;
     if (!(cfg->rtol > 0.0) || !(cfg->atol > 0.0)) return PVDER_EINVAL;
+    ResetK R;
+    rc = fold_reset(par, cfg, ar, R);
+    if (rc) return rc;
     const int ph = (int)par[PVDER_PAR_PHASES];
     const ModelK<double> P = fold_params<double>(par, false);
     const StepK<double> C = fold_cfg<double>(cfg);
     hipStream_t st = (hipStream_t)stream;
-    if (stats && zero_stats) {
-        hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(float), st);
-        if (e != hipSuccess) return hip_rc(e);
-    }
+    rc = zero_stats_if(stats, zero_stats, st);
+    if (rc) return rc;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     if (ph == 3)
-        hipLaunchKernelGGL((step_rk45_kernel<double, 3>), grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL((step_rk45_kernel<double, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
                            action, out, hstep, stats, n_env);
     else
-        hipLaunchKernelGGL((step_rk45_kernel<double, 1>), grid, block, 0, st, P, C, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL((step_rk45_kernel<double, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
                            action, out, hstep, stats, n_env);
+    if (R.enabled) {      // same-step auto-reset as a second pass (see step_rk45_kernel)
+        if (ph == 3)
+            hipLaunchKernelGGL((reset_kernel<double, 3, true>), grid, block, 0, st, P, R, fstate, istate, ev_vg,
+                               ev_si, (const uint8_t *)nullptr, out, n_env);
+        else
+            hipLaunchKernelGGL((reset_kernel<double, 1, true>), grid, block, 0, st, P, R, fstate, istate, ev_vg,
+                               ev_si, (const uint8_t *)nullptr, out, n_env);
+    }
     return hip_rc(hipGetLastError());
 }
 

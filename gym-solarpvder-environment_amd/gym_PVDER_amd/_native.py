@@ -20,11 +20,11 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
-           "pvder_reset_masked_f64", "pvder_step_rk4_f32", "pvder_step_rk45_f64"]
+           "pvder_reset_masked_f64", "pvder_step_etdrk4_f32", "pvder_step_rk4_f32", "pvder_step_rk45_f64"]
 
 
 class StepCfg(C.Structure):
@@ -42,6 +42,12 @@ class EventSpec(C.Structure):
     _fields_ = [("ev_count", C.c_int32), ("enable_voltage", C.c_int32), ("enable_insol", C.c_int32),
                 ("reserved", C.c_int32), ("v_min", C.c_float), ("v_max", C.c_float),
                 ("s_min", C.c_float), ("s_max", C.c_float)]
+
+
+class AutoReset(C.Structure):
+    """``struct pvder_autoreset`` (include/pvder_hip.h)."""
+    _fields_ = [("enabled", C.c_int32), ("keep_events", C.c_int32), ("seed", C.c_uint64),
+                ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double))]
 
 
 def hipcc_path() -> str:
@@ -88,15 +94,17 @@ def lib() -> C.CDLL:
         raise ImportError("libpvder_hip.so ABI %d != expected %d" % (L.pvder_version(), ABI_VERSION))
     vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
     dp = C.POINTER(C.c_double)
+    cfgp, arp = C.POINTER(StepCfg), C.POINTER(AutoReset)
     for name in ("pvder_reset_masked_f32", "pvder_reset_masked_f64"):
         f = getattr(L, name)
         f.restype = i32
-        f.argtypes = [dp, dp, C.POINTER(StepCfg), C.POINTER(EventSpec), vp, vp, vp, vp, vp, vp, u64, i64,
-                      i32, i32, vp]
-    L.pvder_step_rk4_f32.restype = i32
-    L.pvder_step_rk4_f32.argtypes = [dp, C.POINTER(StepCfg), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+        f.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp]
+    for name in ("pvder_step_etdrk4_f32", "pvder_step_rk4_f32"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.pvder_step_rk45_f64.restype = i32
-    L.pvder_step_rk45_f64.argtypes = [dp, C.POINTER(StepCfg), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.pvder_step_rk45_f64.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     _lib = L
     return L
 

@@ -68,9 +68,5 @@ class ShardedPVDERVec:
         return g[:, :11], g[:, 11], g[:, 12] != 0
 
     def step(self, local_actions: torch.Tensor):
-        _, reward, done, _ = self.env.step(local_actions)
-        # the env has auto-reset the finished envs: reward/done of the ended transition travel in
-        # rows 11/12, which the reset kernel cleared -> put them back before the gather
-        self.env.out[11].copy_(reward)
-        self.env.out[12].copy_(done.to(self.env.out.dtype))
+        self.env.step(local_actions, return_tensors=False)
         return self._collate() + ({},)

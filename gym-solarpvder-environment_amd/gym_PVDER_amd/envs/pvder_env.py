@@ -108,7 +108,7 @@ class PVDER(EnvSpecMixin):
 
     def __init__(self, goals_list=('voltage_regulation',), n_sim_time_steps_per_env_step=15,
                  max_sim_time=40.0, DISCRETE_REWARD=True, verbosity='INFO', device="cuda",
-                 integrator="rk4", micro_steps=None, seed=0, model_type='model_2'):
+                 integrator=None, micro_steps=None, seed=0, model_type='model_2'):
         PVDER.count += 1                                             # :117
         self.name = 'GymDER_' + str(PVDER.count)
         self.verbosity = verbosity

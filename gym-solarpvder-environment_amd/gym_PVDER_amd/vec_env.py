@@ -26,7 +26,9 @@ logger = logging.getLogger("gym_PVDER_amd")
 
 SIM_TIME_STEP = 1.0 / 60.0               # env_sim_spec['sim_time_step'], PVDER_env.py:63
 MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
-DEFAULT_MICRO = 4096                     # RK4 micro-steps per sim time step (h = 4.07 us)
+# integrator steps per 1/60 s sim time step (DESIGN.md "Kernels"): classic RK4 is stability-bound
+# by the current loop (h <= ~4.5 us); ETDRK4 propagates that loop exactly and is accuracy-bound
+DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
 
 OBSERVED_QUANTITIES = ['iaR', 'iaI', 'vaR', 'vaI', 'P_PCC', 'Q_PCC', 'Vdc', 'Ppv', 'Vdc_ref', 'Q_ref',
                        'tStart']         # PVDER_env.py:44-49
@@ -122,8 +124,10 @@ class PVDERVec(EnvSpecMixin):
         goals_list, n_sim_time_steps_per_env_step, max_sim_time, DISCRETE_REWARD
         num_envs:   N
         device:     torch device (a ROCm GPU)
-        integrator: 'rk4' (fp32 fixed-step, default) or 'rk45' (fp64 adaptive Dormand-Prince)
-        micro_steps: RK4 steps per 1/60 s sim time step
+        integrator: 'etdrk4' (fp32 fixed-step exponential RK4, default for the three-phase model),
+                    'rk4' (fp32 fixed-step classic RK4 micro-stepping) or 'rk45' (fp64 adaptive
+                    Dormand-Prince)
+        micro_steps: integrator steps per 1/60 s sim time step (default 8 / 4096)
         auto_reset: reset finished envs inside ``step`` (their returned obs is the reset obs)
         model_type: 'model_2' (three phase, derId 50, the PVDER-v0 default) or 'model_1'
         seed / env_id_base: key of the on-device event generator (env_id_base = global index of
@@ -134,16 +138,24 @@ class PVDERVec(EnvSpecMixin):
 
     def __init__(self, num_envs: int, goals_list=('voltage_regulation',),
                  n_sim_time_steps_per_env_step: int = 15, max_sim_time: float = 40.0,
-                 DISCRETE_REWARD: bool = True, device="cuda", integrator: str = "rk4",
-                 micro_steps: int = DEFAULT_MICRO, auto_reset: bool = True, model_type: str = 'model_2',
+                 DISCRETE_REWARD: bool = True, device="cuda", integrator: Optional[str] = None,
+                 micro_steps: Optional[int] = None, auto_reset: bool = True, model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
                  events_spec: Optional[dict] = None):
         if not isinstance(num_envs, int) or num_envs < 1:
             raise ValueError("num_envs must be a positive integer")
-        if integrator not in ("rk4", "rk45"):
-            raise ValueError("integrator must be 'rk4' or 'rk45'")
         if model_type not in self.env_model_spec:
             raise ValueError("model_type must be one of %s" % list(self.env_model_spec))
+        if integrator is None:
+            integrator = "etdrk4" if model_type == 'model_2' else "rk4"
+        if integrator not in ("etdrk4", "rk4", "rk45"):
+            raise ValueError("integrator must be 'etdrk4', 'rk4' or 'rk45'")
+        if integrator == "etdrk4" and model_type != 'model_2':
+            raise ValueError("integrator 'etdrk4' is implemented for the three-phase model (model_2) only")
+        if micro_steps is None:
+            micro_steps = DEFAULT_MICRO[integrator]
+        if isinstance(micro_steps, bool) or not isinstance(micro_steps, int) or micro_steps < 1:
+            raise ValueError("micro_steps must be a positive integer")
         self.num_envs = num_envs
         self._set_n(n_sim_time_steps_per_env_step)
         self.max_sim_time_user = max_sim_time
@@ -167,7 +179,7 @@ class PVDERVec(EnvSpecMixin):
         if self.device.type != "cuda":
             raise RuntimeError("PVDERVec runs on a ROCm GPU only (device=%s); there is no CPU path" % device)
         self._lib = _native.lib()
-        self.fdtype = torch.float32 if integrator == "rk4" else torch.float64
+        self.fdtype = torch.float64 if integrator == "rk45" else torch.float32
         N = num_envs
         self._alloc_event_tables()
         self.fstate = torch.zeros((self.ns + 2, N), dtype=self.fdtype, device=self.device)
@@ -298,14 +310,22 @@ class PVDERVec(EnvSpecMixin):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _autoreset(self, enabled: bool) -> _native.AutoReset:
+        a = _native.AutoReset()
+        a.enabled = 1 if enabled else 0
+        a.keep_events = 1 if self._keep_events else 0
+        a.seed = self.seed & (2 ** 64 - 1)
+        a.env_id_base = self.env_id_base
+        a.spec = self._spec()
+        a.y0 = C.cast(self._y0_c, C.POINTER(C.c_double))
+        return a
+
     def _reset_launch(self, mask: Optional[torch.Tensor]):
         fn = self._lib.pvder_reset_masked_f32 if self.fdtype == torch.float32 else self._lib.pvder_reset_masked_f64
-        cfg, spec = self._cfg(), self._spec()
-        rc = fn(self._par_c, self._y0_c, C.byref(cfg), C.byref(spec), self.fstate.data_ptr(),
-                self.istate.data_ptr(), self.ev_vg.data_ptr(), self.ev_si.data_ptr(),
-                mask.data_ptr() if mask is not None else None, self.out.data_ptr(),
-                C.c_uint64(self.seed & (2 ** 64 - 1)), C.c_int64(self.env_id_base),
-                1 if self._keep_events else 0, self.num_envs, self._stream())
+        cfg, ar = self._cfg(), self._autoreset(True)
+        rc = fn(self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
+                self.ev_vg.data_ptr(), self.ev_si.data_ptr(), mask.data_ptr() if mask is not None else None,
+                self.out.data_ptr(), self.num_envs, self._stream())
         _native.check(rc, "pvder_reset_masked")
 
     # -- Gym-like API (batched) ---------------------------------------------------------------------
@@ -324,47 +344,41 @@ class PVDERVec(EnvSpecMixin):
         self._needs_reset = False
         return self.obs
 
-    def step(self, actions: torch.Tensor):
+    def step(self, actions: torch.Tensor, return_tensors: bool = True):
         """One transition of every env.  ``actions``: [N] integer tensor with values in 0..4
-        (Discrete(5), PVDER_env.py:50).  Returns (obs[N,11], reward[N], done[N] bool, info)."""
+        (Discrete(5), PVDER_env.py:50).  Returns (obs[N,11], reward[N], done[N] bool, info); obs and
+        reward are views of the output block ``self.out`` ([13, N]), valid until the next step.
+        ``return_tensors=False`` only enqueues the launch (results are in ``self.out``)."""
         if self._needs_reset:
             raise RuntimeError("call reset() before step()")
         if actions.shape != (self.num_envs,):
             raise ValueError("actions must have shape (%d,)" % self.num_envs)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
-        cfg = self._cfg()
+        cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
+        a = (self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
+             self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr())
         with torch.cuda.device(self.device):
             if self._timing:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()          # same stream the kernel is launched on (torch's current stream)
-            if self.integrator == "rk4":
-                rc = self._lib.pvder_step_rk4_f32(self._par_c, C.byref(cfg), self.fstate.data_ptr(),
-                                                  self.istate.data_ptr(), self.ev_vg.data_ptr(),
-                                                  self.ev_si.data_ptr(), actions.data_ptr(),
-                                                  self.out.data_ptr(), self.stats.data_ptr(), 1,
-                                                  self.num_envs, self._stream())
+            # ONE launch: action -> integrate -> reward/done/obs -> same-step auto-reset of finished
+            # envs (their obs rows hold the reset observation, reward/done rows the ended transition)
+            if self.integrator == "etdrk4":
+                rc = self._lib.pvder_step_etdrk4_f32(*a, self.stats.data_ptr(), 1, self.num_envs, self._stream())
+            elif self.integrator == "rk4":
+                rc = self._lib.pvder_step_rk4_f32(*a, self.stats.data_ptr(), 1, self.num_envs, self._stream())
             else:
-                rc = self._lib.pvder_step_rk45_f64(self._par_c, C.byref(cfg), self.fstate.data_ptr(),
-                                                   self.istate.data_ptr(), self.ev_vg.data_ptr(),
-                                                   self.ev_si.data_ptr(), actions.data_ptr(),
-                                                   self.out.data_ptr(), self.hstep.data_ptr(),
-                                                   self.stats.data_ptr(), 1, self.num_envs, self._stream())
+                rc = self._lib.pvder_step_rk45_f64(*a, self.hstep.data_ptr(), self.stats.data_ptr(), 1,
+                                                   self.num_envs, self._stream())
             if self._timing:
                 ev1.record()
                 self._events.append((ev0, ev1))
             _native.check(rc, "pvder_step")
-            reward = self.out[11].clone()
-            done = self.out[12] != 0
-            if self.auto_reset:
-                # same-step auto-reset of finished envs (old-gym VectorEnv behaviour): their row of
-                # the output block is overwritten with the reset observation, reward/done keep the
-                # values of the transition that ended the episode
-                self._reset_launch(done.to(torch.uint8))
-                if self.hstep is not None:
-                    self.hstep.masked_fill_(done, 0.0)
-        return self.obs, reward, done, {}
+            if not return_tensors:
+                return None
+            return self.obs, self.out[11], self.out[12] != 0, {}
 
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 1
+#define PVDER_ABI_VERSION 2
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -84,7 +84,8 @@ enum pvder_goal { /* goals_list[0], PVDER_env.py:78-93, :234 */
 /* ---- per-launch step configuration (host struct, passed by pointer, copied at launch) */
 typedef struct pvder_step_cfg {
     int32_t n_sub;        /* n_sim_time_steps_per_env_step (PVDER_env.py:603-620) */
-    int32_t micro;        /* RK4 micro-steps per 1/60 s sim time step (h = 1/(60*micro)) */
+    int32_t micro;        /* integrator steps per 1/60 s sim time step (h = 1/(60*micro)): classic RK4
+                             needs ~4096 (stiff current loop), ETDRK4 8; ignored by RK45 */
     int32_t max_ksub;     /* done when ksub >= max_ksub  (tStop >= max_sim_time, :183) */
     int32_t max_steps;    /* TimeLimit max_episode_steps (gym_PVDER/__init__.py:10); 0 = none */
     int32_t goal;         /* enum pvder_goal */
@@ -111,49 +112,66 @@ typedef struct pvder_event_spec {
     float s_min, s_max;      /* U[min,max] insolation */
 } pvder_event_spec;
 
+/* ---- reset arguments, also used for the in-kernel same-step auto-reset of finished envs
+ * (PVDER.reset / setup_PVDER_simulation, PVDER_env.py:316-334, :366-398) */
+typedef struct pvder_autoreset {
+    int32_t enabled;         /* step entry points: reset envs that finish in this step (old-gym
+                                VectorEnv behaviour); ignored by pvder_reset_masked_* */
+    int32_t keep_events;     /* != 0: keep the event tables (explicit tables of a parity run) */
+    uint64_t seed;           /* counter generator key: (seed, env_id_base + e, episode, k) */
+    int64_t env_id_base;     /* global id of env 0 of this shard */
+    pvder_event_spec spec;
+    const double *y0;        /* host, PVDER_NS doubles: steady state in the kernels' state order
+                                (last entry = delta = wte - wbase*t at t = 0) */
+} pvder_autoreset;
+
 int pvder_version(void);
 int pvder_par_count(void);
+/* Threads per workgroup of the step kernels (bench.py reports it with the roofline). */
+int pvder_block_size(void);
 
-/* Masked reset (PVDER.reset / setup_PVDER_simulation, PVDER_env.py:316-334, :366-398).
- * For every env with mask[e] != 0 (mask == NULL: all):
- *   fstate <- y0 (host, ns doubles, steady state in delta form), Q_ref <- 0, Vdc_ref <- par,
- *   istate: ksub = steps = status = 0, episode += 1,
- *   event tables ev_vg/ev_si [K+1][n_env] refilled from the counter generator keyed
- *   (seed, env_id_base + e, episode, k) unless `keep_events` != 0 (explicit tables for parity),
- *   out block <- reset observation (reward 0, done 0)  when `out` != NULL. */
-int pvder_reset_masked_f32(const double *par, const double *y0, const pvder_step_cfg *cfg,
-                           const pvder_event_spec *spec, float *fstate, int32_t *istate,
-                           float *ev_vg, float *ev_si, const uint8_t *mask, float *out,
-                           uint64_t seed, int64_t env_id_base, int keep_events, int n_env,
-                           void *stream);
-int pvder_reset_masked_f64(const double *par, const double *y0, const pvder_step_cfg *cfg,
-                           const pvder_event_spec *spec, double *fstate, int32_t *istate,
-                           float *ev_vg, float *ev_si, const uint8_t *mask, double *out,
-                           uint64_t seed, int64_t env_id_base, int keep_events, int n_env,
-                           void *stream);
+/* Masked reset.  For every env with mask[e] != 0 (mask == NULL: all):
+ *   fstate <- ar->y0, Q_ref <- 0, Vdc_ref <- par; istate: ksub = steps = status = 0, episode += 1;
+ *   event tables ev_vg/ev_si [K+1][n_env] refilled from the counter generator unless
+ *   ar->keep_events; out block <- reset observation (reward 0, done 0) when out != NULL. */
+int pvder_reset_masked_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                           float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                           const uint8_t *mask, float *out, int n_env, void *stream);
+int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                           double *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                           const uint8_t *mask, double *out, int n_env, void *stream);
 
 /* One env transition for n_env envs (PVDER.step, PVDER_env.py:138-196): action_calc ->
- * integrate n_sub sim time steps -> reward_calc -> done -> state, one fused launch.
- * fp32 fixed-step classic RK4 (cfg->micro steps per 1/60 s, Kahan-compensated state update).
- * action: [n_env] uint8 in 0..4 (values > 4 are treated as 0 and flagged in stats[3]).
- * Envs whose status != 0 on entry are not advanced (stale tuple, :145-152).
- * stats (device, 4 floats, may be NULL): [0] sum of rewards, [1] #done, [2] #non-finite,
- * [3] #invalid actions -- produced by a wave-level reduction + one atomic per wave; the
- * caller zeroes it (or lets pvder_step_* do it: zero_stats != 0 enqueues a memset first). */
-int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, float *fstate,
-                       int32_t *istate, const float *ev_vg, const float *ev_si,
-                       const uint8_t *action, float *out, float *stats, int zero_stats,
-                       int n_env, void *stream);
+ * integrate n_sub sim time steps -> reward_calc -> done -> state, ONE fused launch.
+ *   action: [n_env] uint8 in 0..4 (values > 4 are treated as 0 and counted in stats[3]).
+ *   Envs whose status != 0 on entry are not advanced (stale tuple, :145-152).
+ *   ar (may be NULL): when ar->enabled, envs that finish in this step are reset in the same
+ *     launch: obs rows = reset observation, reward/done rows = the transition that ended.
+ *   stats (device, 4 floats, may be NULL): [0] sum of rewards, [1] #done, [2] #non-finite,
+ *     [3] #invalid actions -- wave-level reduction + one atomic per wave; zero_stats != 0
+ *     enqueues a memset of it first.
+ *
+ * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (exponential-time-differencing Runge-Kutta 4,
+ *   Krogstad form): the stiff filter-current/controller pair of each phase is propagated with
+ *   the exact matrix exponential, the other 11 states by classic RK4; cfg->micro ~ 8.
+ *   Three-phase model only (PVDER_EINVAL otherwise).
+ * pvder_step_rk4_f32: fp32 fixed-step classic RK4 micro-stepping (cfg->micro ~ 4096),
+ *   Kahan-compensated state update. */
+int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                          float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                          const uint8_t *action, float *out, float *stats, int zero_stats,
+                          int n_env, void *stream);
+int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                       float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                       const uint8_t *action, float *out, float *stats, int zero_stats, int n_env,
+                       void *stream);
 
 /* Same transition, fp64 adaptive Dormand-Prince RK45 (cfg->rtol/atol), per-env step size kept
  * in hstep [n_env] doubles (in/out; 0 = pick an initial step). */
-int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, double *fstate,
-                        int32_t *istate, const float *ev_vg, const float *ev_si,
+int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                        double *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                         const uint8_t *action, double *out, double *hstep, float *stats,
                         int zero_stats, int n_env, void *stream);
-
-/* Threads per workgroup of the step kernels (bench.py reports it with the roofline). */
-int pvder_block_size(void);
 
 #ifdef __cplusplus
 }

@@ -36,9 +36,10 @@ def run_case(name, device, integrator, copies=64, **kw):
     return g, np.stack(obs), np.stack(rew), np.stack(done), env
 
 
+@pytest.mark.parametrize("integrator", ["etdrk4", "rk4"])
 @pytest.mark.parametrize("name", CASES)
-def test_rk4_f32_vs_golden(gpu_device, name):
-    g, obs, rew, done, env = run_case(name, gpu_device, "rk4")
+def test_f32_kernels_vs_golden(gpu_device, name, integrator):
+    g, obs, rew, done, env = run_case(name, gpu_device, integrator)
     assert np.array_equal(obs[:, :1].repeat(obs.shape[1], 1), obs)      # identical envs -> identical outputs
     err = rel_l2(obs[:, 0], g["obs"])
     assert err < FP32_TOL, "rel-L2 %.3e" % err
@@ -133,8 +134,8 @@ def test_full_size_properties(gpu_device):
     spec = default_events_spec()
     spec['insolation']['ENABLE'] = True
     spec['voltage']['t_events_start'] = spec['insolation']['t_events_start'] = 0.1
-    N, n_sub, micro = 65536, 6, 4096
-    kw = dict(n_sim_time_steps_per_env_step=n_sub, micro_steps=micro, seed=99, events_spec=spec, max_sim_time=1.0)
+    N, n_sub = 65536, 6
+    kw = dict(n_sim_time_steps_per_env_step=n_sub, seed=99, events_spec=spec, max_sim_time=1.0)
     full = PVDERVec(N, device=gpu_device, **kw)
     half = [PVDERVec(N // 2, device=gpu_device, env_id_base=b, **kw) for b in (0, N // 2)]
     full.reset(); [h.reset() for h in half]

@@ -54,8 +54,8 @@ def test_rk4_f32_trajectory_vs_fp64_bridge(gpu_device, n_sub, steps):
     spec = both_events_spec()
     spec["voltage"]["t_events_start"] = spec["insolation"]["t_events_start"] = 0.2   # events inside the run
     spec["voltage"]["t_events_step"] = 0.2
-    env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, micro_steps=micro, seed=11,
-                   events_spec=spec, auto_reset=False)
+    env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator="rk4", micro_steps=micro,
+                   seed=11, events_spec=spec, auto_reset=False)
     env.reset()
     vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
     ref = BridgeVecEnv(N, n=n_sub, method="rk4", micro=micro)
@@ -93,3 +93,77 @@ def test_rk45_f64_trajectory_vs_bridge(gpu_device):
         err = rel_l2(obs.cpu().numpy(), o2, axis=1)
         assert err.max() < FP64_TOL, "step %d rel-L2 %.3e" % (t, err.max())
         assert np.array_equal(rew.cpu().numpy(), r2)
+
+
+@pytest.mark.parametrize("n_sub,steps,micro", [(4, 20, 8), (15, 6, 8), (15, 6, 4)])
+def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, micro):
+    """fp32 ETDRK4 (8 steps per 1/60 s) vs the converged fp64 solution (C bridge RK45, rtol 1e-8)."""
+    N = 64
+    rng = np.random.default_rng(17)
+    actions = rng.integers(0, 5, size=(steps, N))
+    spec = both_events_spec()
+    spec["voltage"]["t_events_start"] = spec["insolation"]["t_events_start"] = 0.2
+    spec["voltage"]["t_events_step"] = 0.2
+    env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator="etdrk4", micro_steps=micro,
+                   seed=23, events_spec=spec, auto_reset=False)
+    env.reset()
+    vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
+    ref = BridgeVecEnv(N, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11)
+    ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+    got_obs, want_obs = [], []
+    for t in range(steps):
+        obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
+        o2, r2, d2 = ref.step(actions[t])
+        got_obs.append(obs.cpu().numpy().astype(np.float64))
+        want_obs.append(o2)
+        assert np.array_equal(done.cpu().numpy(), d2)
+        assert (rew.cpu().numpy() != r2).mean() < 0.02
+    got, want = np.stack(got_obs), np.stack(want_obs)
+    err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
+    assert err.max() < FP32_TOL, "max rel-L2 over envs %.3e" % err.max()
+    assert env.step_stats()["n_nonfinite"] == 0
+
+
+def test_duty_cycle_saturation_anti_windup(gpu_device):
+    """State pushed past |m| = m_limit (low DC-link voltage): the conditional-integration
+    anti-windup branches run on the device and ETDRK4 takes its classic-RK4 fallback there.
+
+    With a duty cycle AT its limit the right-hand side is discontinuous (component-wise freezing by
+    sign tests) and the trajectory slides/chatters along |m| = m_limit: the result then depends on
+    the integrator at the 1e-2 level -- on the CPU, fp64 RK4 at h and h/2 differ by 1.7e-2 and RK45
+    by 1.4e-1 (DESIGN.md "Saturation").  So: same-scheme agreement to 5e-2, and the two device
+    integrators (ETDRK4 falling back to the same RK4 micro-steps) must agree closely."""
+    N, n_sub, steps = 64, 4, 3
+    vdc = np.linspace(0.975, 0.99, N)
+    m = pm.build_model("50")
+    envs = {}
+    for integrator, micro in (("rk4", 4096), ("etdrk4", 8)):
+        env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator=integrator,
+                       micro_steps=micro, seed=5, auto_reset=False)
+        env.reset()
+        # perturbed start: Vdc = Vdc_ref ~ 0.98 pu  ->  the loop drives |m| = |vt|/(Vdc/2) to ~1.02
+        env.fstate[18].copy_(torch.as_tensor(vdc, dtype=env.fstate.dtype, device=gpu_device))
+        env.fstate[24].copy_(torch.as_tensor(vdc, dtype=env.fstate.dtype, device=gpu_device))
+        envs[integrator] = env
+    ref = BridgeVecEnv(N, n=n_sub, method="rk4", micro=4096)
+    e0 = envs["rk4"]
+    ref.reset(e0.ev_vg.cpu().numpy().astype(np.float64), e0.ev_si.cpu().numpy().astype(np.float64),
+              ev_s0=e0.ev_s0, ev_ds=e0.ev_ds)
+    ref.Y[:, 18] = vdc
+    ref.vdcref[:] = vdc
+    m_peak = 0.0
+    a = np.zeros(N, dtype=np.int64)
+    for t in range(steps):
+        o2, r2, d2 = ref.step(a)
+        outs = {}
+        for name, env in envs.items():
+            obs, rew, done, _ = env.step(torch.as_tensor(a, device=gpu_device))
+            outs[name] = obs.cpu().numpy().astype(np.float64)
+            assert np.isfinite(outs[name]).all() and env.step_stats()["n_nonfinite"] == 0
+            assert rel_l2(outs[name], o2, axis=1).max() < 5e-2, (name, t)
+        assert rel_l2(outs["etdrk4"], outs["rk4"], axis=1).max() < 2e-3, t
+        m_peak = max(m_peak, np.abs(m.Kp_GCC * (ref.Y[:, 4] + 1j * ref.Y[:, 5]) + ref.Y[:, 2] + 1j * ref.Y[:, 3]).max())
+    assert m_peak > m.m_limit, "the scenario must drive |m| past the limit (got %.4f)" % m_peak
+    # on the device too the duty cycle sits at/above the limit (the freeze logic is active)
+    st = envs["rk4"].fstate[:23].t().cpu().numpy().astype(np.float64)
+    assert np.abs(m.Kp_GCC * (st[:, 4] + 1j * st[:, 5]) + st[:, 2] + 1j * st[:, 3]).max() > m.m_limit
