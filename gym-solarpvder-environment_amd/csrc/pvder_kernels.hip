@@ -407,7 +407,8 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 struct EtdK {
     float m[10][16];        // E2,E,P1,A1,A2,B1,B3,C1,C2,C4: per entry (re,re),(-im,im) for 11,12,21,22
     float c0kp;             // c0 * Kp_GCC  (for N_i)
-    float sat2;             // guard: (0.97*m_limit)^2
+    float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
+    float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
     int rk4_sub;            // classic RK4 micro-steps replacing one ETD step in the fallback
 };
 enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
@@ -538,10 +539,14 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
         // slow pairs of the packed layout: x_a, x_b, x_c, (Vdc,xDC), (xQ,xPLL), (delta,0)
         constexpr int SL[6] = {1, 4, 7, 9, 10, 11};
         pvder::SubPk S;
+        int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
         for (int s = 0; s < C.n_sub; ++s) {
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            const bool input_jump = row != prev_row;          // a grid-voltage / insolation event starts here
+            prev_row = row;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < C.micro; ++j) {
+                const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
                 // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
                 // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
                 const lds_v4 *Mq = (const lds_v4 *)Mlds;
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
 #pragma unroll
                 for (int q = 0; q < 3; ++q) yt[SL[q]] = pvder::fma2(h6, ks[q] + nsl[q], y[SL[q]]);   // x_p candidate
                 const float m2b = max_m2(P, yt);
-                if (fmaxf(m2a, m2b) > Ec.sat2) {
+                if (fmaxf(m2a, m2b) > guard) {
                     // duty cycle near its limit: anti-windup may switch the fast dynamics -> redo
                     // this step with classic RK4 micro-steps (rare; PVDER-v0 episodes never get here)
                     rk4_pk_steps(P, K, S, y, comp, Ec.rk4_sub, h / (float)Ec.rk4_sub, t0, tq / (float)Ec.rk4_sub,
@@ -907,8 +912,13 @@ EtdK make_etd(const double *par, int micro) {
     pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), E.m[EM_C2]);
     pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), E.m[EM_C4]);
     E.c0kp = (float)(c0 * kp);
-    const double g = 0.97 * par[PVDER_PAR_M_LIMIT];
-    E.sat2 = (float)(g * g);
+    // Anti-windup switches the fast dynamics only while |m_p| > m_limit.  On a step that starts at
+    // an input jump the under-damped current loop (zeta ~ 0.17) overshoots, so |m| may cross the
+    // limit inside the step although both ends are below it: keep 3 % clearance there; between
+    // jumps m moves by < 1e-3 per step and 0.2 % is ample.
+    const double ge = 0.97 * par[PVDER_PAR_M_LIMIT], gs = 0.998 * par[PVDER_PAR_M_LIMIT];
+    E.sat2_event = (float)(ge * ge);
+    E.sat2_smooth = (float)(gs * gs);
     // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
     E.rk4_sub = (4096 + micro - 1) / micro;
     if (E.rk4_sub < 1) E.rk4_sub = 1;
