@@ -106,6 +106,22 @@ def classic_rk4_leg(dev, N, n_sub, steps):
             "valu_frac": fl / VALU_PEAK_F32, "hbm_frac": BYTES_PER_ENV_STEP_F32 * N / avg / HBM_PEAK}
 
 
+def pmc_traffic(kernel, n_env):
+    """HBM bytes per launch from the committed PMC pass (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes); PMC counters
+    cannot be read from inside the timed process, so the newest summary under profiles/ is reported,
+    or null when it does not match this kernel / size."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel") == kernel and int(d.get("envs", -1)) == n_env:
+                return float(d["traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,7 +201,7 @@ def main():
                        "integrator": args.integrator,
                        "collective": "all_gather_into_tensor [13, N_local] per step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(KERNEL_NAME[args.integrator], N),
                          "kernel": KERNEL_NAME[args.integrator],
                          "kernel_avg_ms": avg_kern_s * 1e3, "algorithmic_bytes_per_env_step": bytes_step},
             # the binding roof of this path is the fp32 VALU, not HBM
