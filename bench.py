@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--integrator", default="etdrk4", choices=["etdrk4", "rk4", "rk45"])
     ap.add_argument("--classic-steps", type=int, default=3, help="classic-RK4 steps timed beside the main run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
+    ap.add_argument("--sync-gather", type=int, default=0,
+                    help="1: wait for each step's all-gather before the next step (no compute/comm overlap)")
     return ap.parse_args()
 
 
@@ -128,11 +130,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PVDER_BENCH_FORCE_DIST") == "1":   # (forced: exercises RCCL at world 1)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = world
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -151,15 +157,36 @@ def main():
     gen.manual_seed(1234 + rank)
     total = args.warmup + args.steps
     actions = torch.randint(0, 5, (total, N), generator=gen, device=dev, dtype=torch.uint8)
-    gathered = torch.empty((world, 13, N), dtype=env.out.dtype, device=dev) if world > 1 else None
+    # ONE collective per step (RCCL over xGMI): all-gather of the [13, N_local] output block.  It is
+    # double-buffered and asynchronous: the gather of step t runs on RCCL's stream while the step
+    # kernel of t+1 computes (the rollout does not consume the collated block before the next
+    # launch); every gather has completed inside the timed region (waited for before the final sync).
+    if dist is not None:
+        stage = [torch.empty_like(env.out) for _ in range(2)]
+        gathered = [torch.empty((world * 13, N), dtype=env.out.dtype, device=dev) for _ in range(2)]
+        pending = [None, None]
 
     def one_step(i):
         env.step(actions[i], return_tensors=False)      # results land in env.out ([13, N])
         if dist is not None:
-            dist.all_gather_into_tensor(gathered.view(world * 13, N), env.out)     # ONE collective per step (RCCL/xGMI)
+            b = i & 1
+            if pending[b] is not None:
+                pending[b].wait()                        # stream dependency only, no host block
+            stage[b].copy_(env.out)                      # 3.4 MB device copy: frees env.out for step t+1
+            pending[b] = dist.all_gather_into_tensor(gathered[b], stage[b], async_op=True)
+            if args.sync_gather:
+                pending[b].wait()
+
+    def drain():
+        if dist is not None:
+            for b in (0, 1):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
 
     for i in range(args.warmup):
         one_step(i)
+    drain()
     env.kernel_timing(True)
     torch.cuda.synchronize(dev)
     if dist is not None:
@@ -168,6 +195,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         one_step(i)
+    drain()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -199,7 +227,9 @@ def main():
                                                       "rk45": "fp64 adaptive RK45"}[args.integrator]),
                        "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro,
                        "integrator": args.integrator,
-                       "collective": "all_gather_into_tensor [13, N_local] per step" if world > 1 else "none"},
+                       "collective": ("all_gather_into_tensor [13, N_local] per step, %s"
+                                      % ("synchronous" if args.sync_gather else "overlapped with the next step"))
+                       if dist is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(KERNEL_NAME[args.integrator], N),
                          "kernel": KERNEL_NAME[args.integrator],

@@ -355,6 +355,9 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("actions must have shape (%d,)" % self.num_envs)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        # host structs are rebuilt per call (a few microseconds): every property the reference lets
+        # the user change between steps (events spec, goals, ...) is picked up without a cache to
+        # invalidate; the launch itself is asynchronous
         cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
         a = (self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
              self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr())
