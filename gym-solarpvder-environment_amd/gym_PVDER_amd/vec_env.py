@@ -154,6 +154,8 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("integrator 'etdrk4' is implemented for the three-phase model (model_2) only")
         if micro_steps is None:
             micro_steps = DEFAULT_MICRO[integrator]
+            if integrator == "rk4" and model_type == 'model_1':
+                micro_steps = 8192      # derId 10: current-loop poles at 1.02e6 rad/s (h <= 2.8 us)
         if isinstance(micro_steps, bool) or not isinstance(micro_steps, int) or micro_steps < 1:
             raise ValueError("micro_steps must be a positive integer")
         self.num_envs = num_envs

@@ -164,3 +164,34 @@ def test_full_size_properties(gpu_device):
     a = torch.zeros(N, dtype=torch.uint8, device=gpu_device); a[:7] = 9
     full.step(a)
     assert full.step_stats()["n_bad_action"] == 7
+
+
+# ---- single-phase model_1 (derId "10", PVDER_env.py:56, config_der.json:66-84)
+def test_single_phase_model_vs_bridge(gpu_device):
+    from gym_PVDER_amd.vec_env import PVDERVec
+    from oracle.bridge_env import BridgeVecEnv
+    g1 = np.load(os.path.join(GOLD, "steady_state.npz"))
+    N, n_sub, steps = 64, 4, 4
+    rng = np.random.default_rng(21)
+    actions = rng.integers(0, 5, size=(steps, N))
+    for integrator, kw, tol in (("rk4", {}, FP32_TOL), ("rk45", dict(rtol=1e-8, atol=1e-11), FP64_TOL)):
+        env = PVDERVec(N, device=gpu_device, model_type='model_1', integrator=integrator,
+                       n_sim_time_steps_per_env_step=n_sub, seed=8, auto_reset=False,
+                       goals_list=['power_regulation'], **kw)
+        assert env.phases == 1 and env.ns == 11 and env.fstate.shape == (13, N)
+        ob0 = env.reset().cpu().numpy().astype(np.float64)
+        assert np.abs(ob0 - g1["obs0_10"][None, :]).max() < 2e-6
+        ref = BridgeVecEnv(N, n=n_sub, der_id="10", goal="power_regulation",
+                           **(dict(method="rk4", micro=env.micro_steps) if integrator == "rk4"
+                              else dict(method="rk45", rtol=1e-8, atol=1e-11)))
+        ref.reset(env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64),
+                  ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+        got, want = [], []
+        for t in range(steps):
+            obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
+            o2, r2, d2 = ref.step(actions[t])
+            got.append(obs.cpu().numpy().astype(np.float64)); want.append(o2)
+            assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(done.cpu().numpy(), d2)
+        got, want = np.stack(got), np.stack(want)
+        err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
+        assert err.max() < tol, (integrator, err.max())
