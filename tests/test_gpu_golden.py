@@ -195,3 +195,37 @@ def test_single_phase_model_vs_bridge(gpu_device):
         got, want = np.stack(got), np.stack(want)
         err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
         assert err.max() < tol, (integrator, err.max())
+
+
+# ---- calc_returns sweep (PVDER_env.py:458-497) on the batched env
+def test_calc_returns_sweep(gpu_device):
+    from gym_PVDER_amd.evaluate import calc_returns
+    res = calc_returns(episodes=8, device=gpu_device, goals=['voltage_regulation', 'Q_regulation'],
+                       n_sim_time_steps_per_env_step=60, max_sim_time=5.0)
+    assert set(res) == {'voltage_regulation', 'Q_regulation'}
+    for goal in res:
+        assert set(res[goal]) == {'random', 'inc', 'dec', 'no_change'}
+        for spec in res[goal].values():
+            assert -5 * 5 <= spec['return'] <= 5                 # 5 one-second steps, rewards in {-5,-1,+1}
+    # 'inc' is a no-op: the references stay at their reset values (550 V, 0 VAR)
+    assert res['voltage_regulation']['inc']['ref'] == pytest.approx([550.0, 0.0], abs=1e-3)
+    # 'dec' raises Q_ref by 25*60 VAR per step (PVDER_env.py:75, :617)
+    assert res['voltage_regulation']['dec']['ref'][1] == pytest.approx(5 * 25 * 60, rel=1e-5)
+    assert res['voltage_regulation']['no_change']['ref'][1] == pytest.approx(-5 * 25 * 60, rel=1e-5)
+
+
+def test_ragged_env_counts(gpu_device):
+    """n_env not a multiple of the wave / workgroup size: tail lanes must neither store nor disturb."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    outs = {}
+    for N in (1, 63, 65, 1000, 1024):
+        env = PVDERVec(N, device=gpu_device, n_sim_time_steps_per_env_step=4, seed=31)
+        env.reset()
+        gen = torch.Generator(device=gpu_device); gen.manual_seed(1)
+        a = torch.randint(0, 5, (3, 1024), generator=gen, device=gpu_device, dtype=torch.uint8)
+        for t in range(3):
+            obs, rew, done, _ = env.step(a[t, :N].contiguous())
+        outs[N] = (obs.clone(), rew.clone(), env.step_stats())
+        assert outs[N][2]["reward_sum"] == float(rew.sum()) and outs[N][2]["n_bad_action"] == 0
+    for N in (1, 63, 65, 1000):
+        assert torch.equal(outs[N][0], outs[1024][0][:N]) and torch.equal(outs[N][1], outs[1024][1][:N])
