@@ -33,9 +33,9 @@ HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
 BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, three-phase fp32
 # flop per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
-FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 2245}
+FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 740}     # etdrk4: balanced fast-path kernel (full 23-state kernel: 2245)
 DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
-KERNEL_NAME = {"etdrk4": "step_etdrk4_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
+KERNEL_NAME = {"etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
 
 
 def parse():

@@ -32,6 +32,7 @@ using pvder::SubK;
 using pvder::v2;
 
 constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
+constexpr int kDeferred = -1; // transient istate status: "advance me in the follow-up launch"
 
 template <typename T>
 struct StepK {
@@ -145,7 +146,8 @@ struct Lane {
 template <typename T, int NS>
 __device__ __forceinline__ void prologue(const StepK<T> &C, const T *__restrict__ fstate,
                                          const int32_t *__restrict__ istate,
-                                         const uint8_t *__restrict__ action, int n_env, Lane<T> &L, T *y) {
+                                         const uint8_t *__restrict__ action, int n_env, Lane<T> &L, T *y,
+                                         int run_status = 0) {
     const size_t N = (size_t)n_env;
     L.e = blockIdx.x * kBlock + threadIdx.x;
     L.live = L.e < n_env;
@@ -153,7 +155,10 @@ __device__ __forceinline__ void prologue(const StepK<T> &C, const T *__restrict_
     L.ksub = istate[PVDER_I_KSUB * N + L.ec];
     L.steps = istate[PVDER_I_STEPS * N + L.ec];
     L.status = istate[PVDER_I_STATUS * N + L.ec];
-    L.run = L.live && L.status == 0;               // finished envs return the stale tuple (:145-152)
+    // finished envs (status 1/2) return the stale tuple (:145-152).  run_status = kDeferred selects
+    // the envs a preceding fast-path kernel handed over to this launch.
+    L.run = L.live && L.status == run_status;
+    if (L.run) L.status = 0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) y[k] = fstate[(size_t)k * N + L.ec];
     L.qref = fstate[(size_t)NS * N + L.ec];
@@ -513,9 +518,17 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
 __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
     const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
     int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env,
+    int run_status) {
     constexpr int NS = 23, NP = pvder::NP;
     const size_t N = (size_t)n_env;
+    if (run_status == kDeferred) {
+        // follow-up launch behind step_etdrk4_bal_kernel: leave at once unless this workgroup holds
+        // a deferred env (in PVDER-v0 rollouts it never does)
+        const int e0 = blockIdx.x * kBlock + threadIdx.x;
+        const int mine = (e0 < n_env) && istate[PVDER_I_STATUS * N + e0] == kDeferred;
+        if (!__syncthreads_or(mine)) return;
+    }
     // The 10 coefficient matrices (160 floats) do not fit the scalar register file next to the
     // model constants (they would be spilled to VGPR lanes and read back with v_readlane in the
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
     __syncthreads();
     Lane<float> L;
     float ys[NS];
-    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
+    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys, run_status);
     if (L.run) {
         v2 y[NP], comp[NP];
         to_pairs(ys, y);
@@ -625,6 +638,184 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
         from_pairs(y, ys);
         L.ksub += C.n_sub;
         L.steps += 1;
+    }
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+}
+
+// =============================================================================================
+// ETDRK4, balanced fast path.  PVDER-v0 feeds the 'ThreePhaseUnbalanced' model a balanced grid
+// (unbalance ratios 1.0) from a balanced steady state, and the ODE maps balanced states to balanced
+// states as long as no anti-windup sign test fires: phases b and c are phase a rotated by -/+120
+// degrees (this is pvder's own 'SolarPVDERThreePhaseBalanced' reduction).  This kernel checks that
+// at entry, integrates phase a + the 5 shared states (11 of 23) with the same ETDRK4 scheme, and
+// writes b and c back by rotation.  An env that is NOT balanced on entry, or whose duty cycle
+// reaches the saturation guard at any step, is left untouched and marked kDeferred: the full
+// kernel (step_etdrk4_kernel, launched right behind with run_status = kDeferred) advances it.
+// =============================================================================================
+__device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
+                                          const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 vx, v2 qp, float delta,
+                                          float qref, float vdcref, v2 &ni, v2 &nu, v2 *__restrict__ ns) {
+    using namespace pvder;
+    const float Vdc = vx.x, xDC = vx.y, xQ = qp.x, xPLL = qp.y;
+    const v2 ma = fma2(bc2(P.KpG), ua, xa);
+    const v2 aP = ma * ia, aQ = S.Asw[0] * ia, aI = ia * ia;
+    const float Pt = 3.f * (aP.x + aP.y);
+    const float Q = 1.5f * (aQ.x + aQ.y) + 3.f * K.qk * (aI.x + aI.y);
+    const float qerr = qref - Q;
+    const float iarR = xDC + P.KpDC * (vdcref - Vdc);
+    const float iarI = xQ - P.KpQ * qerr;
+    float s1, c1;
+    Math<float>::sincos_turns(delta * (float)(1.0 / kTwoPi), s1, c1);
+    v2 V1 = fma2(bc2(P.kviR), ia, S.A0); V1 = fma2(mk2(-P.kviI, P.kviI), swp(ia), V1);   // v_a (V2 = 0)
+    const v2 t1 = V1 * mk2(c1, s1);
+    const float vd = t1.x + t1.y;
+    const float dw = P.KpP * vd + xPLL;
+    const float dwr = dw * P.iwb;
+    const float cmf = K.hiLf * Vdc;
+    v2 n = fma2(bc2(cmf), xa, S.D[0]);
+    n = fma2(bc2(cmf * P.KpG - Ec.c0kp), ua, n);
+    ni = fma2(mk2(dwr, -dwr), swp(ia), n);
+    nu = mk2(P.wp * iarR, P.wp * iarI);
+    ns[0] = bc2(P.KiG) * ua;
+    const float ppv = ppv_of(P, S.pv1, Vdc);
+    const float dVdc = (ppv - 0.25f * Vdc * Pt) * Math<float>::rcp(Vdc) * P.iC;
+    float dxDC = P.KiDC * (vdcref - Vdc);
+    float dxQ = -P.KiQ * qerr;
+    if (iarR * iarR + iarI * iarI > P.ilim2) {
+        dxDC = (dxDC * xDC > 0.f) ? 0.f : dxDC;
+        dxQ = (dxQ * xQ > 0.f) ? 0.f : dxQ;
+    }
+    ns[1] = mk2(dVdc, dxDC);
+    ns[2] = mk2(dxQ, P.KiP * vd);
+    ns[3] = mk2(dw, 0.f);
+    const v2 mm = ma * ma;
+    return mm.x + mm.y;
+}
+
+// |z_b - z_a e^{-j120}|^2 + |z_c - z_a e^{+j120}|^2
+__device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
+    using namespace pvder;
+    const v2 hz = bc2(-0.5f) * za, jz = swp(za) * mk2(-kHalfSqrt3, kHalfSqrt3);
+    const v2 db = zb - (hz - jz), dc = zc - (hz + jz);
+    const v2 s = db * db + dc * dc;
+    return s.x + s.y;
+}
+
+__global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
+    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
+    int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
+    constexpr int NS = 23;
+    const size_t N = (size_t)n_env;
+    __shared__ __attribute__((aligned(16))) float Mlds[10 * 16];
+    if (threadIdx.x < 10 * 16) Mlds[threadIdx.x] = (&Ec.m[0][0])[threadIdx.x];
+    __syncthreads();
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
+    bool defer = false;
+    if (L.run) {
+        v2 ia = pvder::mk2(ys[0], ys[1]), xa = pvder::mk2(ys[2], ys[3]), ua = pvder::mk2(ys[4], ys[5]);
+        v2 vx = pvder::mk2(ys[18], ys[19]), qp = pvder::mk2(ys[20], ys[21]), dl = pvder::mk2(ys[22], 0.f);
+        {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
+            const float ei = unbalance2(ia, pvder::mk2(ys[6], ys[7]), pvder::mk2(ys[12], ys[13]));
+            const float ex = unbalance2(xa, pvder::mk2(ys[8], ys[9]), pvder::mk2(ys[14], ys[15]));
+            const float eu = unbalance2(ua, pvder::mk2(ys[10], ys[11]), pvder::mk2(ys[16], ys[17]));
+            const v2 i2 = ia * ia, x2 = xa * xa;
+            defer = ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
+        }
+        v2 cx = pvder::bc2(0.f), cv = pvder::bc2(0.f), cq = pvder::bc2(0.f), cd = pvder::bc2(0.f);   // Kahan
+        const float h = (float)(1.0 / 60.0) / (float)C.micro;
+        const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+        const v2 two = pvder::bc2(2.f);
+        const pvder::PkConst K = pvder::make_pkconst(P);
+        pvder::SubPk S;
+        int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
+        for (int s = 0; s < C.n_sub && !defer; ++s) {
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            const bool input_jump = row != prev_row;
+            prev_row = row;
+            pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
+            for (int j = 0; j < C.micro && !defer; ++j) {
+                const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
+                const lds_v4 *Mq = (const lds_v4 *)Mlds;
+                asm volatile("" : "+v"(Mq));
+                v2 n1i, n1u, ni, nu, ns[4], ks[4];
+                // software prefetch: issue the LDS reads of the six matrices applied to (z, N1) now,
+                // the model evaluation below hides their latency (one wave per SIMD: nobody else will)
+                const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mP1 = load_mat(Mq, EM_P1);
+                const Mat4 mA1 = load_mat(Mq, EM_A1), mB1 = load_mat(Mq, EM_B1), mC1 = load_mat(Mq, EM_C1);
+                __builtin_amdgcn_sched_barrier(0);     // keep the reads up here (hipcc would sink them to their uses)
+                const float m2a = bal_eval(P, K, Ec, S, ia, xa, ua, vx, qp, dl.x, L.qref, L.vdcref, n1i, n1u, ns);
+                v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
+                matvec(mE2, ia, ua, e2i, e2u);
+                matvec(mE, ia, ua, ei, eu);
+                v2 ti = e2i, tu = e2u;                                          // U2
+                matvec(mP1, n1i, n1u, ti, tu);
+                v2 u3i = e2i, u3u = e2u, u4i = ei, u4u = eu, zi = ei, zu = eu;
+                matvec(mA1, n1i, n1u, u3i, u3u);
+                matvec(mB1, n1i, n1u, u4i, u4u);
+                matvec(mC1, n1i, n1u, zi, zu);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ks[q] = ns[q];
+                const Mat4 mA2 = load_mat(Mq, EM_A2), mB3 = load_mat(Mq, EM_B3), mC2 = load_mat(Mq, EM_C2),
+                           mC4 = load_mat(Mq, EM_C4);          // prefetched behind evaluations 2-4
+                __builtin_amdgcn_sched_barrier(0);
+                bal_eval(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
+                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);   // N2
+                v2 n23i = ni, n23u = nu;
+                ti = u3i; tu = u3u;                                             // U3
+                matvec(mA2, ni, nu, ti, tu);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
+                bal_eval(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
+                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);   // N3
+                n23i += ni; n23u += nu;
+                ti = u4i; tu = u4u;                                             // U4
+                matvec(mB3, ni, nu, ti, tu);
+                matvec(mC2, n23i, n23u, zi, zu);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
+                bal_eval(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], vx),
+                         pvder::fma2(h1, ns[2], qp), dl.x + h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);         // N4
+                matvec(mC4, ni, nu, zi, zu);
+                // Kahan-compensated slow update
+                v2 inc, tsum;
+                inc = pvder::fma2(h6, ks[0] + ns[0], -cx); tsum = xa + inc; cx = (tsum - xa) - inc; const v2 xn = tsum;
+                inc = pvder::fma2(h6, ks[1] + ns[1], -cv); tsum = vx + inc; cv = (tsum - vx) - inc; const v2 vn = tsum;
+                inc = pvder::fma2(h6, ks[2] + ns[2], -cq); tsum = qp + inc; cq = (tsum - qp) - inc; const v2 qn = tsum;
+                inc = pvder::fma2(h6, ks[3] + ns[3], -cd); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
+                const v2 mn = pvder::fma2(pvder::bc2(P.KpG), zu, xn);
+                const v2 mn2 = mn * mn;
+                if (fmaxf(m2a, mn2.x + mn2.y) > guard) {
+                    defer = true;      // near saturation: the full kernel redoes this env step
+                } else {
+                    ia = zi; ua = zu; xa = xn; vx = vn; qp = qn; dl = dn;
+                }
+            }
+        }
+        if (!defer) {
+            // phases b, c = phase a rotated by -/+ 120 degrees
+            const v2 jh3 = pvder::mk2(-pvder::kHalfSqrt3, pvder::kHalfSqrt3);
+            const v2 z[3] = {ia, xa, ua};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const v2 hz = pvder::bc2(-0.5f) * z[k], jz = pvder::swp(z[k]) * jh3;
+                const v2 zb = hz - jz, zc = hz + jz;
+                ys[2 * k] = z[k].x; ys[2 * k + 1] = z[k].y;
+                ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
+                ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
+            }
+            ys[18] = vx.x; ys[19] = vx.y; ys[20] = qp.x; ys[21] = qp.y; ys[22] = dl.x;
+            L.ksub += C.n_sub;
+            L.steps += 1;
+        }
+    }
+    if (defer) {
+        // hand the env over untouched: nothing stored but the marker, nothing added to the stats
+        istate[PVDER_I_STATUS * N + L.e] = kDeferred;
+        L.run = false;
+        L.live = false;
     }
     epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
 }
@@ -1015,8 +1206,19 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     rc = zero_stats_if(stats, zero_stats, st);
     if (rc) return rc;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action, out,
-                       stats, n_env);
+    // Balanced fast path first, then the full kernel for the envs it deferred (unbalanced state or
+    // duty cycle near its limit; none in PVDER-v0 rollouts: every workgroup of the second launch
+    // then exits after one status read).  PVDER_ETD_VARIANT=full runs the full kernel alone (A/B).
+    static const bool full_only = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
+    if (full_only) {
+        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
+                           out, stats, n_env, 0);
+    } else {
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
+                           action, out, stats, n_env);
+        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
+                           out, stats, n_env, (int)kDeferred);
+    }
     return hip_rc(hipGetLastError());
 }
 
