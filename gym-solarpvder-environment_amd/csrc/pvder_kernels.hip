@@ -190,10 +190,14 @@ template <typename T, int PH, bool AR = true>
 __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, const ResetK &R, Lane<T> &L,
                                          T *y, T *__restrict__ fstate, int32_t *__restrict__ istate,
                                          float *__restrict__ ev_vg, float *__restrict__ ev_si,
-                                         T *__restrict__ out, float *__restrict__ stats, int n_env) {
+                                         T *__restrict__ out, float *__restrict__ stats, int n_env,
+                                         float *__restrict__ stats_clear = nullptr) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     const int ec = L.ec;
+    // ping-pong statistics: this launch accumulates into `stats` and clears the OTHER bank for the
+    // next launch (nobody writes that bank now; the kernel boundary orders the clear before its use)
+    if (stats_clear && blockIdx.x == 0 && threadIdx.x < 4) stats_clear[threadIdx.x] = 0.f;
     SubK<T, PH> S;
     {
         const int row = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count);
@@ -267,7 +271,7 @@ template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
     const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
     float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
-    T *__restrict__ out, float *__restrict__ stats, int n_env) {
+    T *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     Lane<T> L;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    epilogue<T, PH>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+    epilogue<T, PH>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
 }
 
 // ---- packed pair layout <-> pvder state order
@@ -367,7 +371,7 @@ __device__ __forceinline__ void rk4_pk_steps(const ModelK<float> &P, const pvder
 __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
     const ModelK<float> P, const StepK<float> C, const ResetK R, float *__restrict__ fstate,
     int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 23, NP = pvder::NP;
     const size_t N = (size_t)n_env;
     Lane<float> L;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
 }
 
 // =============================================================================================
@@ -704,7 +708,7 @@ __device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
 __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
     const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
     int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env) {
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 23;
     const size_t N = (size_t)n_env;
     __shared__ __attribute__((aligned(16))) float Mlds[10 * 16];
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
         L.run = false;
         L.live = false;
     }
-    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
 }
 
 // =============================================================================================
@@ -827,7 +831,7 @@ template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
     const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
     float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
-    T *__restrict__ out, T *__restrict__ hstep, float *__restrict__ stats, int n_env) {
+    T *__restrict__ out, T *__restrict__ hstep, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     Lane<T> L;
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
     const bool ran = L.run;
     // no in-kernel auto-reset here: this kernel sits at the 256-VGPR + AGPR limit; the launcher
     // enqueues reset_kernel<..., true> (reset where status != 0) right behind it instead
-    epilogue<T, PH, false>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+    epilogue<T, PH, false>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
     if (ran) hstep[L.e] = (L.status != 0) ? (T)0 : hn;       // a finished env restarts the controller
 }
 
@@ -1043,8 +1047,15 @@ int check_common(const double *par, const pvder_step_cfg *cfg, int n_env) {
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 
-int zero_stats_if(float *stats, int zero_stats, hipStream_t st) {
-    if (stats && zero_stats) return hip_rc(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+// zero_stats: 0 accumulate into stats[0..3]; 1 memset stats[0..3] first; 2 / 3 ping-pong over an
+// 8-float buffer: accumulate into bank 0 / 1 (stats[0..3] / stats[4..7]) and let the kernel clear the
+// other bank for the next launch (no memset node on the stream)
+int stats_setup(float *stats, int zero_stats, hipStream_t st, float *&acc, float *&clr) {
+    acc = stats; clr = nullptr;
+    if (!stats) return 0;
+    if (zero_stats == 1) return hip_rc(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+    if (zero_stats == 2) { acc = stats; clr = stats + 4; }
+    if (zero_stats == 3) { acc = stats + 4; clr = stats; }
     return 0;
 }
 
@@ -1172,20 +1183,21 @@ int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder
     const ModelK<float> P = fold_params<float>(par, true);
     const StepK<float> C = fold_cfg<float>(cfg);
     hipStream_t st = (hipStream_t)stream;
-    rc = zero_stats_if(stats, zero_stats, st);
+    float *acc, *clr;
+    rc = stats_setup(stats, zero_stats, st, acc, clr);
     if (rc) return rc;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     // PVDER_RK4_VARIANT=generic selects the un-packed template (A/B runs); default = packed kernel
     static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
     if (ph == 3 && !generic)
         hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si, action,
-                           out, stats, n_env);
+                           out, acc, n_env, clr);
     else if (ph == 3)
         hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, stats, n_env);
+                           action, out, acc, n_env, clr);
     else
         hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, stats, n_env);
+                           action, out, acc, n_env, clr);
     return hip_rc(hipGetLastError());
 }
 
@@ -1203,7 +1215,8 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     const StepK<float> C = fold_cfg<float>(cfg);
     const EtdK E = make_etd(par, cfg->micro);
     hipStream_t st = (hipStream_t)stream;
-    rc = zero_stats_if(stats, zero_stats, st);
+    float *acc, *clr;
+    rc = stats_setup(stats, zero_stats, st, acc, clr);
     if (rc) return rc;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     // Balanced fast path first, then the full kernel for the envs it deferred (unbalanced state or
@@ -1211,13 +1224,14 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     // then exits after one status read).  PVDER_ETD_VARIANT=full runs the full kernel alone (A/B).
     static const bool full_only = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     if (full_only) {
+        if (clr) (void)hipMemsetAsync(clr, 0, 4 * sizeof(float), st);     // (A/B variant only)
         hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
-                           out, stats, n_env, 0);
+                           out, acc, n_env, 0);
     } else {
         hipLaunchKernelGGL(step_etdrk4_bal_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
-                           action, out, stats, n_env);
+                           action, out, acc, n_env, clr);
         hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
-                           out, stats, n_env, (int)kDeferred);
+                           out, acc, n_env, (int)kDeferred);
     }
     return hip_rc(hipGetLastError());
 }
@@ -1236,15 +1250,16 @@ int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvde
     const ModelK<double> P = fold_params<double>(par, false);
     const StepK<double> C = fold_cfg<double>(cfg);
     hipStream_t st = (hipStream_t)stream;
-    rc = zero_stats_if(stats, zero_stats, st);
+    float *acc, *clr;
+    rc = stats_setup(stats, zero_stats, st, acc, clr);
     if (rc) return rc;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     if (ph == 3)
         hipLaunchKernelGGL((step_rk45_kernel<double, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, hstep, stats, n_env);
+                           action, out, hstep, acc, n_env, clr);
     else
         hipLaunchKernelGGL((step_rk45_kernel<double, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, hstep, stats, n_env);
+                           action, out, hstep, acc, n_env, clr);
     if (R.enabled) {      // same-step auto-reset as a second pass (see step_rk45_kernel)
         if (ph == 3)
             hipLaunchKernelGGL((reset_kernel<double, 3, true>), grid, block, 0, st, P, R, fstate, istate, ev_vg,

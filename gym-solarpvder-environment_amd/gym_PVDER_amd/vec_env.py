@@ -187,7 +187,8 @@ class PVDERVec(EnvSpecMixin):
         self.fstate = torch.zeros((self.ns + 2, N), dtype=self.fdtype, device=self.device)
         self.istate = torch.zeros((4, N), dtype=torch.int32, device=self.device)
         self.out = torch.zeros((13, N), dtype=self.fdtype, device=self.device)
-        self.stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)    # two banks (ping-pong)
+        self._bank = 0
         self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator == "rk45" else None
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
@@ -370,12 +371,15 @@ class PVDERVec(EnvSpecMixin):
                 ev0.record()          # same stream the kernel is launched on (torch's current stream)
             # ONE launch: action -> integrate -> reward/done/obs -> same-step auto-reset of finished
             # envs (their obs rows hold the reset observation, reward/done rows the ended transition)
+            # statistics: accumulate into bank `_bank`, the kernel clears the other one for the next step
+            self._bank ^= 1
+            zs = 2 + self._bank
             if self.integrator == "etdrk4":
-                rc = self._lib.pvder_step_etdrk4_f32(*a, self.stats.data_ptr(), 1, self.num_envs, self._stream())
+                rc = self._lib.pvder_step_etdrk4_f32(*a, self.stats.data_ptr(), zs, self.num_envs, self._stream())
             elif self.integrator == "rk4":
-                rc = self._lib.pvder_step_rk4_f32(*a, self.stats.data_ptr(), 1, self.num_envs, self._stream())
+                rc = self._lib.pvder_step_rk4_f32(*a, self.stats.data_ptr(), zs, self.num_envs, self._stream())
             else:
-                rc = self._lib.pvder_step_rk45_f64(*a, self.hstep.data_ptr(), self.stats.data_ptr(), 1,
+                rc = self._lib.pvder_step_rk45_f64(*a, self.hstep.data_ptr(), self.stats.data_ptr(), zs,
                                                    self.num_envs, self._stream())
             if self._timing:
                 ev1.record()
@@ -388,7 +392,7 @@ class PVDERVec(EnvSpecMixin):
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,
         #invalid actions -- the batched counterpart of update_reward_stats (env_utilities.py:32-38)."""
-        s = self.stats.tolist()
+        s = self.stats[4 * self._bank: 4 * self._bank + 4].tolist()
         return {"reward_sum": s[0], "n_done": int(s[1]), "n_nonfinite": int(s[2]), "n_bad_action": int(s[3])}
 
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------

@@ -147,9 +147,12 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
  *   Envs whose status != 0 on entry are not advanced (stale tuple, :145-152).
  *   ar (may be NULL): when ar->enabled, envs that finish in this step are reset in the same
  *     launch: obs rows = reset observation, reward/done rows = the transition that ended.
- *   stats (device, 4 floats, may be NULL): [0] sum of rewards, [1] #done, [2] #non-finite,
- *     [3] #invalid actions -- wave-level reduction + one atomic per wave; zero_stats != 0
- *     enqueues a memset of it first.
+ *   stats (device, may be NULL): [0] sum of rewards, [1] #done, [2] #non-finite, [3] #invalid
+ *     actions -- wave-level reduction + one atomic per wave.  zero_stats: 0 = accumulate into
+ *     stats[0..3]; 1 = enqueue a memset of stats[0..3] first; 2 / 3 = ping-pong over an 8-float
+ *     buffer: accumulate into stats[0..3] / stats[4..7] while the kernel clears the other bank for
+ *     the next launch (alternate 2, 3, 2, ... and no memset is ever enqueued; the bank that is
+ *     accumulated into must have been cleared by the previous launch or by the caller).
  *
  * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (exponential-time-differencing Runge-Kutta 4,
  *   Krogstad form): the stiff filter-current/controller pair of each phase is propagated with

@@ -229,3 +229,28 @@ def test_ragged_env_counts(gpu_device):
         assert outs[N][2]["reward_sum"] == float(rew.sum()) and outs[N][2]["n_bad_action"] == 0
     for N in (1, 63, 65, 1000):
         assert torch.equal(outs[N][0], outs[1024][0][:N]) and torch.equal(outs[N][1], outs[1024][1][:N])
+
+
+@pytest.mark.parametrize("integrator", ["etdrk4", "rk4", "rk45"])
+def test_same_step_auto_reset_every_integrator(gpu_device, integrator):
+    """max_sim_time = 1 s, n = 6: every env finishes at step 10, is reset in the same step call
+    (obs = reset observation, reward/done = the ended transition) and runs on with new events."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    N = 128
+    env = PVDERVec(N, device=gpu_device, integrator=integrator, n_sim_time_steps_per_env_step=6,
+                   max_sim_time=1.0, seed=77, auto_reset=True)
+    ob0 = env.reset().clone()
+    ev1 = env.ev_vg.clone()
+    a = torch.zeros(N, dtype=torch.uint8, device=gpu_device)
+    for t in range(1, 13):
+        obs, rew, done, _ = env.step(a)
+        if t == 10:
+            assert bool(done.all()) and env.step_stats()["n_done"] == N
+            assert torch.allclose(obs.double(), ob0.double(), atol=2e-6)        # reset observation
+            assert bool((rew != 0).all())                                        # reward of the ended transition
+            assert int(env.istate[2].min()) == 2 and int(env.istate[0].max()) == 0
+            assert not torch.equal(env.ev_vg, ev1)                               # fresh event draw (episode 2)
+        else:
+            assert not bool(done.any())
+    assert int(env.steps.min()) == 2 and int(env.steps.max()) == 2
+    assert float(obs[:, 10].min()) == pytest.approx(2 * 6 / 60.0, rel=1e-6)    # tStart/max_sim_time
