@@ -1222,7 +1222,8 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     // Balanced fast path first, then the full kernel for the envs it deferred (unbalanced state or
     // duty cycle near its limit; none in PVDER-v0 rollouts: every workgroup of the second launch
     // then exits after one status read).  PVDER_ETD_VARIANT=full runs the full kernel alone (A/B).
-    static const bool full_only = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
+    static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
+    const bool full_only = full_env || (cfg->reserved & 1);      // cfg->reserved bit 0: same switch per call
     if (full_only) {
         if (clr) (void)hipMemsetAsync(clr, 0, 4 * sizeof(float), st);     // (A/B variant only)
         hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,

@@ -282,6 +282,7 @@ class PVDERVec(EnvSpecMixin):
         self._keep_events = False
 
     _keep_events = False
+    _debug_knob = 0          # pvder_step_cfg.reserved (tests only)
 
     # -- launch plumbing --------------------------------------------------------------------------
     def _cfg(self) -> _native.StepCfg:
@@ -299,6 +300,7 @@ class PVDERVec(EnvSpecMixin):
         c.p_target = self.env_reward_spec['reference_values']['P_ref'] / der_model.SBASE   # :245
         c.q_target = self.env_reward_spec['reference_values']['Q_ref'] / der_model.SBASE   # :241
         c.rtol, c.atol = self.rtol, self.atol
+        c.reserved = self._debug_knob
         return c
 
     def _spec(self) -> _native.EventSpec:

@@ -93,7 +93,8 @@ typedef struct pvder_step_cfg {
     int32_t ev_s0;        /* ksub of the first event  (t_events_start*60) */
     int32_t ev_ds;        /* ksub between events      (t_events_step*60)  */
     int32_t ev_count;     /* K events; event tables have K+1 rows (row 0 = nominal) */
-    int32_t reserved;
+    int32_t reserved;     /* integrator-specific test knob, 0 in production: RK45 = cap on attempts per
+                             sim time step; ETDRK4 bit 0 = run the full 23-state kernel only */
     double del_qref;      /* _delQref/Sbase   per env step (:617, :225) */
     double del_vdcref;    /* _delVdcref/Vdcbase per env step (:618, :229) */
     double inv_max_sim_time; /* obs[10] = tStart/max_sim_time (:540) */
