@@ -660,37 +660,37 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
                                           const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 vx, v2 qp, float delta,
                                           float qref, float vdcref, v2 &ni, v2 &nu, v2 *__restrict__ ns) {
     using namespace pvder;
-    const float Vdc = vx.x, xDC = vx.y, xQ = qp.x, xPLL = qp.y;
+    const float Vdc = vx.x;
     const v2 ma = fma2(bc2(P.KpG), ua, xa);
     const v2 aP = ma * ia, aQ = S.Asw[0] * ia, aI = ia * ia;
     const float Pt = 3.f * (aP.x + aP.y);
     const float Q = 1.5f * (aQ.x + aQ.y) + 3.f * K.qk * (aI.x + aI.y);
-    const float qerr = qref - Q;
-    const float iarR = xDC + P.KpDC * (vdcref - Vdc);
-    const float iarI = xQ - P.KpQ * qerr;
+    // packed outer loops: e = (Vdc_ref - Vdc, Q_ref - Q);  iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
+    const v2 e = mk2(vdcref - Vdc, qref - Q);
+    const v2 iar = fma2(mk2(P.KpDC, -P.KpQ), e, mk2(vx.y, qp.x));
+    v2 dpi = mk2(P.KiDC, -P.KiQ) * e;                                    // (dxDC, dxQ)
+    const v2 ir2 = iar * iar;
+    if (ir2.x + ir2.y > P.ilim2) {                                      // rare: current-limit anti-windup
+        dpi.x = (dpi.x * vx.y > 0.f) ? 0.f : dpi.x;
+        dpi.y = (dpi.y * qp.x > 0.f) ? 0.f : dpi.y;
+    }
     float s1, c1;
     Math<float>::sincos_turns(delta * (float)(1.0 / kTwoPi), s1, c1);
     v2 V1 = fma2(bc2(P.kviR), ia, S.A0); V1 = fma2(mk2(-P.kviI, P.kviI), swp(ia), V1);   // v_a (V2 = 0)
     const v2 t1 = V1 * mk2(c1, s1);
     const float vd = t1.x + t1.y;
-    const float dw = P.KpP * vd + xPLL;
+    const float dw = P.KpP * vd + qp.y;
     const float dwr = dw * P.iwb;
     const float cmf = K.hiLf * Vdc;
     v2 n = fma2(bc2(cmf), xa, S.D[0]);
     n = fma2(bc2(cmf * P.KpG - Ec.c0kp), ua, n);
     ni = fma2(mk2(dwr, -dwr), swp(ia), n);
-    nu = mk2(P.wp * iarR, P.wp * iarI);
+    nu = bc2(P.wp) * iar;
     ns[0] = bc2(P.KiG) * ua;
     const float ppv = ppv_of(P, S.pv1, Vdc);
     const float dVdc = (ppv - 0.25f * Vdc * Pt) * Math<float>::rcp(Vdc) * P.iC;
-    float dxDC = P.KiDC * (vdcref - Vdc);
-    float dxQ = -P.KiQ * qerr;
-    if (iarR * iarR + iarI * iarI > P.ilim2) {
-        dxDC = (dxDC * xDC > 0.f) ? 0.f : dxDC;
-        dxQ = (dxQ * xQ > 0.f) ? 0.f : dxQ;
-    }
-    ns[1] = mk2(dVdc, dxDC);
-    ns[2] = mk2(dxQ, P.KiP * vd);
+    ns[1] = mk2(dVdc, dpi.x);
+    ns[2] = mk2(dpi.y, P.KiP * vd);
     ns[3] = mk2(dw, 0.f);
     const v2 mm = ma * ma;
     return mm.x + mm.y;
