@@ -205,3 +205,30 @@ def test_mixed_batch_deferral_to_full_kernel(gpu_device):
     sat = np.zeros(N, dtype=bool); sat[3::4] = True
     assert rel_l2(fast[:, ~sat].reshape(-1, 11), full[:, ~sat].reshape(-1, 11)) < 1e-5
     assert rel_l2(fast[:, sat].reshape(-1, 11), full[:, sat].reshape(-1, 11)) < 2e-3
+
+
+def test_full_episode_drift_vs_converged_bridge(gpu_device):
+    """A complete PVDER-v0 episode (160 env steps = 40 s, 38 voltage/insolation events, random
+    actions): the fp32 ETDRK4 kernel must not drift away from the converged fp64 solution."""
+    N, steps = 8, 160
+    rng = np.random.default_rng(2718)
+    actions = rng.integers(0, 5, size=(steps, N))
+    env = make_vec(N, gpu_device, integrator="etdrk4", seed=1234, events_spec=both_events_spec(), auto_reset=False)
+    env.reset()
+    vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
+    ref = BridgeVecEnv(N, n=15, method="rk45", rtol=1e-8, atol=1e-11)
+    ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+    got, want, rmis = [], [], 0
+    for t in range(steps):
+        obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
+        o2, r2, d2 = ref.step(actions[t])
+        got.append(obs.cpu().numpy().astype(np.float64)); want.append(o2)
+        rmis += int((rew.cpu().numpy() != r2).sum())
+        assert np.array_equal(done.cpu().numpy(), d2)
+    assert bool(done.all()) and d2.all()                 # 160 * 0.25 s = max_sim_time
+    got, want = np.stack(got), np.stack(want)
+    err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
+    assert err.max() < FP32_TOL, "whole-episode rel-L2 %.3e" % err.max()
+    last = rel_l2(got[-20:].transpose(1, 0, 2).reshape(N, -1), want[-20:].transpose(1, 0, 2).reshape(N, -1), axis=1)
+    assert last.max() < FP32_TOL, "last 5 s rel-L2 %.3e (drift)" % last.max()
+    assert rmis <= 0.01 * N * steps                      # discrete reward: only threshold ties may differ
