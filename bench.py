@@ -61,26 +61,31 @@ def events_on_spec():
     return s
 
 
-def cpu_baseline(seconds: float):
+def cpu_baseline(seconds: float, seed: int = 1):
     """The oracle (fp64 SciPy-odeint restatement of the reference's step path, "port") timed on
     one host core the way the reference times itself: wall time around step (PVDER_env.py:140,193)."""
-    from oracle.pvder_oracle_env import OraclePVDER
-    import numpy as np
-    env = OraclePVDER(solver="reference", seed=1)      # PVDER-v0 defaults, voltage events on
-    env.reset()
-    rng = np.random.default_rng(0)
-    n, t_used = 0, 0.0
-    while t_used < seconds:
-        a = int(rng.integers(0, 5))
-        t0 = time.time()
-        _, _, done, _ = env.step(a)
-        t_used += time.time() - t0
-        n += 1
-        if done:
-            env.reset()
-    return {"value": n / t_used, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    from oracle.cpu_worker import run
+    v, n, used = run(seed, seconds)
+    return {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d env steps of 1 env, PVDER-v0 defaults (n=15, LSODA rtol=atol=1e-4, hmax=1/120), "
-                      "random actions, %.1f s of CPU" % (n, t_used)}
+                      "random actions, %.1f s of CPU" % (n, used)}
+
+
+def cpu_baseline_all_cores(seconds: float):
+    """BASELINE.md plan: one oracle env per process on every host core (the reference itself is
+    single-threaded; this is the most its CPU path can do on this box).  Plain child processes,
+    started before this process touches the GPU."""
+    import subprocess
+    # the GPU box gives one GPU's job a 16-core CPU share (os.cpu_count() reports the whole host)
+    n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py")]
+    procs = [subprocess.Popen(cmd + [str(100 + i), str(seconds)], stdout=subprocess.PIPE, text=True) for i in range(n)]
+    vals = []
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 6 + 120)
+        vals.append(float(out.split()[0]))
+    return {"value": float(sum(vals)), "unit": "env-steps/s", "cores": n, "kind": "port",
+            "sample": "%d processes x 1 env, %.1f s of CPU each, same settings as cpu_baseline" % (n, seconds)}
 
 
 def classic_rk4_leg(dev, N, n_sub, steps):
@@ -142,6 +147,15 @@ def main():
     n_gpus = world
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    # CPU legs first: they start child processes, which must happen before this process touches the GPU
+    cpu = {}
+    if world == 1 and dist is None and args.cpu_seconds > 0:
+        try:
+            cpu["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            cpu["cpu_baseline_all_cores"] = cpu_baseline_all_cores(min(args.cpu_seconds, 8.0))
+        except Exception as exc:      # a reported side number: never lose the GPU line over it
+            cpu.setdefault("cpu_baseline", {"value": None})
+            cpu["cpu_baseline"]["error"] = repr(exc)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -242,11 +256,7 @@ def main():
         }
         if world == 1 and args.classic_steps > 0 and args.integrator == "etdrk4":
             out["classic_rk4"] = classic_rk4_leg(dev, N, args.n_sub, args.classic_steps)
-        if world == 1 and args.cpu_seconds > 0:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-            except Exception as exc:      # the baseline is a reported side number: never lose the GPU line
-                out["cpu_baseline"] = {"value": None, "error": repr(exc)}
+        out.update(cpu)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -271,12 +271,13 @@ template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
     const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
     float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
-    T *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
+    T *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear,
+    int run_status) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     Lane<T> L;
     T y[NS], comp[NS];
-    prologue<T, NS>(C, fstate, istate, action, n_env, L, y);
+    prologue<T, NS>(C, fstate, istate, action, n_env, L, y, run_status);
 #pragma unroll
     for (int k = 0; k < NS; ++k) comp[k] = (T)0;
     const T h = (T)(1.0 / 60.0) / (T)C.micro;
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
 // reaches the saturation guard at any step, is left untouched and marked kDeferred: the full
 // kernel (step_etdrk4_kernel, launched right behind with run_status = kDeferred) advances it.
 // =============================================================================================
+template <int PH>
 __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
                                           const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 vx, v2 qp, float delta,
                                           float qref, float vdcref, v2 &ni, v2 &nu, v2 *__restrict__ ns) {
@@ -663,8 +665,8 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     const float Vdc = vx.x;
     const v2 ma = fma2(bc2(P.KpG), ua, xa);
     const v2 aP = ma * ia, aQ = S.Asw[0] * ia, aI = ia * ia;
-    const float Pt = 3.f * (aP.x + aP.y);
-    const float Q = 1.5f * (aQ.x + aQ.y) + 3.f * K.qk * (aI.x + aI.y);
+    const float Pt = (float)PH * (aP.x + aP.y);                          // PH identical phases
+    const float Q = (0.5f * PH) * (aQ.x + aQ.y) + (float)PH * K.qk * (aI.x + aI.y);
     // packed outer loops: e = (Vdc_ref - Vdc, Q_ref - Q);  iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
     const v2 e = mk2(vdcref - Vdc, qref - Q);
     const v2 iar = fma2(mk2(P.KpDC, -P.KpQ), e, mk2(vx.y, qp.x));
@@ -705,11 +707,12 @@ __device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
     return s.x + s.y;
 }
 
+template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
     const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
     int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
     const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
-    constexpr int NS = 23;
+    constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
     __shared__ __attribute__((aligned(16))) float Mlds[10 * 16];
     if (threadIdx.x < 10 * 16) Mlds[threadIdx.x] = (&Ec.m[0][0])[threadIdx.x];
@@ -720,8 +723,8 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
     bool defer = false;
     if (L.run) {
         v2 ia = pvder::mk2(ys[0], ys[1]), xa = pvder::mk2(ys[2], ys[3]), ua = pvder::mk2(ys[4], ys[5]);
-        v2 vx = pvder::mk2(ys[18], ys[19]), qp = pvder::mk2(ys[20], ys[21]), dl = pvder::mk2(ys[22], 0.f);
-        {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
+        v2 vx = pvder::mk2(ys[B], ys[B + 1]), qp = pvder::mk2(ys[B + 2], ys[B + 3]), dl = pvder::mk2(ys[B + 4], 0.f);
+        if constexpr (PH == 3) {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
             const float ei = unbalance2(ia, pvder::mk2(ys[6], ys[7]), pvder::mk2(ys[12], ys[13]));
             const float ex = unbalance2(xa, pvder::mk2(ys[8], ys[9]), pvder::mk2(ys[14], ys[15]));
             const float eu = unbalance2(ua, pvder::mk2(ys[10], ys[11]), pvder::mk2(ys[16], ys[17]));
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
                 const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mP1 = load_mat(Mq, EM_P1);
                 const Mat4 mA1 = load_mat(Mq, EM_A1), mB1 = load_mat(Mq, EM_B1), mC1 = load_mat(Mq, EM_C1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the reads up here (hipcc would sink them to their uses)
-                const float m2a = bal_eval(P, K, Ec, S, ia, xa, ua, vx, qp, dl.x, L.qref, L.vdcref, n1i, n1u, ns);
+                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, vx, qp, dl.x, L.qref, L.vdcref, n1i, n1u, ns);
                 v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
                 matvec(mE2, ia, ua, e2i, e2u);
                 matvec(mE, ia, ua, ei, eu);
@@ -765,14 +768,14 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
                 const Mat4 mA2 = load_mat(Mq, EM_A2), mB3 = load_mat(Mq, EM_B3), mC2 = load_mat(Mq, EM_C2),
                            mC4 = load_mat(Mq, EM_C4);          // prefetched behind evaluations 2-4
                 __builtin_amdgcn_sched_barrier(0);
-                bal_eval(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
                          pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);   // N2
                 v2 n23i = ni, n23u = nu;
                 ti = u3i; tu = u3u;                                             // U3
                 matvec(mA2, ni, nu, ti, tu);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
-                bal_eval(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
                          pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);   // N3
                 n23i += ni; n23u += nu;
                 ti = u4i; tu = u4u;                                             // U4
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
                 matvec(mC2, n23i, n23u, zi, zu);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
-                bal_eval(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], vx),
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], vx),
                          pvder::fma2(h1, ns[2], qp), dl.x + h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);         // N4
                 matvec(mC4, ni, nu, zi, zu);
                 // Kahan-compensated slow update
@@ -804,13 +807,15 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
             const v2 z[3] = {ia, xa, ua};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const v2 hz = pvder::bc2(-0.5f) * z[k], jz = pvder::swp(z[k]) * jh3;
-                const v2 zb = hz - jz, zc = hz + jz;
                 ys[2 * k] = z[k].x; ys[2 * k + 1] = z[k].y;
-                ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
-                ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
+                if constexpr (PH == 3) {
+                    const v2 hz = pvder::bc2(-0.5f) * z[k], jz = pvder::swp(z[k]) * jh3;
+                    const v2 zb = hz - jz, zc = hz + jz;
+                    ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
+                    ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
+                }
             }
-            ys[18] = vx.x; ys[19] = vx.y; ys[20] = qp.x; ys[21] = qp.y; ys[22] = dl.x;
+            ys[B] = vx.x; ys[B + 1] = vx.y; ys[B + 2] = qp.x; ys[B + 3] = qp.y; ys[B + 4] = dl.x;
             L.ksub += C.n_sub;
             L.steps += 1;
         }
@@ -821,7 +826,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
         L.run = false;
         L.live = false;
     }
-    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
+    epilogue<float, PH>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
 }
 
 // =============================================================================================
@@ -1122,7 +1127,7 @@ EtdK make_etd(const double *par, int micro) {
     E.sat2_event = (float)(ge * ge);
     E.sat2_smooth = (float)(gs * gs);
     // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
-    E.rk4_sub = (4096 + micro - 1) / micro;
+    E.rk4_sub = (4096 + micro - 1) / micro;      // (three-phase full kernel only)
     if (E.rk4_sub < 1) E.rk4_sub = 1;
     return E;
 }
@@ -1194,10 +1199,10 @@ int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder
                            out, acc, n_env, clr);
     else if (ph == 3)
         hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, clr);
+                           action, out, acc, n_env, clr, 0);
     else
         hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, clr);
+                           action, out, acc, n_env, clr, 0);
     return hip_rc(hipGetLastError());
 }
 
@@ -1207,7 +1212,7 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     int rc = check_common(par, cfg, n_env);
     if (rc) return rc;
     if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
-    if ((int)par[PVDER_PAR_PHASES] != 3) return PVDER_EINVAL;     // three-phase model only
+    const int ph = (int)par[PVDER_PAR_PHASES];
     ResetK R;
     rc = fold_reset(par, cfg, ar, R);
     if (rc) return rc;
@@ -1224,12 +1229,21 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     // then exits after one status read).  PVDER_ETD_VARIANT=full runs the full kernel alone (A/B).
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     const bool full_only = full_env || (cfg->reserved & 1);      // cfg->reserved bit 0: same switch per call
-    if (full_only) {
+    if (ph == 1) {
+        // single phase: the "balanced" kernel IS the model; an env whose duty cycle reaches the guard
+        // is redone by classic RK4 micro-steps (8192 per 1/60 s: poles at 1.0e6 rad/s) in the follow-up
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
+                           action, out, acc, n_env, clr);
+        StepK<float> C4 = C;
+        C4.micro = 8192;
+        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C4, R, fstate, istate, ev_vg, ev_si,
+                           action, out, acc, n_env, (float *)nullptr, (int)kDeferred);
+    } else if (full_only) {
         if (clr) (void)hipMemsetAsync(clr, 0, 4 * sizeof(float), st);     // (A/B variant only)
         hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
                            out, acc, n_env, 0);
     } else {
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
                            action, out, acc, n_env, clr);
         hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
                            out, acc, n_env, (int)kDeferred);

@@ -124,7 +124,7 @@ class PVDERVec(EnvSpecMixin):
         goals_list, n_sim_time_steps_per_env_step, max_sim_time, DISCRETE_REWARD
         num_envs:   N
         device:     torch device (a ROCm GPU)
-        integrator: 'etdrk4' (fp32 fixed-step exponential RK4, default for the three-phase model),
+        integrator: 'etdrk4' (fp32 fixed-step exponential RK4, default),
                     'rk4' (fp32 fixed-step classic RK4 micro-stepping) or 'rk45' (fp64 adaptive
                     Dormand-Prince)
         micro_steps: integrator steps per 1/60 s sim time step (default 8 / 4096)
@@ -147,11 +147,9 @@ class PVDERVec(EnvSpecMixin):
         if model_type not in self.env_model_spec:
             raise ValueError("model_type must be one of %s" % list(self.env_model_spec))
         if integrator is None:
-            integrator = "etdrk4" if model_type == 'model_2' else "rk4"
+            integrator = "etdrk4"
         if integrator not in ("etdrk4", "rk4", "rk45"):
             raise ValueError("integrator must be 'etdrk4', 'rk4' or 'rk45'")
-        if integrator == "etdrk4" and model_type != 'model_2':
-            raise ValueError("integrator 'etdrk4' is implemented for the three-phase model (model_2) only")
         if micro_steps is None:
             micro_steps = DEFAULT_MICRO[integrator]
             if integrator == "rk4" and model_type == 'model_1':

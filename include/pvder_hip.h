@@ -158,7 +158,6 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
  * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (exponential-time-differencing Runge-Kutta 4,
  *   Krogstad form): the stiff filter-current/controller pair of each phase is propagated with
  *   the exact matrix exponential, the other 11 states by classic RK4; cfg->micro ~ 8.
- *   Three-phase model only (PVDER_EINVAL otherwise).
  * pvder_step_rk4_f32: fp32 fixed-step classic RK4 micro-stepping (cfg->micro ~ 4096),
  *   Kahan-compensated state update. */
 int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,

@@ -104,8 +104,6 @@ def test_argument_validation_mirrors_reference_setters():
     with pytest.raises(ValueError):
         PVDERVec(4, integrator="euler")
     with pytest.raises(ValueError):
-        PVDERVec(4, integrator="etdrk4", model_type="model_1")     # exponential scheme: three-phase only
-    with pytest.raises(ValueError):
         PVDERVec(4, micro_steps=0)
     with pytest.raises(ValueError):
         PVDERVec(4, DISCRETE_REWARD="yes")
