@@ -36,7 +36,7 @@ constexpr int kDeferred = -1; // transient istate status: "advance me in the fol
 
 template <typename T>
 struct StepK {
-    int n_sub, micro, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it;
+    int n_sub, micro, micro2, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it;
     T dq, dv, inv_tmax, p_t, q_t, rtol, atol;
 };
 
@@ -249,17 +249,23 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
         out[PVDER_O_REWARD * N + e] = reward;
         out[PVDER_O_DONE * N + e] = (T)done_f;
     }
-    // ---- wave-level reduction of the step statistics, one atomic per wave
+    // ---- statistics: wave-level butterfly reduction, the 4 waves of the workgroup combined through
+    // LDS, then ONE atomic per workgroup and statistic (same-address float atomics serialise at the
+    // memory side at ~12 ns each: 1024 per-wave atomics cost more than the rest of the epilogue)
     if (stats) {
+        __shared__ float wsum[4][kBlock / 64];
         const float r = wave_sum(L.run ? (float)reward : 0.f);
         const float d = wave_sum(done_f);
         const float nf = wave_sum(nonfinite);
         const float ba = wave_sum(L.live ? L.bad_action : 0.f);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[0], r);
-            if (d != 0.f) atomicAdd(&stats[1], d);
-            if (nf != 0.f) atomicAdd(&stats[2], nf);
-            if (ba != 0.f) atomicAdd(&stats[3], ba);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { wsum[0][w] = r; wsum[1][w] = d; wsum[2][w] = nf; wsum[3][w] = ba; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < kBlock / 64; ++k) t += wsum[threadIdx.x][k];
+            if (t != 0.f) atomicAdd(&stats[threadIdx.x], t);
         }
     }
 }
@@ -415,11 +421,13 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 // dynamics; such (rare) steps are redone by classic RK4 micro-steps from the saved state.
 // =============================================================================================
 struct EtdK {
-    float m[10][16];        // E2,E,P1,A1,A2,B1,B3,C1,C2,C4: per entry (re,re),(-im,im) for 11,12,21,22
+    // two step sizes: set 0 for h = 1/(60*micro) (sim time steps that start at an input jump),
+    // set 1 for h = 1/(60*micro_coarse) (all others)
+    float m[2][10][16];     // E2,E,P1,A1,A2,B1,B3,C1,C2,C4: per entry (re,re),(-im,im) for 11,12,21,22
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
-    int rk4_sub;            // classic RK4 micro-steps replacing one ETD step in the fallback
+    int rk4_sub[2];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
 };
 enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
 
@@ -538,8 +546,8 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
     // model constants (they would be spilled to VGPR lanes and read back with v_readlane in the
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
     // the same address: conflict-free, no VALU issue slot).
-    __shared__ __attribute__((aligned(16))) float Mlds[10 * 16];
-    if (threadIdx.x < 10 * 16) Mlds[threadIdx.x] = (&Ec.m[0][0])[threadIdx.x];
+    __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
+    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = (&Ec.m[0][0][0])[k];
     __syncthreads();
     Lane<float> L;
     float ys[NS];
@@ -549,10 +557,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
         to_pairs(ys, y);
 #pragma unroll
         for (int k = 0; k < NP; ++k) comp[k] = pvder::bc2(0.f);
-        const float h = (float)(1.0 / 60.0) / (float)C.micro;
-        const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
         const v2 two = pvder::bc2(2.f);
-        const float tq = 2.f / (float)C.micro;
         const pvder::PkConst K = pvder::make_pkconst(P);
         // slow pairs of the packed layout: x_a, x_b, x_c, (Vdc,xDC), (xQ,xPLL), (delta,0)
         constexpr int SL[6] = {1, 4, 7, 9, 10, 11};
@@ -562,12 +567,22 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             const bool input_jump = row != prev_row;          // a grid-voltage / insolation event starts here
             prev_row = row;
+            // two-rate schedule: the sim time step that starts at an input jump (new action: s == 0;
+            // new event row) takes C.micro steps, every other one C.micro2 (DESIGN.md "Step schedule")
+            // (wave-uniform: if any env of the wave has a jump here the whole wave takes the fine rate --
+            // never less accurate, and the step loop keeps a scalar trip count)
+            const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
+            const int nst = fine ? C.micro : C.micro2;
+            const int rk4_sub = fine ? Ec.rk4_sub[0] : Ec.rk4_sub[1];
+            const float h = (float)(1.0 / 60.0) / (float)nst;
+            const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+            const float tq = 2.f / (float)nst;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
-            for (int j = 0; j < C.micro; ++j) {
+            for (int j = 0; j < nst; ++j) {
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
                 // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
                 // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
-                const lds_v4 *Mq = (const lds_v4 *)Mlds;
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 40);
                 asm volatile("" : "+v"(Mq));
                 const float t0 = (float)j * tq, t1 = ((float)j + 0.5f) * tq, t2 = ((float)j + 1.f) * tq;
                 v2 n1f[6], nf[6], nsl[6], ks[6], yt[NP], n23[6];
@@ -624,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
                 if (fmaxf(m2a, m2b) > guard) {
                     // duty cycle near its limit: anti-windup may switch the fast dynamics -> redo
                     // this step with classic RK4 micro-steps (rare; PVDER-v0 episodes never get here)
-                    rk4_pk_steps(P, K, S, y, comp, Ec.rk4_sub, h / (float)Ec.rk4_sub, t0, tq / (float)Ec.rk4_sub,
+                    rk4_pk_steps(P, K, S, y, comp, rk4_sub, h / (float)rk4_sub, t0, tq / (float)rk4_sub,
                                  L.qref, L.vdcref);
                 } else {
 #pragma unroll
@@ -714,8 +729,8 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
     const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
-    __shared__ __attribute__((aligned(16))) float Mlds[10 * 16];
-    if (threadIdx.x < 10 * 16) Mlds[threadIdx.x] = (&Ec.m[0][0])[threadIdx.x];
+    __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
+    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = (&Ec.m[0][0][0])[k];
     __syncthreads();
     Lane<float> L;
     float ys[NS];
@@ -732,8 +747,6 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
             defer = ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
         }
         v2 cx = pvder::bc2(0.f), cv = pvder::bc2(0.f), cq = pvder::bc2(0.f), cd = pvder::bc2(0.f);   // Kahan
-        const float h = (float)(1.0 / 60.0) / (float)C.micro;
-        const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
         const v2 two = pvder::bc2(2.f);
         const pvder::PkConst K = pvder::make_pkconst(P);
         pvder::SubPk S;
@@ -742,10 +755,15 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             const bool input_jump = row != prev_row;
             prev_row = row;
+            // two-rate schedule, wave-uniform (see step_etdrk4_kernel)
+            const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
+            const int nst = fine ? C.micro : C.micro2;
+            const float h = (float)(1.0 / 60.0) / (float)nst;
+            const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
-            for (int j = 0; j < C.micro && !defer; ++j) {
+            for (int j = 0; j < nst && !defer; ++j) {
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
-                const lds_v4 *Mq = (const lds_v4 *)Mlds;
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 40);
                 asm volatile("" : "+v"(Mq));
                 v2 n1i, n1u, ni, nu, ns[4], ks[4];
                 // software prefetch: issue the LDS reads of the six matrices applied to (z, N1) now,
@@ -1017,7 +1035,8 @@ ModelK<T> fold_params(const double *par, bool exp2_path) {
 template <typename T>
 StepK<T> fold_cfg(const pvder_step_cfg *c) {
     StepK<T> C;
-    C.n_sub = c->n_sub; C.micro = c->micro; C.max_ksub = c->max_ksub; C.max_steps = c->max_steps;
+    C.n_sub = c->n_sub; C.micro = c->micro; C.max_ksub = c->max_ksub;
+    C.micro2 = c->micro_coarse > 0 ? c->micro_coarse : c->micro; C.max_steps = c->max_steps;
     C.goal = c->goal; C.discrete = c->discrete; C.ev_s0 = c->ev_s0; C.ev_ds = c->ev_ds;
     C.ev_count = c->ev_count;
     C.max_it = c->reserved > 0 ? c->reserved : 20000000;   // RK45: attempts per sim time step
@@ -1090,7 +1109,7 @@ void pack_m2(const M2 &M, float *o) {
         o[4 * k + 2] = (float)(-e[k].imag()); o[4 * k + 3] = (float)e[k].imag();
     }
 }
-EtdK make_etd(const double *par, int micro) {
+EtdK make_etd(const double *par, int micro, int micro_coarse) {
     const double iLf = 1.0 / par[PVDER_PAR_LF];
     const cd kvi(par[PVDER_PAR_KVI_RE], par[PVDER_PAR_KVI_IM]);
     const cd Z0 = iLf * (kvi + par[PVDER_PAR_RF]) + cd(0.0, 1.0);
@@ -1100,24 +1119,30 @@ EtdK make_etd(const double *par, int micro) {
     const cd tr = L.a + L.d, det = L.a * L.d - L.b * L.c;
     const cd disc = std::sqrt(tr * tr - 4.0 * det);
     const cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
-    const double h = 1.0 / (60.0 * micro);
-    M2 ph[4], pf[4];      // phi_k(h L/2), phi_k(h L)
-    for (int k = 0; k < 4; ++k) {
-        ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
-        pf[k] = fun2(L, l1, l2, phi(k, h * l1), phi(k, h * l2));
-    }
     EtdK E;
     const M2 Z{};
-    pack_m2(ph[0], E.m[EM_E2]);
-    pack_m2(pf[0], E.m[EM_E]);
-    pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), E.m[EM_P1]);
-    pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), E.m[EM_A1]);
-    pack_m2(lin(h, ph[2], 0, Z, 0, Z), E.m[EM_A2]);
-    pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), E.m[EM_B1]);
-    pack_m2(lin(2 * h, pf[2], 0, Z, 0, Z), E.m[EM_B3]);
-    pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), E.m[EM_C1]);
-    pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), E.m[EM_C2]);
-    pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), E.m[EM_C4]);
+    const int mic[2] = {micro, micro_coarse};
+    for (int set = 0; set < 2; ++set) {
+        const double h = 1.0 / (60.0 * mic[set]);
+        M2 ph[4], pf[4];      // phi_k(h L/2), phi_k(h L)
+        for (int k = 0; k < 4; ++k) {
+            ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
+            pf[k] = fun2(L, l1, l2, phi(k, h * l1), phi(k, h * l2));
+        }
+        pack_m2(ph[0], E.m[set][EM_E2]);
+        pack_m2(pf[0], E.m[set][EM_E]);
+        pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), E.m[set][EM_P1]);
+        pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), E.m[set][EM_A1]);
+        pack_m2(lin(h, ph[2], 0, Z, 0, Z), E.m[set][EM_A2]);
+        pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), E.m[set][EM_B1]);
+        pack_m2(lin(2 * h, pf[2], 0, Z, 0, Z), E.m[set][EM_B3]);
+        pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), E.m[set][EM_C1]);
+        pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), E.m[set][EM_C2]);
+        pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), E.m[set][EM_C4]);
+        // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
+        E.rk4_sub[set] = (4096 + mic[set] - 1) / mic[set];      // (three-phase full kernel only)
+        if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;
+    }
     E.c0kp = (float)(c0 * kp);
     // Anti-windup switches the fast dynamics only while |m_p| > m_limit.  On a step that starts at
     // an input jump the under-damped current loop (zeta ~ 0.17) overshoots, so |m| may cross the
@@ -1126,9 +1151,6 @@ EtdK make_etd(const double *par, int micro) {
     const double ge = 0.97 * par[PVDER_PAR_M_LIMIT], gs = 0.998 * par[PVDER_PAR_M_LIMIT];
     E.sat2_event = (float)(ge * ge);
     E.sat2_smooth = (float)(gs * gs);
-    // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
-    E.rk4_sub = (4096 + micro - 1) / micro;      // (three-phase full kernel only)
-    if (E.rk4_sub < 1) E.rk4_sub = 1;
     return E;
 }
 
@@ -1218,7 +1240,7 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     if (rc) return rc;
     const ModelK<float> P = fold_params<float>(par, true);
     const StepK<float> C = fold_cfg<float>(cfg);
-    const EtdK E = make_etd(par, cfg->micro);
+    const EtdK E = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro);
     hipStream_t st = (hipStream_t)stream;
     float *acc, *clr;
     rc = stats_setup(stats, zero_stats, st, acc, clr);

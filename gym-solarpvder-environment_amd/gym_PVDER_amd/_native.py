@@ -34,7 +34,7 @@ class StepCfg(C.Structure):
                 ("ev_s0", C.c_int32), ("ev_ds", C.c_int32), ("ev_count", C.c_int32),
                 ("reserved", C.c_int32), ("del_qref", C.c_double), ("del_vdcref", C.c_double),
                 ("inv_max_sim_time", C.c_double), ("p_target", C.c_double), ("q_target", C.c_double),
-                ("rtol", C.c_double), ("atol", C.c_double)]
+                ("rtol", C.c_double), ("atol", C.c_double), ("micro_coarse", C.c_int32), ("pad_", C.c_int32)]
 
 
 class EventSpec(C.Structure):

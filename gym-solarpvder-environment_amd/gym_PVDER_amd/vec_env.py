@@ -29,6 +29,8 @@ MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
 # integrator steps per 1/60 s sim time step (DESIGN.md "Kernels"): classic RK4 is stability-bound
 # by the current loop (h <= ~4.5 us); ETDRK4 propagates that loop exactly and is accuracy-bound
 DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
+# ETDRK4 two-rate schedule: sim time steps that do not start at an input jump (new action / event)
+DEFAULT_MICRO_COARSE = 2
 
 OBSERVED_QUANTITIES = ['iaR', 'iaI', 'vaR', 'vaI', 'P_PCC', 'Q_PCC', 'Vdc', 'Ppv', 'Vdc_ref', 'Q_ref',
                        'tStart']         # PVDER_env.py:44-49
@@ -128,6 +130,8 @@ class PVDERVec(EnvSpecMixin):
                     'rk4' (fp32 fixed-step classic RK4 micro-stepping) or 'rk45' (fp64 adaptive
                     Dormand-Prince)
         micro_steps: integrator steps per 1/60 s sim time step (default 8 / 4096)
+        micro_coarse: ETDRK4 only -- steps per sim time step that does not start at an input jump
+                    (new action or event); default 2, 0 = uniform micro_steps
         auto_reset: reset finished envs inside ``step`` (their returned obs is the reset obs)
         model_type: 'model_2' (three phase, derId 50, the PVDER-v0 default) or 'model_1'
         seed / env_id_base: key of the on-device event generator (env_id_base = global index of
@@ -139,7 +143,8 @@ class PVDERVec(EnvSpecMixin):
     def __init__(self, num_envs: int, goals_list=('voltage_regulation',),
                  n_sim_time_steps_per_env_step: int = 15, max_sim_time: float = 40.0,
                  DISCRETE_REWARD: bool = True, device="cuda", integrator: Optional[str] = None,
-                 micro_steps: Optional[int] = None, auto_reset: bool = True, model_type: str = 'model_2',
+                 micro_steps: Optional[int] = None, micro_coarse: Optional[int] = None, auto_reset: bool = True,
+                 model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
                  events_spec: Optional[dict] = None):
         if not isinstance(num_envs, int) or num_envs < 1:
@@ -156,6 +161,11 @@ class PVDERVec(EnvSpecMixin):
                 micro_steps = 8192      # derId 10: current-loop poles at 1.02e6 rad/s (h <= 2.8 us)
         if isinstance(micro_steps, bool) or not isinstance(micro_steps, int) or micro_steps < 1:
             raise ValueError("micro_steps must be a positive integer")
+        if micro_coarse is None:
+            micro_coarse = min(DEFAULT_MICRO_COARSE, micro_steps) if integrator == "etdrk4" else 0
+        if isinstance(micro_coarse, bool) or not isinstance(micro_coarse, int) or micro_coarse < 0:
+            raise ValueError("micro_coarse must be a non-negative integer")
+        self.micro_coarse = int(micro_coarse)
         self.num_envs = num_envs
         self._set_n(n_sim_time_steps_per_env_step)
         self.max_sim_time_user = max_sim_time
@@ -287,6 +297,7 @@ class PVDERVec(EnvSpecMixin):
         c = _native.StepCfg()
         c.n_sub = self._n
         c.micro = self.micro_steps
+        c.micro_coarse = self.micro_coarse
         c.max_ksub = int(math.ceil(self._max_sim_time * 60.0 - 1e-6))
         c.max_steps = self.max_episode_steps
         c.goal = GOAL_IDS[self._goals_list[0]]                 # only the first goal counts (:234)

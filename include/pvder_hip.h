@@ -101,6 +101,10 @@ typedef struct pvder_step_cfg {
     double p_target;      /* P_ref/Sbase (:245) */
     double q_target;      /* Q_ref/Sbase (:241) */
     double rtol, atol;    /* RK45 only */
+    int32_t micro_coarse; /* ETDRK4 two-rate schedule: a sim time step that starts at an input jump (new
+                             action or new event row) takes `micro` steps, every other one
+                             `micro_coarse` (0 = same as micro).  PVDER defaults: 8 / 2 */
+    int32_t pad_;
 } pvder_step_cfg;
 
 /* ---- event generator spec for reset (PVDER_env.py:60-61, :400-411) */

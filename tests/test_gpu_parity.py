@@ -95,9 +95,12 @@ def test_rk45_f64_trajectory_vs_bridge(gpu_device):
         assert np.array_equal(rew.cpu().numpy(), r2)
 
 
-@pytest.mark.parametrize("n_sub,steps,micro", [(4, 20, 8), (15, 6, 8), (15, 6, 4)])
-def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, micro):
-    """fp32 ETDRK4 (8 steps per 1/60 s) vs the converged fp64 solution (C bridge RK45, rtol 1e-8)."""
+@pytest.mark.parametrize("n_sub,steps,micro,coarse", [(4, 20, 8, 2), (15, 6, 8, 2), (15, 6, 8, 0), (15, 6, 4, 2),
+                                                        (15, 6, 8, 4)])
+def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, micro, coarse):
+    """fp32 ETDRK4 vs the converged fp64 solution (C bridge RK45, rtol 1e-8): default two-rate
+    schedule (8 steps in a sim time step that starts at an input jump, 2 otherwise), uniform 8
+    (coarse = 0), and coarser variants."""
     N = 64
     rng = np.random.default_rng(17)
     actions = rng.integers(0, 5, size=(steps, N))
@@ -105,7 +108,7 @@ def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, mic
     spec["voltage"]["t_events_start"] = spec["insolation"]["t_events_start"] = 0.2
     spec["voltage"]["t_events_step"] = 0.2
     env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator="etdrk4", micro_steps=micro,
-                   seed=23, events_spec=spec, auto_reset=False)
+                   micro_coarse=coarse, seed=23, events_spec=spec, auto_reset=False)
     env.reset()
     vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
     ref = BridgeVecEnv(N, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11)
