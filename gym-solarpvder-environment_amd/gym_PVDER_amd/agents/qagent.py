@@ -1,0 +1,95 @@
+"""Device-resident tabular Q-learning over a batched PVDER-v0.
+
+Batched counterpart of the reference's ``QAgent`` (/root/reference/gym_PVDER/agents/qagent.py:10-135):
+same discretisation (6 bins per observation dimension over the Box(-10, 10) range, :35-45), same
+constant -2 initial table (:37), epsilon-greedy action choice (:63-68), the same update
+``Q <- (1-lr) Q + lr (r + gamma max_a' Q')`` for running envs (:88-95) and ``Q <- 0`` for the
+transition that ends an episode (:100-103), epsilon decayed once per episode
+(agent_utilities.py:79-84) -- but N environments learn into ONE table in lockstep, and nothing
+leaves the GPU: observations, actions, rewards and the table are device tensors, the env step is the
+fused HIP launch of PVDERVec.  (6^11 x 5 fp32 entries = 7.3 GB: fits a 288 GB MI355X many times.)
+When several envs hit the same (state, action) in one step, one of their updates wins.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from ..vec_env import PVDERVec
+
+
+class BatchedQAgent:
+    train_spec = {'LEARNING_RATE': 0.1, 'DISCOUNT': 0.95, 'EPISODES': 200, 'STATS_EVERY': 5}     # qagent.py:14-18
+    explore_spec = {'EPSILON_DECAY': 0.98, 'MIN_EPSILON': 0.001}                               # qagent.py:24-25
+
+    def __init__(self, env: PVDERVec, bins: int = 6, seed: int = 0):
+        if not isinstance(env, PVDERVec):
+            raise TypeError("env must be a PVDERVec")
+        self.env = env
+        self.bins = int(bins)
+        self.n_obs, self.n_act = 11, 5
+        dev = env.device
+        self.low, self.high = -10.0, 10.0                          # observation_space (PVDER_env.py:51)
+        self.win = (self.high - self.low) / self.bins              # discrete_os_win_size (qagent.py:38)
+        n_states = self.bins ** self.n_obs
+        self.q_table = torch.full((n_states, self.n_act), -2.0, dtype=torch.float32, device=dev)   # :37
+        self._strides = torch.tensor([self.bins ** (self.n_obs - 1 - k) for k in range(self.n_obs)],
+                                     dtype=torch.int64, device=dev)
+        self.epsilon = 1.0                                         # qagent.py:27
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.aggregate_episode_rewards: Dict[str, List[float]] = {'episode': [], 'average': [], 'max': [], 'min': []}
+
+    def get_discrete_state(self, obs: torch.Tensor) -> torch.Tensor:
+        """[N, 11] observations -> flat table row index [N] (qagent.py:43-45)."""
+        d = ((obs.to(torch.float32) - self.low) / self.win).to(torch.int64).clamp_(0, self.bins - 1)
+        return (d * self._strides).sum(dim=1)
+
+    def agent_action(self, obs: torch.Tensor) -> torch.Tensor:
+        """Greedy actions [N] uint8 (qagent.py:130-135)."""
+        return self.q_table[self.get_discrete_state(obs)].argmax(dim=1).to(torch.uint8)
+
+    def update_epsilon(self):                                       # agent_utilities.py:79-84
+        if self.epsilon > self.explore_spec['MIN_EPSILON']:
+            self.epsilon = max(self.explore_spec['MIN_EPSILON'], self.epsilon * self.explore_spec['EPSILON_DECAY'])
+
+    def train(self, episodes: Optional[int] = None) -> Dict[str, List[float]]:
+        """``episodes`` lockstep episodes of all N envs (the env must not auto-reset)."""
+        env = self.env
+        assert not env.auto_reset, "construct the PVDERVec with auto_reset=False: episodes are reset here"
+        lr, gamma = self.train_spec['LEARNING_RATE'], self.train_spec['DISCOUNT']
+        N = env.num_envs
+        episodes = self.train_spec['EPISODES'] if episodes is None else episodes
+        recent: List[torch.Tensor] = []
+        for episode in range(episodes):
+            s = self.get_discrete_state(env.reset())
+            ep_reward = torch.zeros(N, dtype=torch.float64, device=env.device)
+            alive = torch.ones(N, dtype=torch.bool, device=env.device)
+            for _ in range(env.max_episode_steps + 1):
+                greedy = self.q_table[s].argmax(dim=1)
+                rand_a = torch.randint(0, self.n_act, (N,), generator=self.gen, device=env.device)
+                explore = torch.rand(N, generator=self.gen, device=env.device) <= self.epsilon       # :63
+                a = torch.where(explore, rand_a, greedy)
+                obs, r, done, _ = env.step(a.to(torch.uint8))
+                s2 = self.get_discrete_state(obs)
+                r32 = r.to(torch.float32)
+                ep_reward += torch.where(alive, r.to(torch.float64), torch.zeros_like(ep_reward))
+                cur = self.q_table[s, a]
+                new_q = (1.0 - lr) * cur + lr * (r32 + gamma * self.q_table[s2].max(dim=1).values)   # :88-95
+                new_q = torch.where(done, torch.zeros_like(new_q), new_q)                              # :100-103
+                upd = alive                                      # finished envs return stale tuples
+                self.q_table.index_put_((s[upd], a[upd]), new_q[upd])
+                alive = alive & ~done
+                s = s2
+                if not bool(alive.any()):
+                    break
+            self.update_epsilon()
+            recent.append(ep_reward)
+            if episode % self.train_spec['STATS_EVERY'] == 0:                                           # :113-120
+                block = torch.stack(recent[-self.train_spec['STATS_EVERY']:])
+                self.aggregate_episode_rewards['episode'].append(episode)
+                self.aggregate_episode_rewards['average'].append(float(block.mean()))
+                self.aggregate_episode_rewards['max'].append(float(block.max()))
+                self.aggregate_episode_rewards['min'].append(float(block.min()))
+        return self.aggregate_episode_rewards
