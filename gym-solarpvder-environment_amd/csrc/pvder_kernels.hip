@@ -251,7 +251,7 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
     }
     // ---- statistics: wave-level butterfly reduction, the 4 waves of the workgroup combined through
     // LDS, then ONE atomic per workgroup and statistic (same-address float atomics serialise at the
-    // memory side at ~12 ns each: 1024 per-wave atomics cost more than the rest of the epilogue)
+    // memory side, ~12 ns each: 256 instead of 1024 of them per statistic)
     if (stats) {
         __shared__ float wsum[4][kBlock / 64];
         const float r = wave_sum(L.run ? (float)reward : 0.f);
