@@ -420,3 +420,81 @@ def make_event_table(spec: dict, sinsol0: float = 100.0, rng=None, counter_key=N
             si[j] = val
     v = spec["voltage"]
     return EventTable(t0=float(v["t_events_start"]), dt=float(v["t_events_step"]), vgrid=vg, sinsol=si)
+
+
+# --------------------------------------------------------------------------------------------
+# Analytic Jacobian (the reference passes one to LSODA: jacFlag=True, PVDER_env.py:386)
+# --------------------------------------------------------------------------------------------
+_JAC_CACHE: Dict[str, object] = {}
+
+
+def analytic_jacobian(m: DERModel):
+    """d rhs/dy of the un-saturated model as a compiled function J(y, t, vg, si, qref, vdcref),
+    derived symbolically (sympy) from the same equations as :func:`rhs` and lambdified with common
+    sub-expression elimination.  pvder ships a hand-written ``jac_ODE_model``; inside an anti-windup
+    branch callers fall back to :func:`jac_fd` (a Jacobian only steers LSODA's Newton iteration)."""
+    if m.der_id in _JAC_CACHE:
+        return _JAC_CACHE[m.der_id]
+    import sympy as sp
+    P = m.phases
+    n = m.n_states
+    ys = sp.symbols("y0:%d" % n, real=True)
+    t, vgm, sinsol, qref, vdcref = sp.symbols("t vg si qref vdcref", real=True)
+    b = 6 * P
+    Vdc, xDC, xQ, xPLL, wte = ys[b], ys[b + 1], ys[b + 2], ys[b + 3], ys[b + 4]
+    rot = [(1.0, 0.0), (-0.5, -math.sqrt(3) / 2), (-0.5, math.sqrt(3) / 2)][:P]
+    vga = vgm * m.vg_scale
+    kgR, kgI, kiR, kiI = m.kv_g.real, m.kv_g.imag, m.kv_i.real, m.kv_i.imag
+    iR = [ys[6 * p] for p in range(P)]; iI = [ys[6 * p + 1] for p in range(P)]
+    xR = [ys[6 * p + 2] for p in range(P)]; xI = [ys[6 * p + 3] for p in range(P)]
+    uR = [ys[6 * p + 4] for p in range(P)]; uI = [ys[6 * p + 5] for p in range(P)]
+    mR = [m.Kp_GCC * uR[p] + xR[p] for p in range(P)]; mI = [m.Kp_GCC * uI[p] + xI[p] for p in range(P)]
+    vtR = [mR[p] * Vdc / 2 for p in range(P)]; vtI = [mI[p] * Vdc / 2 for p in range(P)]
+    vR, vI = [], []
+    for p in range(P):
+        gR, gI = vga * rot[p][0], vga * rot[p][1]                      # vg_p
+        vR.append(kgR * gR - kgI * gI + kiR * iR[p] - kiI * iI[p])
+        vI.append(kgR * gI + kgI * gR + kiR * iI[p] + kiI * iR[p])
+    ReS = sum(vtR[p] * iR[p] + vtI[p] * iI[p] for p in range(P)) / 2
+    Qp = sum(vI[p] * iR[p] - vR[p] * iI[p] for p in range(P)) / 2
+    Vact = Vdc * VDCBASE
+    ppv = (m.Np * ISCR * (sinsol / 100.0) * Vact - m.Np * IRS * Vact * (sp.exp(m.pv_vt * Vdc) - 1)) / SBASE
+    iarR = xDC + m.Kp_DC * (vdcref - Vdc)
+    iarI = xQ - m.Kp_Q * (qref - Qp)
+    wt = WBASE * t
+    if P == 3:
+        vt_dom = [vR[p] * sp.cos(wt) - vI[p] * sp.sin(wt) for p in range(3)]
+        a120 = (-0.5, math.sqrt(3) / 2); a240 = (-0.5, -math.sqrt(3) / 2)
+        UsR = (2.0 / 3.0) * (vt_dom[0] + vt_dom[1] * a120[0] + vt_dom[2] * a240[0])
+        UsI = (2.0 / 3.0) * (vt_dom[1] * a120[1] + vt_dom[2] * a240[1])
+        vd = UsR * sp.cos(wte) + UsI * sp.sin(wte)
+    else:
+        al = vR[0] * sp.cos(wt) - vI[0] * sp.sin(wt)
+        be = vR[0] * sp.sin(wt) + vI[0] * sp.cos(wt)
+        vd = al * sp.cos(wte) + be * sp.sin(wte)
+    we = m.Kp_PLL * vd + xPLL + WBASE
+    wr = we / WBASE if m.opts.winv_is_pll else 1.0
+    f = [0] * n
+    for p in range(P):
+        rR = iarR * rot[p][0] - iarI * rot[p][1]
+        rI = iarR * rot[p][1] + iarI * rot[p][0]
+        f[6 * p] = (1.0 / m.Lf) * (-m.Rf * iR[p] - vR[p] + vtR[p]) + wr * iI[p]
+        f[6 * p + 1] = (1.0 / m.Lf) * (-m.Rf * iI[p] - vI[p] + vtI[p]) - wr * iR[p]
+        f[6 * p + 2] = m.Ki_GCC * uR[p]
+        f[6 * p + 3] = m.Ki_GCC * uI[p]
+        f[6 * p + 4] = m.wp * (-uR[p] + rR - iR[p])
+        f[6 * p + 5] = m.wp * (-uI[p] + rI - iI[p])
+    f[b] = (ppv - ReS) / (Vdc * m.C)
+    f[b + 1] = m.Ki_DC * (vdcref - Vdc)
+    f[b + 2] = -m.Ki_Q * (qref - Qp)
+    f[b + 3] = m.Ki_PLL * vd
+    f[b + 4] = we
+    J = sp.Matrix(f).jacobian(sp.Matrix(ys))
+    fn = sp.lambdify((ys, t, vgm, sinsol, qref, vdcref), J, modules="numpy", cse=True)
+
+    def jac(y, tt, vg, si, q, v):
+        return np.asarray(fn(tuple(float(v_) for v_ in y), float(tt), float(vg), float(si), float(q), float(v)),
+                          dtype=np.float64)
+
+    _JAC_CACHE[m.der_id] = jac
+    return jac

@@ -84,6 +84,7 @@ class OraclePVDER:
         self.rng = random.Random(seed)
         self.nfev = 0
         self.y = None
+        self._jac = None
 
     # -- reset (PVDER_env.py:316-334, 366-398) ------------------------------------------------
     def reset(self, event_table: Optional[pm.EventTable] = None, counter_key=None):
@@ -134,8 +135,16 @@ class OraclePVDER:
         return pm.rhs(self.model, y, t, vg, si, self.Q_ref, self.Vdc_ref)
 
     def jac(self, y, t):
-        vg, si = self.events.at(t, self.model.opts.event_inclusive)
-        return pm.jac_fd(self.model, y, t, vg, si, self.Q_ref, self.Vdc_ref)
+        """Analytic Jacobian (jacFlag=True, PVDER_env.py:386); finite differences inside an
+        anti-windup branch, where the analytic (un-saturated) expression does not apply."""
+        m = self.model
+        vg, si = self.events.at(t, m.opts.event_inclusive)
+        o = pm.algebraic(m, y, t, vg, si, self.Q_ref, self.Vdc_ref)
+        if max(abs(mm) for mm in o.m) > m.m_limit or abs(o.iref[0]) > m.iref_limit:
+            return pm.jac_fd(m, y, t, vg, si, self.Q_ref, self.Vdc_ref)
+        if self._jac is None:
+            self._jac = pm.analytic_jacobian(m)
+        return self._jac(y, t, vg, si, self.Q_ref, self.Vdc_ref)
 
     def integrate(self):
         """n output intervals of 1/60 s (np.linspace of :158).  "reference" = one odeint call per
