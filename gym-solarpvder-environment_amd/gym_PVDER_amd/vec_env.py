@@ -406,6 +406,29 @@ class PVDERVec(EnvSpecMixin):
         s = self.stats[4 * self._bank: 4 * self._bank + 4].tolist()
         return {"reward_sum": s[0], "n_done": int(s[1]), "n_nonfinite": int(s[2]), "n_bad_action": int(s[3])}
 
+    # -- checkpoint / resume (the reference has none: reset() rebuilds the sim) ----
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Everything a bit-exact resume needs: ODE states + refs, counters, event tables, RK45 step
+        sizes and the statistics banks (clones, safe to torch.save)."""
+        d = {"fstate": self.fstate.clone(), "istate": self.istate.clone(), "ev_vg": self.ev_vg.clone(),
+             "ev_si": self.ev_si.clone(), "out": self.out.clone(), "stats": self.stats.clone(),
+             "bank": torch.tensor(self._bank)}
+        if self.hstep is not None:
+            d["hstep"] = self.hstep.clone()
+        return d
+
+    def load_state_dict(self, d: Dict[str, torch.Tensor]):
+        for k in ("fstate", "istate", "ev_vg", "ev_si", "out", "stats"):
+            t = getattr(self, k)
+            if d[k].shape != t.shape or d[k].dtype != t.dtype:
+                raise ValueError("state_dict entry %r does not match this env (%s %s vs %s %s)"
+                                 % (k, tuple(d[k].shape), d[k].dtype, tuple(t.shape), t.dtype))
+            t.copy_(d[k])
+        if self.hstep is not None:
+            self.hstep.copy_(d["hstep"])
+        self._bank = int(d["bank"])
+        self._needs_reset = False
+
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------
     _timing = False
 

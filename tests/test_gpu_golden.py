@@ -277,3 +277,24 @@ def test_batched_q_agent_learns_on_device(gpu_device):
     assert -5 * 8 <= stats['min'][-1] <= stats['max'][-1] <= 8   # 8 one-second steps, rewards in {-5,-1,+1}
     a = agent.agent_action(env.obs)
     assert a.dtype == torch.uint8 and int(a.max()) <= 4
+
+
+def test_checkpoint_resume_is_bit_exact(gpu_device, tmp_path):
+    from gym_PVDER_amd.vec_env import PVDERVec
+    kw = dict(device=gpu_device, n_sim_time_steps_per_env_step=6, max_sim_time=1.0, seed=13)
+    env = PVDERVec(300, **kw)
+    env.reset()
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(2)
+    a = torch.randint(0, 5, (14, 300), generator=gen, device=gpu_device, dtype=torch.uint8)
+    for t in range(6):
+        env.step(a[t])
+    torch.save(env.state_dict(), tmp_path / "ckpt.pt")
+    ref = [tuple(x.clone() for x in env.step(a[t])[:3]) for t in range(6, 14)]      # crosses an auto-reset
+    env2 = PVDERVec(300, **kw)
+    env2.load_state_dict(torch.load(tmp_path / "ckpt.pt"))
+    for t in range(6, 14):
+        obs, rew, done, _ = env2.step(a[t])
+        assert torch.equal(obs, ref[t - 6][0]) and torch.equal(rew, ref[t - 6][1]) and torch.equal(done, ref[t - 6][2])
+    assert env2.step_stats() == env.step_stats()
+    with pytest.raises(ValueError):
+        PVDERVec(299, **kw).load_state_dict(env.state_dict())
