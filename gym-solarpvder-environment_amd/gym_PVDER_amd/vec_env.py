@@ -260,8 +260,8 @@ class PVDERVec(EnvSpecMixin):
                                 device=self.device)
 
     def update_env_events(self, event_spec_list: List[dict]):
-        """PVDER_env.py:413-438: mutate the event spec; new random events take effect at the next
-        reset (and immediately for running episodes' tables, as the reference regenerates)."""
+        """PVDER_env.py:413-438: mutate the event spec; as in the reference, an env that already has a
+        simulation attached gets a fresh random event draw at once (:435-438), states untouched."""
         assert isinstance(event_spec_list, list), 'event_spec_list should be a list!'
         for event_spec in event_spec_list:
             assert isinstance(event_spec, dict), 'Event spec should be a dictionary!'
@@ -277,6 +277,13 @@ class PVDERVec(EnvSpecMixin):
         if (K, s0, ds) != (self.ev_count, self.ev_s0, self.ev_ds):
             self._alloc_event_tables()
             self._needs_reset = True
+        elif not self._needs_reset and not self._keep_events:
+            # regenerate the event tables of the running episodes (new episode key -> new draw)
+            saved = (self.fstate.clone(), self.istate.clone(), self.out.clone())
+            self._reset_launch(None)
+            episode = self.istate[2].clone()
+            self.fstate.copy_(saved[0]); self.istate.copy_(saved[1]); self.out.copy_(saved[2])
+            self.istate[2].copy_(episode)
 
     def set_event_tables(self, vgrid: torch.Tensor, sinsol: torch.Tensor):
         """Explicit per-env event tables [K+1, N] (row 0 = nominal) -- parity runs share them

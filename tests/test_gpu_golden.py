@@ -122,6 +122,12 @@ def test_update_env_events(gpu_device):
     assert env.sim.simulation_events._events_spec['voltage']['min'] == 0.95
     vg = env._vec.ev_vg.cpu().numpy()
     assert vg[1:].min() < 0.98 and vg.min() >= 0.95
+    # with a simulation attached the events are redrawn at once (PVDER_env.py:435-438), state untouched
+    ob1, st1 = env._vec.out.clone(), env._vec.fstate.clone()
+    env.update_env_events([{'voltage': {'min': 0.9, 'max': 0.91}}])
+    vg2 = env._vec.ev_vg.cpu().numpy()
+    assert vg2[1:].max() <= 0.91 + 1e-6 and vg2[1:].min() >= 0.9 - 1e-6
+    assert torch.equal(env._vec.out, ob1) and torch.equal(env._vec.fstate, st1) and env.steps == 0
     with pytest.raises(ValueError):
         env.update_env_events([{'voltage': {'bogus': 1}}])
     with pytest.raises(ValueError):
