@@ -420,10 +420,13 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 // While a duty cycle is near its limit the conditional-integration anti-windup changes the fast
 // dynamics; such (rare) steps are redone by classic RK4 micro-steps from the saved state.
 // =============================================================================================
+// The coefficient matrices themselves (2 step sizes x 10 matrices x 16 floats: set 0 for
+// h = 1/(60*micro), the sim time steps that start at an input jump, set 1 for h = 1/(60*micro_coarse);
+// order E2,E,P1,A1,A2,B1,B3,C1,C2,C4; per complex entry (re,re),(-im,im) for 11,12,21,22) live in a
+// small device buffer filled once by the caller from pvder_etdrk4_coefficients(): as a by-value
+// kernel argument they made the kernarg segment 1.9 KB, which every workgroup re-reads at launch.
+constexpr int kCoefFloats = 2 * 10 * 16;
 struct EtdK {
-    // two step sizes: set 0 for h = 1/(60*micro) (sim time steps that start at an input jump),
-    // set 1 for h = 1/(60*micro_coarse) (all others)
-    float m[2][10][16];     // E2,E,P1,A1,A2,B1,B3,C1,C2,C4: per entry (re,re),(-im,im) for 11,12,21,22
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
@@ -529,10 +532,10 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
 }
 
 __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
-    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
-    int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env,
-    int run_status) {
+    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, const float *__restrict__ coef,
+    float *__restrict__ fstate, int32_t *__restrict__ istate, float *__restrict__ ev_vg,
+    float *__restrict__ ev_si, const uint8_t *__restrict__ action, float *__restrict__ out,
+    float *__restrict__ stats, int n_env, int run_status) {
     constexpr int NS = 23, NP = pvder::NP;
     const size_t N = (size_t)n_env;
     if (run_status == kDeferred) {
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
     // the same address: conflict-free, no VALU issue slot).
     __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
-    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = (&Ec.m[0][0][0])[k];
+    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = coef[k];
     __syncthreads();
     Lane<float> L;
     float ys[NS];
@@ -724,13 +727,14 @@ __device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
-    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, float *__restrict__ fstate,
-    int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
+    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, const float *__restrict__ coef,
+    float *__restrict__ fstate, int32_t *__restrict__ istate, float *__restrict__ ev_vg,
+    float *__restrict__ ev_si, const uint8_t *__restrict__ action, float *__restrict__ out,
+    float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
     __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
-    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = (&Ec.m[0][0][0])[k];
+    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = coef[k];
     __syncthreads();
     Lane<float> L;
     float ys[NS];
@@ -1109,7 +1113,7 @@ void pack_m2(const M2 &M, float *o) {
         o[4 * k + 2] = (float)(-e[k].imag()); o[4 * k + 3] = (float)e[k].imag();
     }
 }
-EtdK make_etd(const double *par, int micro, int micro_coarse) {
+EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* host, kCoefFloats, may be NULL */) {
     const double iLf = 1.0 / par[PVDER_PAR_LF];
     const cd kvi(par[PVDER_PAR_KVI_RE], par[PVDER_PAR_KVI_IM]);
     const cd Z0 = iLf * (kvi + par[PVDER_PAR_RF]) + cd(0.0, 1.0);
@@ -1120,6 +1124,8 @@ EtdK make_etd(const double *par, int micro, int micro_coarse) {
     const cd disc = std::sqrt(tr * tr - 4.0 * det);
     const cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
     EtdK E;
+    float scratch[kCoefFloats];
+    float(*m)[10][16] = reinterpret_cast<float(*)[10][16]>(coef ? coef : scratch);
     const M2 Z{};
     const int mic[2] = {micro, micro_coarse};
     for (int set = 0; set < 2; ++set) {
@@ -1129,16 +1135,16 @@ EtdK make_etd(const double *par, int micro, int micro_coarse) {
             ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
             pf[k] = fun2(L, l1, l2, phi(k, h * l1), phi(k, h * l2));
         }
-        pack_m2(ph[0], E.m[set][EM_E2]);
-        pack_m2(pf[0], E.m[set][EM_E]);
-        pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), E.m[set][EM_P1]);
-        pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), E.m[set][EM_A1]);
-        pack_m2(lin(h, ph[2], 0, Z, 0, Z), E.m[set][EM_A2]);
-        pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), E.m[set][EM_B1]);
-        pack_m2(lin(2 * h, pf[2], 0, Z, 0, Z), E.m[set][EM_B3]);
-        pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), E.m[set][EM_C1]);
-        pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), E.m[set][EM_C2]);
-        pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), E.m[set][EM_C4]);
+        pack_m2(ph[0], m[set][EM_E2]);
+        pack_m2(pf[0], m[set][EM_E]);
+        pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), m[set][EM_P1]);
+        pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), m[set][EM_A1]);
+        pack_m2(lin(h, ph[2], 0, Z, 0, Z), m[set][EM_A2]);
+        pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), m[set][EM_B1]);
+        pack_m2(lin(2 * h, pf[2], 0, Z, 0, Z), m[set][EM_B3]);
+        pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), m[set][EM_C1]);
+        pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), m[set][EM_C2]);
+        pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), m[set][EM_C4]);
         // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
         E.rk4_sub[set] = (4096 + mic[set] - 1) / mic[set];      // (three-phase full kernel only)
         if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;
@@ -1228,9 +1234,18 @@ int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder
     return hip_rc(hipGetLastError());
 }
 
+int pvder_etdrk4_coef_count(void) { return kCoefFloats; }
+
+int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, float *coef_host) {
+    if (!par || !cfg || !coef_host || cfg->micro < 1) return PVDER_EINVAL;
+    make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, coef_host);
+    return 0;
+}
+
 int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
-                          float *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action,
-                          float *out, float *stats, int zero_stats, int n_env, void *stream) {
+                          const float *coef, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                          const uint8_t *action, float *out, float *stats, int zero_stats, int n_env,
+                          void *stream) {
     int rc = check_common(par, cfg, n_env);
     if (rc) return rc;
     if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
@@ -1240,7 +1255,8 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     if (rc) return rc;
     const ModelK<float> P = fold_params<float>(par, true);
     const StepK<float> C = fold_cfg<float>(cfg);
-    const EtdK E = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro);
+    if (!coef) return PVDER_EINVAL;
+    const EtdK E = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, nullptr);
     hipStream_t st = (hipStream_t)stream;
     float *acc, *clr;
     rc = stats_setup(stats, zero_stats, st, acc, clr);
@@ -1254,7 +1270,7 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     if (ph == 1) {
         // single phase: the "balanced" kernel IS the model; an env whose duty cycle reaches the guard
         // is redone by classic RK4 micro-steps (8192 per 1/60 s: poles at 1.0e6 rad/s) in the follow-up
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si,
                            action, out, acc, n_env, clr);
         StepK<float> C4 = C;
         C4.micro = 8192;
@@ -1262,12 +1278,12 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
                            action, out, acc, n_env, (float *)nullptr, (int)kDeferred);
     } else if (full_only) {
         if (clr) (void)hipMemsetAsync(clr, 0, 4 * sizeof(float), st);     // (A/B variant only)
-        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
+        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si, action,
                            out, acc, n_env, 0);
     } else {
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si,
                            action, out, acc, n_env, clr);
-        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, fstate, istate, ev_vg, ev_si, action,
+        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si, action,
                            out, acc, n_env, (int)kDeferred);
     }
     return hip_rc(hipGetLastError());

@@ -20,11 +20,12 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
-           "pvder_reset_masked_f64", "pvder_step_etdrk4_f32", "pvder_step_rk4_f32", "pvder_step_rk45_f64"]
+           "pvder_reset_masked_f64", "pvder_step_etdrk4_f32", "pvder_step_rk4_f32", "pvder_step_rk45_f64",
+           "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients"]
 
 
 class StepCfg(C.Structure):
@@ -99,10 +100,12 @@ def lib() -> C.CDLL:
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp]
-    for name in ("pvder_step_etdrk4_f32", "pvder_step_rk4_f32"):
-        f = getattr(L, name)
-        f.restype = i32
-        f.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.pvder_step_rk4_f32.restype = i32
+    L.pvder_step_rk4_f32.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.pvder_step_etdrk4_f32.restype = i32
+    L.pvder_step_etdrk4_f32.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.pvder_etdrk4_coefficients.restype = i32
+    L.pvder_etdrk4_coefficients.argtypes = [dp, cfgp, C.POINTER(C.c_float)]
     L.pvder_step_rk45_f64.restype = i32
     L.pvder_step_rk45_f64.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     _lib = L

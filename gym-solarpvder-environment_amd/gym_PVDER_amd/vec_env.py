@@ -328,6 +328,18 @@ class PVDERVec(EnvSpecMixin):
         s.s_min, s.s_max = self.env_events_spec['insolation']['min'], self.env_events_spec['insolation']['max']
         return s
 
+    def _etd_coef(self, cfg) -> torch.Tensor:
+        """Device copy of the ETDRK4 coefficient block (host-folded in fp64 by the library), refreshed
+        only when the step sizes change."""
+        key = (cfg.micro, cfg.micro_coarse)
+        if getattr(self, "_coef_key", None) != key:
+            n = self._lib.pvder_etdrk4_coef_count()
+            host = (C.c_float * n)()
+            _native.check(self._lib.pvder_etdrk4_coefficients(self._par_c, C.byref(cfg), host), "pvder_etdrk4_coefficients")
+            self._coef = torch.tensor(list(host), dtype=torch.float32, device=self.device)
+            self._coef_key = key
+        return self._coef
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -393,7 +405,8 @@ class PVDERVec(EnvSpecMixin):
             self._bank ^= 1
             zs = 2 + self._bank
             if self.integrator == "etdrk4":
-                rc = self._lib.pvder_step_etdrk4_f32(*a, self.stats.data_ptr(), zs, self.num_envs, self._stream())
+                rc = self._lib.pvder_step_etdrk4_f32(*a[:3], self._etd_coef(cfg).data_ptr(), *a[3:],
+                                                     self.stats.data_ptr(), zs, self.num_envs, self._stream())
             elif self.integrator == "rk4":
                 rc = self._lib.pvder_step_rk4_f32(*a, self.stats.data_ptr(), zs, self.num_envs, self._stream())
             else:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 2
+#define PVDER_ABI_VERSION 3
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -165,9 +165,18 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
  * pvder_step_rk4_f32: fp32 fixed-step classic RK4 micro-stepping (cfg->micro ~ 4096),
  *   Kahan-compensated state update. */
 int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
-                          float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
-                          const uint8_t *action, float *out, float *stats, int zero_stats,
-                          int n_env, void *stream);
+                          const float *coef, float *fstate, int32_t *istate, float *ev_vg,
+                          float *ev_si, const uint8_t *action, float *out, float *stats,
+                          int zero_stats, int n_env, void *stream);
+
+/* ETDRK4 coefficient block: pvder_etdrk4_coef_count() floats (phi-function matrices of the constant
+ * stiff 2x2 block for the two step sizes 1/(60*micro) and 1/(60*micro_coarse), folded in fp64).
+ * pvder_etdrk4_coefficients() computes it on the HOST into coef_host; the caller uploads it once
+ * to a device buffer and passes that buffer as `coef` to every pvder_step_etdrk4_f32() call with the
+ * same par / micro / micro_coarse (kept out of the kernel-argument segment, which every workgroup
+ * re-reads at launch). */
+int pvder_etdrk4_coef_count(void);
+int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, float *coef_host);
 int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
                        float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                        const uint8_t *action, float *out, float *stats, int zero_stats, int n_env,
