@@ -26,6 +26,17 @@
 #include "pvder_model_pk.hpp"
 
 namespace {
+// Debug-only in-kernel timeline (tools/trace_timeline.py builds a separate library with
+// -DPVDER_TRACE; the shipped library compiles these to nothing).  Slot = 100 MHz wall clock of wave 0.
+#ifdef PVDER_TRACE
+__device__ unsigned long long g_trace[4096 * 32];
+#define PVDER_TRACE_AT(slot)                                                                   \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 32 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define PVDER_TRACE_AT(slot) do { } while (0)
+#endif
 
 using pvder::ModelK;
 using pvder::SubK;
@@ -678,7 +689,8 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
 template <int PH>
 __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
                                           const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 vx, v2 qp, float delta,
-                                          float qref, float vdcref, v2 &ni, v2 &nu, v2 *__restrict__ ns) {
+                                          float qref, float vdcref, v2 kpo, v2 kio, v2 &ni, v2 &nu,
+                                          v2 *__restrict__ ns) {
     using namespace pvder;
     const float Vdc = vx.x;
     const v2 ma = fma2(bc2(P.KpG), ua, xa);
@@ -687,8 +699,8 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     const float Q = (0.5f * PH) * (aQ.x + aQ.y) + (float)PH * K.qk * (aI.x + aI.y);
     // packed outer loops: e = (Vdc_ref - Vdc, Q_ref - Q);  iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
     const v2 e = mk2(vdcref - Vdc, qref - Q);
-    const v2 iar = fma2(mk2(P.KpDC, -P.KpQ), e, mk2(vx.y, qp.x));
-    v2 dpi = mk2(P.KiDC, -P.KiQ) * e;                                    // (dxDC, dxQ)
+    const v2 iar = fma2(kpo, e, mk2(vx.y, qp.x));
+    v2 dpi = kio * e;                                                    // (dxDC, dxQ)
     const v2 ir2 = iar * iar;
     if (ir2.x + ir2.y > P.ilim2) {                                      // rare: current-limit anti-windup
         dpi.x = (dpi.x * vx.y > 0.f) ? 0.f : dpi.x;
@@ -733,9 +745,11 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
     float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
     constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
+    PVDER_TRACE_AT(0);
     __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
     for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = coef[k];
     __syncthreads();
+    PVDER_TRACE_AT(1);
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
@@ -753,9 +767,22 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
         v2 cx = pvder::bc2(0.f), cv = pvder::bc2(0.f), cq = pvder::bc2(0.f), cd = pvder::bc2(0.f);   // Kahan
         const v2 two = pvder::bc2(2.f);
         const pvder::PkConst K = pvder::make_pkconst(P);
+        // outer-loop gains (Kp_DC, -Kp_Q), (Ki_DC, -Ki_Q), pinned to SGPRs.  Left to itself hipcc
+        // merges the adjacent kernarg fields into one 12-byte memcpy to a private slot, promotes that
+        // slot to LDS and -- to index it by flat work-item id -- makes every wave read the AQL
+        // dispatch packet (host memory, over PCIe) at kernel entry: workgroup starts then trickle in
+        // at ~100 ns each, 25 us for 256 workgroups (tools/trace_timeline.py, tools/dispatch_probe.hip).
+        float g_kpdc = P.KpDC, g_kpq = -P.KpQ, g_kidc = P.KiDC, g_kiq = -P.KiQ;
+        asm volatile("" : "+s"(g_kpdc), "+s"(g_kpq), "+s"(g_kidc), "+s"(g_kiq));
+        const v2 kpo = pvder::mk2(g_kpdc, g_kpq), kio = pvder::mk2(g_kidc, g_kiq);
         pvder::SubPk S;
         int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
+#ifdef PVDER_TRACE
+        if (threadIdx.x == 0 && blockIdx.x < 4096)      // forces the state loads to have landed
+            g_trace[blockIdx.x * 32 + 2] = wall_clock64() + (vx.x > 1e30f ? 1 : 0);
+#endif
         for (int s = 0; s < C.n_sub && !defer; ++s) {
+            if (s < 16) PVDER_TRACE_AT(3 + s);
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             const bool input_jump = row != prev_row;
             prev_row = row;
@@ -775,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
                 const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mP1 = load_mat(Mq, EM_P1);
                 const Mat4 mA1 = load_mat(Mq, EM_A1), mB1 = load_mat(Mq, EM_B1), mC1 = load_mat(Mq, EM_C1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the reads up here (hipcc would sink them to their uses)
-                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, vx, qp, dl.x, L.qref, L.vdcref, n1i, n1u, ns);
+                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, vx, qp, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns);
                 v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
                 matvec(mE2, ia, ua, e2i, e2u);
                 matvec(mE, ia, ua, ei, eu);
@@ -791,14 +818,14 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
                            mC4 = load_mat(Mq, EM_C4);          // prefetched behind evaluations 2-4
                 __builtin_amdgcn_sched_barrier(0);
                 bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
-                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);   // N2
+                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N2
                 v2 n23i = ni, n23u = nu;
                 ti = u3i; tu = u3u;                                             // U3
                 matvec(mA2, ni, nu, ti, tu);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
                 bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
-                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);   // N3
+                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N3
                 n23i += ni; n23u += nu;
                 ti = u4i; tu = u4u;                                             // U4
                 matvec(mB3, ni, nu, ti, tu);
@@ -806,7 +833,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
                 bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], vx),
-                         pvder::fma2(h1, ns[2], qp), dl.x + h * ns[3].x, L.qref, L.vdcref, ni, nu, ns);         // N4
+                         pvder::fma2(h1, ns[2], qp), dl.x + h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);         // N4
                 matvec(mC4, ni, nu, zi, zu);
                 // Kahan-compensated slow update
                 v2 inc, tsum;
@@ -842,6 +869,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
             L.steps += 1;
         }
     }
+    PVDER_TRACE_AT(20);
     if (defer) {
         // hand the env over untouched: nothing stored but the marker, nothing added to the stats
         istate[PVDER_I_STATUS * N + L.e] = kDeferred;
@@ -849,6 +877,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
         L.live = false;
     }
     epilogue<float, PH>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
+    PVDER_TRACE_AT(21);
 }
 
 // =============================================================================================
@@ -1323,5 +1352,11 @@ int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvde
     }
     return hip_rc(hipGetLastError());
 }
+
+#ifdef PVDER_TRACE
+int pvder_debug_trace(unsigned long long *host, int n_words) {
+    return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * (size_t)n_words);
+}
+#endif
 
 }  // extern "C"
