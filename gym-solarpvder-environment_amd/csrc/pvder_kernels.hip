@@ -445,6 +445,24 @@ struct EtdK {
 };
 enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
 
+// The ONE by-value argument of the two ETDRK4 kernels (kernarg offset 0).  A single struct so that
+// the out-of-line 23-state path (etdrk4_full_path, a real function call) can read the same arguments straight from the kernarg segment instead of having ~130
+// scalars passed to it.
+struct EtdArgs {
+    ModelK<float> P;
+    StepK<float> C;
+    ResetK R;
+    EtdK Ec;
+    const float *coef;
+    float *fstate;
+    int32_t *istate;
+    float *ev_vg, *ev_si;
+    const uint8_t *action;
+    float *out;
+    float *stats, *stats_clear;
+    int n_env, run_status;
+};
+
 typedef float v4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4 lds_v4;     // LDS-resident coefficient entries
 
@@ -542,16 +560,40 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
     return fmaxf(fmaxf(a.x + a.y, b.x + b.y), c.x + c.y);
 }
 
-__global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
-    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, const float *__restrict__ coef,
-    float *__restrict__ fstate, int32_t *__restrict__ istate, float *__restrict__ ev_vg,
-    float *__restrict__ ev_si, const uint8_t *__restrict__ action, float *__restrict__ out,
-    float *__restrict__ stats, int n_env, int run_status) {
+// The 23-state ETDRK4 path.  ONE compiled copy, out of line ON PURPOSE: step_etdrk4_kernel is just a
+// call of it (tail = 0: the whole launch, A.run_status selects the envs), and the workgroups of
+// step_etdrk4_bal_kernel<3> call it for the lanes they must defer (tail = 1: `defer` flags those
+// lanes, whose state in memory is untouched; every other lane of the workgroup is finished).  Inlined
+// into the balanced kernel it drags that kernel's hot loop to 256 VGPRs + AGPR copies; as a call it
+// costs the fast path one workgroup-wide OR.  The arguments are re-read from the caller's kernarg
+// segment (EtdArgs is the only argument of both kernels; llvm.amdgcn.kernarg.segment.ptr itself is
+// null inside a callee, so the kernel passes the address, made wave-uniform again here so that the
+// reads stay scalar loads).
+typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
+__device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsigned ka_hi, int tail_i, int defer_i) {
+    const unsigned long long ka = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_hi) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)ka_lo);
+    const EtdArgs &A = *(const EtdArgs *)(KernargPtr)ka;
+    const bool tail = __builtin_amdgcn_readfirstlane(tail_i) != 0, defer = defer_i != 0;
+    const int run_status = tail ? 0 : A.run_status;
+    const ModelK<float> &P = A.P;
+    const StepK<float> &C = A.C;
+    const ResetK &R = A.R;
+    const EtdK &Ec = A.Ec;
+    const float *__restrict__ coef = A.coef;
+    float *__restrict__ fstate = A.fstate;
+    int32_t *__restrict__ istate = A.istate;
+    float *__restrict__ ev_vg = A.ev_vg;
+    float *__restrict__ ev_si = A.ev_si;
+    const uint8_t *__restrict__ action = A.action;
+    float *__restrict__ out = A.out;
+    float *__restrict__ stats = A.stats;
+    const int n_env = A.n_env;
     constexpr int NS = 23, NP = pvder::NP;
     const size_t N = (size_t)n_env;
-    if (run_status == kDeferred) {
-        // follow-up launch behind step_etdrk4_bal_kernel: leave at once unless this workgroup holds
-        // a deferred env (in PVDER-v0 rollouts it never does)
+    if (!tail && run_status == kDeferred) {
+        // follow-up launch behind a fast-path kernel: leave at once unless this workgroup holds a
+        // deferred env
         const int e0 = blockIdx.x * kBlock + threadIdx.x;
         const int mine = (e0 < n_env) && istate[PVDER_I_STATUS * N + e0] == kDeferred;
         if (!__syncthreads_or(mine)) return;
@@ -566,6 +608,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(C, fstate, istate, action, n_env, L, ys, run_status);
+    if (tail) L.live = L.run = L.run && defer;     // everyone else in the workgroup is done already
     if (L.run) {
         v2 y[NP], comp[NP];
         to_pairs(ys, y);
@@ -676,6 +719,11 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(
     epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
 }
 
+__global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(const EtdArgs A) {
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    etdrk4_full_path((unsigned)ka, (unsigned)(ka >> 32), 0, 0);
+}
+
 // =============================================================================================
 // ETDRK4, balanced fast path.  PVDER-v0 feeds the 'ThreePhaseUnbalanced' model a balanced grid
 // (unbalance ratios 1.0) from a balanced steady state, and the ODE maps balanced states to balanced
@@ -738,11 +786,21 @@ __device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
 }
 
 template <int PH>
-__global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
-    const ModelK<float> P, const StepK<float> C, const ResetK R, const EtdK Ec, const float *__restrict__ coef,
-    float *__restrict__ fstate, int32_t *__restrict__ istate, float *__restrict__ ev_vg,
-    float *__restrict__ ev_si, const uint8_t *__restrict__ action, float *__restrict__ out,
-    float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
+__global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A) {
+    const ModelK<float> &P = A.P;
+    const StepK<float> &C = A.C;
+    const ResetK &R = A.R;
+    const EtdK &Ec = A.Ec;
+    const float *__restrict__ coef = A.coef;
+    float *__restrict__ fstate = A.fstate;
+    int32_t *__restrict__ istate = A.istate;
+    float *__restrict__ ev_vg = A.ev_vg;
+    float *__restrict__ ev_si = A.ev_si;
+    const uint8_t *__restrict__ action = A.action;
+    float *__restrict__ out = A.out;
+    float *__restrict__ stats = A.stats;
+    float *__restrict__ stats_clear = A.stats_clear;
+    const int n_env = A.n_env;
     constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
     PVDER_TRACE_AT(0);
@@ -871,13 +929,21 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(
     }
     PVDER_TRACE_AT(20);
     if (defer) {
-        // hand the env over untouched: nothing stored but the marker, nothing added to the stats
-        istate[PVDER_I_STATUS * N + L.e] = kDeferred;
+        // hand the env over untouched: nothing stored, nothing added to the stats
+        if constexpr (PH == 1) istate[PVDER_I_STATUS * N + L.e] = kDeferred;     // marker for the follow-up launch
         L.run = false;
         L.live = false;
     }
     epilogue<float, PH>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
     PVDER_TRACE_AT(21);
+    if constexpr (PH == 3) {
+        // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the
+        // 23-state path right here -- no second launch
+        if (__syncthreads_or((int)defer)) {
+            const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+            etdrk4_full_path((unsigned)ka, (unsigned)(ka >> 32), 1, (int)defer);
+        }
+    }
 }
 
 // =============================================================================================
@@ -1282,38 +1348,37 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     ResetK R;
     rc = fold_reset(par, cfg, ar, R);
     if (rc) return rc;
-    const ModelK<float> P = fold_params<float>(par, true);
-    const StepK<float> C = fold_cfg<float>(cfg);
     if (!coef) return PVDER_EINVAL;
-    const EtdK E = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, nullptr);
+    EtdArgs A;
+    A.P = fold_params<float>(par, true);
+    A.C = fold_cfg<float>(cfg);
+    A.R = R;
+    A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, nullptr);
     hipStream_t st = (hipStream_t)stream;
     float *acc, *clr;
     rc = stats_setup(stats, zero_stats, st, acc, clr);
     if (rc) return rc;
+    A.coef = coef; A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
+    A.action = action; A.out = out; A.stats = acc; A.stats_clear = clr; A.n_env = n_env; A.run_status = 0;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    // Balanced fast path first, then the full kernel for the envs it deferred (unbalanced state or
-    // duty cycle near its limit; none in PVDER-v0 rollouts: every workgroup of the second launch
-    // then exits after one status read).  PVDER_ETD_VARIANT=full runs the full kernel alone (A/B).
+    // Three-phase: ONE launch -- the balanced fast path, whose workgroups call the 23-state path
+    // themselves for the envs they must defer (unbalanced state or duty cycle near its limit; none in
+    // PVDER-v0 rollouts).  PVDER_ETD_VARIANT=full runs the 23-state kernel alone (A/B).
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     const bool full_only = full_env || (cfg->reserved & 1);      // cfg->reserved bit 0: same switch per call
     if (ph == 1) {
         // single phase: the "balanced" kernel IS the model; an env whose duty cycle reaches the guard
-        // is redone by classic RK4 micro-steps (8192 per 1/60 s: poles at 1.0e6 rad/s) in the follow-up
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, clr);
-        StepK<float> C4 = C;
+        // is redone by classic RK4 micro-steps (8192 per 1/60 s: poles at 1.0e6 rad/s) in a follow-up
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
+        StepK<float> C4 = A.C;
         C4.micro = 8192;
-        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C4, R, fstate, istate, ev_vg, ev_si,
+        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, A.P, C4, A.R, fstate, istate, ev_vg, ev_si,
                            action, out, acc, n_env, (float *)nullptr, (int)kDeferred);
     } else if (full_only) {
         if (clr) (void)hipMemsetAsync(clr, 0, 4 * sizeof(float), st);     // (A/B variant only)
-        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si, action,
-                           out, acc, n_env, 0);
+        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, A);
     } else {
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, clr);
-        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, P, C, R, E, coef, fstate, istate, ev_vg, ev_si, action,
-                           out, acc, n_env, (int)kDeferred);
+        hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
     }
     return hip_rc(hipGetLastError());
 }
