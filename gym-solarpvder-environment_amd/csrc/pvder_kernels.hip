@@ -431,12 +431,13 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 // While a duty cycle is near its limit the conditional-integration anti-windup changes the fast
 // dynamics; such (rare) steps are redone by classic RK4 micro-steps from the saved state.
 // =============================================================================================
-// The coefficient matrices themselves (2 step sizes x 10 matrices x 16 floats: set 0 for
+// The coefficient matrices themselves (2 step sizes x 10 matrices x 8 floats: set 0 for
 // h = 1/(60*micro), the sim time steps that start at an input jump, set 1 for h = 1/(60*micro_coarse);
-// order E2,E,P1,A1,A2,B1,B3,C1,C2,C4; per complex entry (re,re),(-im,im) for 11,12,21,22) live in a
+// order E2,E,P1,A1,A2,B1,B3,C1,C2,C4; per complex entry (re, im) for 11,12,21,22) live in a
 // small device buffer filled once by the caller from pvder_etdrk4_coefficients(): as a by-value
 // kernel argument they made the kernarg segment 1.9 KB, which every workgroup re-reads at launch.
-constexpr int kCoefFloats = 2 * 10 * 16;
+constexpr int kMatFloats = 8;                      // 2x2 complex: (re, im) of entries 11, 12, 21, 22
+constexpr int kCoefFloats = 2 * 10 * kMatFloats;
 struct EtdK {
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
@@ -466,23 +467,28 @@ struct EtdArgs {
 typedef float v4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4 lds_v4;     // LDS-resident coefficient entries
 
-// one complex matrix entry c = (re, re, -im, im):  acc += c * z
-__device__ __forceinline__ v2 cmac(v2 acc, v4 c, v2 z) {
-    acc = pvder::fma2(pvder::mk2(c.x, c.y), z, acc);
-    return pvder::fma2(pvder::mk2(c.z, c.w), pvder::swp(z), acc);
+// one complex matrix entry c = (re, im):  acc += c * z  -- two v_pk_fma_f32: the broadcast of re / im,
+// the swap of z and the sign of the low product are operand modifiers (op_sel, op_sel_hi, neg_lo), so
+// an entry costs 2 floats of LDS and no moves
+// (hipcc folds the broadcast itself; the second one it would build with v_xor + v_mov, hence the asm:
+//  lo += -c.hi * z.hi,  hi += c.hi * z.lo)
+__device__ __forceinline__ v2 cmac(v2 acc, v2 c, v2 z) {
+    acc = pvder::fma2(pvder::bc2(c.x), z, acc);
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(c), "v"(z));
+    return acc;
 }
-struct Mat4 { v4 e[4]; };      // entries 11, 12, 21, 22
+struct Mat4 { v4 lo, hi; };    // lo = entries 11, 12;  hi = entries 21, 22
 __device__ __forceinline__ Mat4 load_mat(const lds_v4 *M, int k) {
     Mat4 m;
-    m.e[0] = M[4 * k + 0]; m.e[1] = M[4 * k + 1]; m.e[2] = M[4 * k + 2]; m.e[3] = M[4 * k + 3];   // ds_read_b128 x4
+    m.lo = M[2 * k + 0]; m.hi = M[2 * k + 1];        // ds_read_b128 x2
     return m;
 }
 // (oi, ou) += M * (ni, nu)
 __device__ __forceinline__ void matvec(const Mat4 &M, v2 ni, v2 nu, v2 &oi, v2 &ou) {
-    oi = cmac(oi, M.e[0], ni);
-    oi = cmac(oi, M.e[1], nu);
-    ou = cmac(ou, M.e[2], ni);
-    ou = cmac(ou, M.e[3], nu);
+    oi = cmac(oi, pvder::mk2(M.lo.x, M.lo.y), ni);
+    oi = cmac(oi, pvder::mk2(M.lo.z, M.lo.w), nu);
+    ou = cmac(ou, pvder::mk2(M.hi.x, M.hi.y), ni);
+    ou = cmac(ou, pvder::mk2(M.hi.z, M.hi.w), nu);
 }
 
 // N(y): fast part nf[2p] = N_i of phase p, nf[2p+1] = N_u; slow part ns[0..2] = dx_p,
@@ -602,8 +608,8 @@ __device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsig
     // model constants (they would be spilled to VGPR lanes and read back with v_readlane in the
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
     // the same address: conflict-free, no VALU issue slot).
-    __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
-    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = coef[k];
+    __shared__ __attribute__((aligned(16))) float Mlds[kCoefFloats];
+    for (int k = threadIdx.x; k < kCoefFloats; k += kBlock) Mlds[k] = coef[k];
     __syncthreads();
     Lane<float> L;
     float ys[NS];
@@ -639,7 +645,7 @@ __device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsig
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
                 // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
                 // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
-                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 40);
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 20);
                 asm volatile("" : "+v"(Mq));
                 const float t0 = (float)j * tq, t1 = ((float)j + 0.5f) * tq, t2 = ((float)j + 1.f) * tq;
                 v2 n1f[6], nf[6], nsl[6], ks[6], yt[NP], n23[6];
@@ -736,30 +742,32 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(const EtdArgs A) {
 // =============================================================================================
 template <int PH>
 __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
-                                          const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 vx, v2 qp, float delta,
+                                          const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 pa, v2 pb, float delta,
                                           float qref, float vdcref, v2 kpo, v2 kio, v2 &ni, v2 &nu,
                                           v2 *__restrict__ ns) {
     using namespace pvder;
-    const float Vdc = vx.x;
+    // slow pairs: pa = (xDC, xQ) -- the two outer PI integrators, pb = (Vdc, xPLL)
+    const float Vdc = pb.x;
     const v2 ma = fma2(bc2(P.KpG), ua, xa);
-    const v2 aP = ma * ia, aQ = S.Asw[0] * ia, aI = ia * ia;
-    const float Pt = (float)PH * (aP.x + aP.y);                          // PH identical phases
-    const float Q = (0.5f * PH) * (aQ.x + aQ.y) + (float)PH * K.qk * (aI.x + aI.y);
+    // dot products as mul + fma (written as sums of a packed product hipcc pairs them up through
+    // three v_mov); Q = Im S_PCC = PH (Asw/2 + qk i) . i
+    const float Pt = (float)PH * __builtin_fmaf(ma.y, ia.y, ma.x * ia.x);    // PH identical phases
+    const v2 tq = fma2(bc2((float)PH * K.qk), ia, bc2(0.5f * PH) * S.Asw[0]);
+    const float Q = __builtin_fmaf(tq.y, ia.y, tq.x * ia.x);
     // packed outer loops: e = (Vdc_ref - Vdc, Q_ref - Q);  iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
     const v2 e = mk2(vdcref - Vdc, qref - Q);
-    const v2 iar = fma2(kpo, e, mk2(vx.y, qp.x));
+    const v2 iar = fma2(kpo, e, pa);
     v2 dpi = kio * e;                                                    // (dxDC, dxQ)
     const v2 ir2 = iar * iar;
     if (ir2.x + ir2.y > P.ilim2) {                                      // rare: current-limit anti-windup
-        dpi.x = (dpi.x * vx.y > 0.f) ? 0.f : dpi.x;
-        dpi.y = (dpi.y * qp.x > 0.f) ? 0.f : dpi.y;
+        dpi.x = (dpi.x * pa.x > 0.f) ? 0.f : dpi.x;
+        dpi.y = (dpi.y * pa.y > 0.f) ? 0.f : dpi.y;
     }
     float s1, c1;
     Math<float>::sincos_turns(delta * (float)(1.0 / kTwoPi), s1, c1);
     v2 V1 = fma2(bc2(P.kviR), ia, S.A0); V1 = fma2(mk2(-P.kviI, P.kviI), swp(ia), V1);   // v_a (V2 = 0)
-    const v2 t1 = V1 * mk2(c1, s1);
-    const float vd = t1.x + t1.y;
-    const float dw = P.KpP * vd + qp.y;
+    const float vd = __builtin_fmaf(V1.y, s1, V1.x * c1);
+    const float dw = P.KpP * vd + pb.y;
     const float dwr = dw * P.iwb;
     const float cmf = K.hiLf * Vdc;
     v2 n = fma2(bc2(cmf), xa, S.D[0]);
@@ -769,11 +777,10 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     ns[0] = bc2(P.KiG) * ua;
     const float ppv = ppv_of(P, S.pv1, Vdc);
     const float dVdc = (ppv - 0.25f * Vdc * Pt) * Math<float>::rcp(Vdc) * P.iC;
-    ns[1] = mk2(dVdc, dpi.x);
-    ns[2] = mk2(dpi.y, P.KiP * vd);
+    ns[1] = dpi;
+    ns[2] = mk2(dVdc, P.KiP * vd);
     ns[3] = mk2(dw, 0.f);
-    const v2 mm = ma * ma;
-    return mm.x + mm.y;
+    return __builtin_fmaf(ma.y, ma.y, ma.x * ma.x);
 }
 
 // |z_b - z_a e^{-j120}|^2 + |z_c - z_a e^{+j120}|^2
@@ -804,8 +811,8 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
     constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
     PVDER_TRACE_AT(0);
-    __shared__ __attribute__((aligned(16))) float Mlds[2 * 10 * 16];
-    for (int k = threadIdx.x; k < 2 * 10 * 16; k += kBlock) Mlds[k] = coef[k];
+    __shared__ __attribute__((aligned(16))) float Mlds[kCoefFloats];
+    for (int k = threadIdx.x; k < kCoefFloats; k += kBlock) Mlds[k] = coef[k];
     __syncthreads();
     PVDER_TRACE_AT(1);
     Lane<float> L;
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
     bool defer = false;
     if (L.run) {
         v2 ia = pvder::mk2(ys[0], ys[1]), xa = pvder::mk2(ys[2], ys[3]), ua = pvder::mk2(ys[4], ys[5]);
-        v2 vx = pvder::mk2(ys[B], ys[B + 1]), qp = pvder::mk2(ys[B + 2], ys[B + 3]), dl = pvder::mk2(ys[B + 4], 0.f);
+        v2 pa = pvder::mk2(ys[B + 1], ys[B + 2]), pb = pvder::mk2(ys[B], ys[B + 3]), dl = pvder::mk2(ys[B + 4], 0.f);   // (xDC,xQ), (Vdc,xPLL)
         if constexpr (PH == 3) {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
             const float ei = unbalance2(ia, pvder::mk2(ys[6], ys[7]), pvder::mk2(ys[12], ys[13]));
             const float ex = unbalance2(xa, pvder::mk2(ys[8], ys[9]), pvder::mk2(ys[14], ys[15]));
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
         int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
 #ifdef PVDER_TRACE
         if (threadIdx.x == 0 && blockIdx.x < 4096)      // forces the state loads to have landed
-            g_trace[blockIdx.x * 32 + 2] = wall_clock64() + (vx.x > 1e30f ? 1 : 0);
+            g_trace[blockIdx.x * 32 + 2] = wall_clock64() + (pb.x > 1e30f ? 1 : 0);
 #endif
         for (int s = 0; s < C.n_sub && !defer; ++s) {
             if (s < 16) PVDER_TRACE_AT(3 + s);
@@ -852,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < nst && !defer; ++j) {
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
-                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 40);
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 20);
                 asm volatile("" : "+v"(Mq));
                 v2 n1i, n1u, ni, nu, ns[4], ks[4];
                 // software prefetch: issue the LDS reads of the six matrices applied to (z, N1) now,
@@ -860,7 +867,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mP1 = load_mat(Mq, EM_P1);
                 const Mat4 mA1 = load_mat(Mq, EM_A1), mB1 = load_mat(Mq, EM_B1), mC1 = load_mat(Mq, EM_C1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the reads up here (hipcc would sink them to their uses)
-                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, vx, qp, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns);
+                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, pa, pb, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns);
                 v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
                 matvec(mE2, ia, ua, e2i, e2u);
                 matvec(mE, ia, ua, ei, eu);
@@ -875,36 +882,35 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 const Mat4 mA2 = load_mat(Mq, EM_A2), mB3 = load_mat(Mq, EM_B3), mC2 = load_mat(Mq, EM_C2),
                            mC4 = load_mat(Mq, EM_C4);          // prefetched behind evaluations 2-4
                 __builtin_amdgcn_sched_barrier(0);
-                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
-                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N2
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], pa),
+                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N2
                 v2 n23i = ni, n23u = nu;
                 ti = u3i; tu = u3u;                                             // U3
                 matvec(mA2, ni, nu, ti, tu);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
-                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], vx),
-                         pvder::fma2(h2, ns[2], qp), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N3
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], pa),
+                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N3
                 n23i += ni; n23u += nu;
                 ti = u4i; tu = u4u;                                             // U4
                 matvec(mB3, ni, nu, ti, tu);
                 matvec(mC2, n23i, n23u, zi, zu);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
-                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], vx),
-                         pvder::fma2(h1, ns[2], qp), dl.x + h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);         // N4
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], pa),
+                         pvder::fma2(h1, ns[2], pb), dl.x + h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);         // N4
                 matvec(mC4, ni, nu, zi, zu);
                 // Kahan-compensated slow update
                 v2 inc, tsum;
                 inc = pvder::fma2(h6, ks[0] + ns[0], -cx); tsum = xa + inc; cx = (tsum - xa) - inc; const v2 xn = tsum;
-                inc = pvder::fma2(h6, ks[1] + ns[1], -cv); tsum = vx + inc; cv = (tsum - vx) - inc; const v2 vn = tsum;
-                inc = pvder::fma2(h6, ks[2] + ns[2], -cq); tsum = qp + inc; cq = (tsum - qp) - inc; const v2 qn = tsum;
+                inc = pvder::fma2(h6, ks[1] + ns[1], -cv); tsum = pa + inc; cv = (tsum - pa) - inc; const v2 vn = tsum;
+                inc = pvder::fma2(h6, ks[2] + ns[2], -cq); tsum = pb + inc; cq = (tsum - pb) - inc; const v2 qn = tsum;
                 inc = pvder::fma2(h6, ks[3] + ns[3], -cd); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
                 const v2 mn = pvder::fma2(pvder::bc2(P.KpG), zu, xn);
-                const v2 mn2 = mn * mn;
-                if (fmaxf(m2a, mn2.x + mn2.y) > guard) {
+                if (fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)) > guard) {
                     defer = true;      // near saturation: the full kernel redoes this env step
                 } else {
-                    ia = zi; ua = zu; xa = xn; vx = vn; qp = qn; dl = dn;
+                    ia = zi; ua = zu; xa = xn; pa = vn; pb = qn; dl = dn;
                 }
             }
         }
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                     ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
                 }
             }
-            ys[B] = vx.x; ys[B + 1] = vx.y; ys[B + 2] = qp.x; ys[B + 3] = qp.y; ys[B + 4] = dl.x;
+            ys[B] = pb.x; ys[B + 1] = pa.x; ys[B + 2] = pa.y; ys[B + 3] = pb.y; ys[B + 4] = dl.x;
             L.ksub += C.n_sub;
             L.steps += 1;
         }
@@ -1203,10 +1209,7 @@ M2 lin(double s1, const M2 &A, double s2, const M2 &B, double s3, const M2 &Cm) 
 }
 void pack_m2(const M2 &M, float *o) {
     const cd e[4] = {M.a, M.b, M.c, M.d};
-    for (int k = 0; k < 4; ++k) {
-        o[4 * k + 0] = (float)e[k].real(); o[4 * k + 1] = (float)e[k].real();
-        o[4 * k + 2] = (float)(-e[k].imag()); o[4 * k + 3] = (float)e[k].imag();
-    }
+    for (int k = 0; k < 4; ++k) { o[2 * k] = (float)e[k].real(); o[2 * k + 1] = (float)e[k].imag(); }
 }
 EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* host, kCoefFloats, may be NULL */) {
     const double iLf = 1.0 / par[PVDER_PAR_LF];
@@ -1220,7 +1223,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
     const cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
     EtdK E;
     float scratch[kCoefFloats];
-    float(*m)[10][16] = reinterpret_cast<float(*)[10][16]>(coef ? coef : scratch);
+    float(*m)[10][kMatFloats] = reinterpret_cast<float(*)[10][kMatFloats]>(coef ? coef : scratch);
     const M2 Z{};
     const int mic[2] = {micro, micro_coarse};
     for (int set = 0; set < 2; ++set) {

@@ -395,7 +395,11 @@ class PVDERVec(EnvSpecMixin):
         a = (self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
              self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr())
         with torch.cuda.device(self.device):
+            timed = False
             if self._timing:
+                self._timing_k += 1
+                timed = self._timing_k % self._timing_every == 0
+            if timed:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()          # same stream the kernel is launched on (torch's current stream)
@@ -412,7 +416,7 @@ class PVDERVec(EnvSpecMixin):
             else:
                 rc = self._lib.pvder_step_rk45_f64(*a, self.hstep.data_ptr(), self.stats.data_ptr(), zs,
                                                    self.num_envs, self._stream())
-            if self._timing:
+            if timed:
                 ev1.record()
                 self._events.append((ev0, ev1))
             _native.check(rc, "pvder_step")
@@ -452,9 +456,15 @@ class PVDERVec(EnvSpecMixin):
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------
     _timing = False
 
-    def kernel_timing(self, on: bool = True):
-        """Bracket every step-kernel launch with HIP events on the launch stream."""
+    _timing_every = 1
+    _timing_k = 0
+
+    def kernel_timing(self, on: bool = True, every: int = 1):
+        """Bracket every ``every``-th step-kernel launch with HIP events on the launch stream (each
+        event is a packet of its own on the queue: ~1 us of stream time apiece)."""
         self._timing = bool(on)
+        self._timing_every = max(1, int(every))
+        self._timing_k = 0
         self._events = []
 
     def kernel_times_ms(self) -> List[float]:

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Host-side cost of PVDERVec.step() by piece (debug tool, GPU box only)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+import ctypes as C
+import torch
+from gym_PVDER_amd.vec_env import PVDERVec
+
+dev = torch.device("cuda", 0)
+env = PVDERVec(65536, device=dev, seed=1, auto_reset=True)
+env.reset()
+acts = torch.randint(0, 5, (64, 65536), device=dev, dtype=torch.uint8)
+
+
+def t(f, n=200, reps=15):
+    """median over bursts of n un-synchronised calls (short enough for the queue to absorb them)"""
+    for _ in range(50): f()
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n): f()
+        out.append((time.perf_counter() - t0) / n * 1e6)
+    torch.cuda.synchronize()
+    return sorted(out)[len(out) // 2]
+
+cfg = env._cfg()
+print("_cfg()                 %.2f us" % t(env._cfg))
+print("_autoreset()           %.2f us" % t(lambda: env._autoreset(True)))
+print("_etd_coef(cfg)         %.2f us" % t(lambda: env._etd_coef(cfg)))
+print("_stream()              %.2f us" % t(env._stream))
+print("8 x data_ptr()         %.2f us" % t(lambda: [env.fstate.data_ptr() for _ in range(8)]))
+def ctx():
+    with torch.cuda.device(dev):
+        pass
+print("with torch.cuda.device %.2f us" % t(ctx))
+print("acts[i]                %.2f us" % t(lambda: acts[3]))
+a = acts[3]
+# tiny problem: the C call is then host-bound
+env2 = PVDERVec(256, device=dev, seed=1, auto_reset=True); env2.reset()
+cfg2, ar2 = env2._cfg(), env2._autoreset(True)
+a2 = torch.zeros(256, dtype=torch.uint8, device=dev)
+args2 = (env2._par_c, C.byref(cfg2), C.byref(ar2), env2._etd_coef(cfg2).data_ptr(), env2.fstate.data_ptr(), env2.istate.data_ptr(),
+         env2.ev_vg.data_ptr(), env2.ev_si.data_ptr(), a2.data_ptr(), env2.out.data_ptr(), env2.stats.data_ptr(), 2, 256, env2._stream())
+print("C call alone, 256 envs %.2f us" % t(lambda: env2._lib.pvder_step_etdrk4_f32(*args2), 200))
+print("step() 256 envs        %.2f us" % t(lambda: env2.step(a2, return_tensors=False), 200))
+k = [0]
+def big():
+    k[0] = (k[0] + 1) & 63
+    env.step(acts[k[0]], return_tensors=False)
+print("step() 65536 envs (GPU-bound) %.2f us" % t(big, 200))
