@@ -443,6 +443,7 @@ struct EtdK {
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
     int rk4_sub[2];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
+    float i2_to_m2;         // balanced kernel: |iref|^2 * i2_to_m2 > guard  <=>  |iref| within 10 % of its limit
 };
 enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
 
@@ -744,7 +745,7 @@ template <int PH>
 __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
                                           const pvder::SubPk &S, v2 ia, v2 xa, v2 ua, v2 pa, v2 pb, float delta,
                                           float qref, float vdcref, v2 kpo, v2 kio, v2 &ni, v2 &nu,
-                                          v2 *__restrict__ ns) {
+                                          v2 *__restrict__ ns, float &ir2) {
     using namespace pvder;
     // slow pairs: pa = (xDC, xQ) -- the two outer PI integrators, pb = (Vdc, xPLL)
     const float Vdc = pb.x;
@@ -757,12 +758,10 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     // packed outer loops: e = (Vdc_ref - Vdc, Q_ref - Q);  iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
     const v2 e = mk2(vdcref - Vdc, qref - Q);
     const v2 iar = fma2(kpo, e, pa);
-    v2 dpi = kio * e;                                                    // (dxDC, dxQ)
-    const v2 ir2 = iar * iar;
-    if (ir2.x + ir2.y > P.ilim2) {                                      // rare: current-limit anti-windup
-        dpi.x = (dpi.x * pa.x > 0.f) ? 0.f : dpi.x;
-        dpi.y = (dpi.y * pa.y > 0.f) ? 0.f : dpi.y;
-    }
+    const v2 dpi = kio * e;                                              // (dxDC, dxQ)
+    // no current-limit anti-windup here: the caller hands an env whose |iref| comes within 10 % of
+    // the limit over to the 23-state path (ir2 = |iref|^2)
+    ir2 = __builtin_fmaf(iar.y, iar.y, iar.x * iar.x);
     float s1, c1;
     Math<float>::sincos_turns(delta * (float)(1.0 / kTwoPi), s1, c1);
     v2 V1 = fma2(bc2(P.kviR), ia, S.A0); V1 = fma2(mk2(-P.kviI, P.kviI), swp(ia), V1);   // v_a (V2 = 0)
@@ -775,8 +774,10 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     ni = fma2(mk2(dwr, -dwr), swp(ia), n);
     nu = bc2(P.wp) * iar;
     ns[0] = bc2(P.KiG) * ua;
-    const float ppv = ppv_of(P, S.pv1, Vdc);
-    const float dVdc = (ppv - 0.25f * Vdc * Pt) * Math<float>::rcp(Vdc) * P.iC;
+    // dVdc = (Ppv - Re S)/(Vdc C) with Ppv = max(0, Vdc g(Vdc)), Re S = Vdc Pt/4  (Vdc > 0):
+    //      = (max(0, g) - Pt/4)/C            -- no division
+    const float g = __builtin_fmaf(-P.pvB, Math<float>::exp_pv(P.pvK * Vdc), S.pv1);
+    const float dVdc = __builtin_fmaf(-0.25f * P.iC, Pt, P.iC * fmaxf(g, 0.f));
     ns[1] = dpi;
     ns[2] = mk2(dVdc, P.KiP * vd);
     ns[3] = mk2(dw, 0.f);
@@ -862,12 +863,13 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 20);
                 asm volatile("" : "+v"(Mq));
                 v2 n1i, n1u, ni, nu, ns[4], ks[4];
+                float ir2a, ir2x;
                 // software prefetch: issue the LDS reads of the six matrices applied to (z, N1) now,
                 // the model evaluation below hides their latency (one wave per SIMD: nobody else will)
                 const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mP1 = load_mat(Mq, EM_P1);
                 const Mat4 mA1 = load_mat(Mq, EM_A1), mB1 = load_mat(Mq, EM_B1), mC1 = load_mat(Mq, EM_C1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the reads up here (hipcc would sink them to their uses)
-                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, pa, pb, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns);
+                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, pa, pb, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns, ir2a);
                 v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
                 matvec(mE2, ia, ua, e2i, e2u);
                 matvec(mE, ia, ua, ei, eu);
@@ -883,14 +885,14 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                            mC4 = load_mat(Mq, EM_C4);          // prefetched behind evaluations 2-4
                 __builtin_amdgcn_sched_barrier(0);
                 bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], pa),
-                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N2
+                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);   // N2
                 v2 n23i = ni, n23u = nu;
                 ti = u3i; tu = u3u;                                             // U3
                 matvec(mA2, ni, nu, ti, tu);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
                 bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], pa),
-                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);   // N3
+                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);   // N3
                 n23i += ni; n23u += nu;
                 ti = u4i; tu = u4u;                                             // U4
                 matvec(mB3, ni, nu, ti, tu);
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
                 bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], pa),
-                         pvder::fma2(h1, ns[2], pb), dl.x + h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns);         // N4
+                         pvder::fma2(h1, ns[2], pb), dl.x + h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);         // N4
                 matvec(mC4, ni, nu, zi, zu);
                 // Kahan-compensated slow update
                 v2 inc, tsum;
@@ -907,8 +909,8 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 inc = pvder::fma2(h6, ks[2] + ns[2], -cq); tsum = pb + inc; cq = (tsum - pb) - inc; const v2 qn = tsum;
                 inc = pvder::fma2(h6, ks[3] + ns[3], -cd); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
                 const v2 mn = pvder::fma2(pvder::bc2(P.KpG), zu, xn);
-                if (fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)) > guard) {
-                    defer = true;      // near saturation: the full kernel redoes this env step
+                if (fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * Ec.i2_to_m2) > guard) {
+                    defer = true;      // near duty-cycle saturation or the current limit: the 23-state path redoes this env step
                 } else {
                     ia = zi; ua = zu; xa = xn; pa = vn; pb = qn; dl = dn;
                 }
@@ -1255,6 +1257,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
     const double ge = 0.97 * par[PVDER_PAR_M_LIMIT], gs = 0.998 * par[PVDER_PAR_M_LIMIT];
     E.sat2_event = (float)(ge * ge);
     E.sat2_smooth = (float)(gs * gs);
+    E.i2_to_m2 = (float)(ge * ge / (0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]));
     return E;
 }
 
