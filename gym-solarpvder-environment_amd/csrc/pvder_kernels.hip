@@ -462,7 +462,8 @@ struct EtdArgs {
     const uint8_t *action;
     float *out;
     float *stats, *stats_clear;
-    int n_env, run_status;
+    int n_env;
+    int force_full;          // A/B and tests: every env takes the 23-state path
 };
 
 typedef float v4 __attribute__((ext_vector_type(4)));
@@ -567,22 +568,16 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
     return fmaxf(fmaxf(a.x + a.y, b.x + b.y), c.x + c.y);
 }
 
-// The 23-state ETDRK4 path.  ONE compiled copy, out of line ON PURPOSE: step_etdrk4_kernel is just a
-// call of it (tail = 0: the whole launch, A.run_status selects the envs), and the workgroups of
-// step_etdrk4_bal_kernel<3> call it for the lanes they must defer (tail = 1: `defer` flags those
-// lanes, whose state in memory is untouched; every other lane of the workgroup is finished).  Inlined
-// into the balanced kernel it drags that kernel's hot loop to 256 VGPRs + AGPR copies; as a call it
-// costs the fast path one workgroup-wide OR.  The arguments are re-read from the caller's kernarg
-// segment (EtdArgs is the only argument of both kernels; llvm.amdgcn.kernarg.segment.ptr itself is
-// null inside a callee, so the kernel passes the address, made wave-uniform again here so that the
-// reads stay scalar loads).
+// The 23-state ETDRK4 path, the tail of step_etdrk4_bal_kernel<3>: its workgroups run it for the lanes
+// they must defer (`defer`; their state in memory is untouched, every other lane of the workgroup is
+// finished).  It takes a LAUNDERED copy of the kernarg address and re-reads every argument through
+// it, so that nothing of the fast path's register state stays live across the hot loop on its
+// behalf (sharing the arguments cost the hot loop AGPR copies; a real function call costs the kernel
+// a scratch allocation -- AMDGPU callees save callee-saved VGPRs even when they never return -- and
+// with scratch enabled the workgroups start ~2 us later).
 typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
-__device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsigned ka_hi, int tail_i, int defer_i) {
-    const unsigned long long ka = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_hi) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)ka_lo);
-    const EtdArgs &A = *(const EtdArgs *)(KernargPtr)ka;
-    const bool tail = __builtin_amdgcn_readfirstlane(tail_i) != 0, defer = defer_i != 0;
-    const int run_status = tail ? 0 : A.run_status;
+__device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
+    const int run_status = 0;
     const ModelK<float> &P = A.P;
     const StepK<float> &C = A.C;
     const ResetK &R = A.R;
@@ -598,13 +593,6 @@ __device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsig
     const int n_env = A.n_env;
     constexpr int NS = 23, NP = pvder::NP;
     const size_t N = (size_t)n_env;
-    if (!tail && run_status == kDeferred) {
-        // follow-up launch behind a fast-path kernel: leave at once unless this workgroup holds a
-        // deferred env
-        const int e0 = blockIdx.x * kBlock + threadIdx.x;
-        const int mine = (e0 < n_env) && istate[PVDER_I_STATUS * N + e0] == kDeferred;
-        if (!__syncthreads_or(mine)) return;
-    }
     // The 10 coefficient matrices (160 floats) do not fit the scalar register file next to the
     // model constants (they would be spilled to VGPR lanes and read back with v_readlane in the
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
@@ -615,7 +603,7 @@ __device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsig
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(C, fstate, istate, action, n_env, L, ys, run_status);
-    if (tail) L.live = L.run = L.run && defer;     // everyone else in the workgroup is done already
+    L.live = L.run = L.run && defer;               // everyone else in the workgroup is done already
     if (L.run) {
         v2 y[NP], comp[NP];
         to_pairs(ys, y);
@@ -726,11 +714,6 @@ __device__ __attribute__((noinline)) void etdrk4_full_path(unsigned ka_lo, unsig
     epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
 }
 
-__global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(const EtdArgs A) {
-    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    etdrk4_full_path((unsigned)ka, (unsigned)(ka >> 32), 0, 0);
-}
-
 // =============================================================================================
 // ETDRK4, balanced fast path.  PVDER-v0 feeds the 'ThreePhaseUnbalanced' model a balanced grid
 // (unbalance ratios 1.0) from a balanced steady state, and the ODE maps balanced states to balanced
@@ -739,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_kernel(const EtdArgs A) {
 // at entry, integrates phase a + the 5 shared states (11 of 23) with the same ETDRK4 scheme, and
 // writes b and c back by rotation.  An env that is NOT balanced on entry, or whose duty cycle
 // reaches the saturation guard at any step, is left untouched and marked kDeferred: the full
-// kernel (step_etdrk4_kernel, launched right behind with run_status = kDeferred) advances it.
+// 23-state path (etdrk4_full_tail, at the end of this kernel) advances it.
 // =============================================================================================
 template <int PH>
 __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
@@ -752,7 +735,7 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     const v2 ma = fma2(bc2(P.KpG), ua, xa);
     // dot products as mul + fma (written as sums of a packed product hipcc pairs them up through
     // three v_mov); Q = Im S_PCC = PH (Asw/2 + qk i) . i
-    const float Pt = (float)PH * __builtin_fmaf(ma.y, ia.y, ma.x * ia.x);    // PH identical phases
+    const float Pa = __builtin_fmaf(ma.y, ia.y, ma.x * ia.x);                // Re(m conj i) of one of PH identical phases
     const v2 tq = fma2(bc2((float)PH * K.qk), ia, bc2(0.5f * PH) * S.Asw[0]);
     const float Q = __builtin_fmaf(tq.y, ia.y, tq.x * ia.x);
     // packed outer loops: e = (Vdc_ref - Vdc, Q_ref - Q);  iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
@@ -774,10 +757,10 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     ni = fma2(mk2(dwr, -dwr), swp(ia), n);
     nu = bc2(P.wp) * iar;
     ns[0] = bc2(P.KiG) * ua;
-    // dVdc = (Ppv - Re S)/(Vdc C) with Ppv = max(0, Vdc g(Vdc)), Re S = Vdc Pt/4  (Vdc > 0):
-    //      = (max(0, g) - Pt/4)/C            -- no division
+    // dVdc = (Ppv - Re S)/(Vdc C) with Ppv = max(0, Vdc g(Vdc)), Re S = Vdc PH Pa/4  (Vdc > 0):
+    //      = (max(0, g) - PH Pa/4)/C         -- no division
     const float g = __builtin_fmaf(-P.pvB, Math<float>::exp_pv(P.pvK * Vdc), S.pv1);
-    const float dVdc = __builtin_fmaf(-0.25f * P.iC, Pt, P.iC * fmaxf(g, 0.f));
+    const float dVdc = __builtin_fmaf(-0.25f * PH * P.iC, Pa, P.iC * fmaxf(g, 0.f));
     ns[1] = dpi;
     ns[2] = mk2(dVdc, P.KiP * vd);
     ns[3] = mk2(dw, 0.f);
@@ -819,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
-    bool defer = false;
+    bool defer = PH == 3 && A.force_full != 0;       // (A/B and tests: everything through the 23-state tail)
     if (L.run) {
         v2 ia = pvder::mk2(ys[0], ys[1]), xa = pvder::mk2(ys[2], ys[3]), ua = pvder::mk2(ys[4], ys[5]);
         v2 pa = pvder::mk2(ys[B + 1], ys[B + 2]), pb = pvder::mk2(ys[B], ys[B + 3]), dl = pvder::mk2(ys[B + 4], 0.f);   // (xDC,xQ), (Vdc,xPLL)
@@ -828,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             const float ex = unbalance2(xa, pvder::mk2(ys[8], ys[9]), pvder::mk2(ys[14], ys[15]));
             const float eu = unbalance2(ua, pvder::mk2(ys[10], ys[11]), pvder::mk2(ys[16], ys[17]));
             const v2 i2 = ia * ia, x2 = xa * xa;
-            defer = ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
+            defer |= ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
         }
         v2 cx = pvder::bc2(0.f), cv = pvder::bc2(0.f), cq = pvder::bc2(0.f), cd = pvder::bc2(0.f);   // Kahan
         const v2 two = pvder::bc2(2.f);
@@ -847,7 +830,12 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
         if (threadIdx.x == 0 && blockIdx.x < 4096)      // forces the state loads to have landed
             g_trace[blockIdx.x * 32 + 2] = wall_clock64() + (pb.x > 1e30f ? 1 : 0);
 #endif
-        for (int s = 0; s < C.n_sub && !defer; ++s) {
+        // `defer` only accumulates: a deferred lane keeps computing (its results are discarded -- the
+        // 23-state path restarts it from the state in memory), so the loops carry no per-lane exit and
+        // the state update needs no mask; a wave whose lanes are ALL deferred leaves
+        float i2m = Ec.i2_to_m2;
+        asm volatile("" : "+v"(i2m));          // keep it in a VGPR (it would be re-read from the kernarg segment every step)
+        for (int s = 0; s < C.n_sub && !__builtin_amdgcn_readfirstlane(__all((int)defer)); ++s) {
             if (s < 16) PVDER_TRACE_AT(3 + s);
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             const bool input_jump = row != prev_row;
@@ -858,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             const float h = (float)(1.0 / 60.0) / (float)nst;
             const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
-            for (int j = 0; j < nst && !defer; ++j) {
+            for (int j = 0; j < nst; ++j) {
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
                 const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 20);
                 asm volatile("" : "+v"(Mq));
@@ -909,11 +897,9 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 inc = pvder::fma2(h6, ks[2] + ns[2], -cq); tsum = pb + inc; cq = (tsum - pb) - inc; const v2 qn = tsum;
                 inc = pvder::fma2(h6, ks[3] + ns[3], -cd); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
                 const v2 mn = pvder::fma2(pvder::bc2(P.KpG), zu, xn);
-                if (fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * Ec.i2_to_m2) > guard) {
-                    defer = true;      // near duty-cycle saturation or the current limit: the 23-state path redoes this env step
-                } else {
-                    ia = zi; ua = zu; xa = xn; pa = vn; pb = qn; dl = dn;
-                }
+                // near duty-cycle saturation or the current limit: the 23-state path redoes this env step
+                defer |= fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+                ia = zi; ua = zu; xa = xn; pa = vn; pb = qn; dl = dn;
             }
         }
         if (!defer) {
@@ -948,8 +934,9 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
         // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the
         // 23-state path right here -- no second launch
         if (__syncthreads_or((int)defer)) {
-            const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-            etdrk4_full_path((unsigned)ka, (unsigned)(ka >> 32), 1, (int)defer);
+            KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            etdrk4_full_tail(*(const EtdArgs *)ka, defer);
         }
     }
 }
@@ -1360,16 +1347,17 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     A.C = fold_cfg<float>(cfg);
     A.R = R;
     A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, nullptr);
+    A.force_full = 0;
     hipStream_t st = (hipStream_t)stream;
     float *acc, *clr;
     rc = stats_setup(stats, zero_stats, st, acc, clr);
     if (rc) return rc;
     A.coef = coef; A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
-    A.action = action; A.out = out; A.stats = acc; A.stats_clear = clr; A.n_env = n_env; A.run_status = 0;
+    A.action = action; A.out = out; A.stats = acc; A.stats_clear = clr; A.n_env = n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    // Three-phase: ONE launch -- the balanced fast path, whose workgroups call the 23-state path
+    // Three-phase: ONE launch -- the balanced fast path, whose workgroups run the 23-state path
     // themselves for the envs they must defer (unbalanced state or duty cycle near its limit; none in
-    // PVDER-v0 rollouts).  PVDER_ETD_VARIANT=full runs the 23-state kernel alone (A/B).
+    // PVDER-v0 rollouts).  PVDER_ETD_VARIANT=full sends every env down the 23-state path (A/B).
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     const bool full_only = full_env || (cfg->reserved & 1);      // cfg->reserved bit 0: same switch per call
     if (ph == 1) {
@@ -1380,10 +1368,8 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
         C4.micro = 8192;
         hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, A.P, C4, A.R, fstate, istate, ev_vg, ev_si,
                            action, out, acc, n_env, (float *)nullptr, (int)kDeferred);
-    } else if (full_only) {
-        if (clr) (void)hipMemsetAsync(clr, 0, 4 * sizeof(float), st);     // (A/B variant only)
-        hipLaunchKernelGGL(step_etdrk4_kernel, grid, block, 0, st, A);
     } else {
+        A.force_full = full_only ? 1 : 0;
         hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
     }
     return hip_rc(hipGetLastError());
