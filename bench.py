@@ -35,7 +35,10 @@ HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
 BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, three-phase fp32
 # flop per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
-FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 740}     # etdrk4: balanced fast-path kernel (full 23-state kernel: 2245)
+FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 731}     # etdrk4: balanced fast path (23-state tail: ~2200)
+# instructions per integrator step of the same loops (one wave per SIMD at 65 536 envs: the loop is
+# bound by the single-wave issue rate, tools/issue_probe.hip: 2.25-2.5 ns per independent instruction)
+INSTR_PER_STEP = {"etdrk4": 326}
 DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
 KERNEL_NAME = {"etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
 
@@ -104,7 +107,7 @@ def classic_rk4_leg(dev, N, n_sub, steps):
     gen.manual_seed(99)
     acts = torch.randint(0, 5, (steps + 1, N), generator=gen, device=dev, dtype=torch.uint8)
     env.step(acts[0], return_tensors=False)
-    env.kernel_timing(args.time_every > 0, max(1, args.time_every))
+    env.kernel_timing(True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(1, steps + 1):
@@ -270,7 +273,10 @@ def main():
             "valu_roofline": {"bound": "valu_f32", "achieved": flops / 1e12, "peak": VALU_PEAK_F32 / 1e12,
                               "unit": "TFLOP/s", "frac": flops / VALU_PEAK_F32,
                               "flop_per_integrator_step": fps,
-                              "integrator_steps_per_env_step": steps_per_env_step} if fps else None,
+                              "integrator_steps_per_env_step": steps_per_env_step,
+                              "instr_per_integrator_step": INSTR_PER_STEP.get(args.integrator),
+                              "ns_per_instr_per_wave": (avg_kern_s * 1e9 / (steps_per_env_step * INSTR_PER_STEP[args.integrator])
+                                                        if args.integrator in INSTR_PER_STEP else None)} if fps else None,
             "last_step_stats": st,
         }
         if world == 1 and args.classic_steps > 0 and args.integrator == "etdrk4":
