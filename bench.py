@@ -253,7 +253,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.integrator == "rk45" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
+            "config": {"workload": ("BASELINE configs[2]" if (N, args.n_sub) == (65536, 15) else "variant of BASELINE configs[2]") +
+                                   ": %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
                                    % (N, args.n_sub, {"etdrk4": "fp32 ETDRK4 (exponential RK4), %d steps per 1/60 s after an input jump, %d otherwise"
                                                                 % (args.micro, env.micro_coarse or args.micro),
