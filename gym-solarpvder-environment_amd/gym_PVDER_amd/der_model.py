@@ -133,3 +133,34 @@ def steady_state(par: np.ndarray, der_id: str = "50", vgrid: float = 1.0, q_ref:
         y0 += [ip.real, ip.imag, mp.real, mp.imag, 0.0, 0.0]
     y0 += [vdc, ia.real, ia.imag, 0.0, WTE0]
     return np.asarray(y0, dtype=np.float64)
+
+
+def physical_outputs(par: np.ndarray, y: np.ndarray, vgrid: np.ndarray, q_ref: np.ndarray,
+                     vdc_ref: np.ndarray) -> dict:
+    """Host-side (numpy, fp64) algebraic outputs of state rows ``y`` ([NS, ...], kernels' state
+    order) in PHYSICAL units -- the quantities ``PVDER.render`` prints (PVDER_env.py:339-349) and the
+    reference's ``SimulationResults`` plots (:359-364): duty cycle ma, currents, LV-side voltages,
+    inverter / PCC powers, DC-link voltage, PV power.  Display only: nothing on the step path uses it."""
+    ph = int(par[IDX["PHASES"]])
+    kvg = complex(par[IDX["KVG_RE"]], par[IDX["KVG_IM"]])
+    kvi = complex(par[IDX["KVI_RE"]], par[IDX["KVI_IM"]])
+    y = np.asarray(y, dtype=np.float64)
+    B = 6 * ph
+    rot = [1.0, cmath.exp(-2j * math.pi / 3.0), cmath.exp(2j * math.pi / 3.0)][:ph]
+    vdc = y[B]
+    out = {"Vdc": vdc * VDCBASE, "Q_ref": np.asarray(q_ref) * SBASE, "Vdc_ref": np.asarray(vdc_ref) * VDCBASE}
+    s_inv = 0.0
+    s_pcc = 0.0
+    for p, name in enumerate("abc"[:ph]):
+        i_p = y[6 * p] + 1j * y[6 * p + 1]
+        x_p = y[6 * p + 2] + 1j * y[6 * p + 3]
+        u_p = y[6 * p + 4] + 1j * y[6 * p + 5]
+        m_p = par[IDX["KP_GCC"]] * u_p + x_p
+        vt_p = m_p * vdc / 2.0
+        v_p = kvg * (np.asarray(vgrid) * par[IDX["VG_SCALE"]] * rot[p]) + kvi * i_p
+        s_inv = s_inv + 0.5 * vt_p * np.conj(i_p)
+        s_pcc = s_pcc + 0.5 * v_p * np.conj(i_p)
+        out["m" + name], out["i" + name] = m_p, i_p * IBASE
+        out["vt" + name], out["v" + name] = vt_p * VBASE, v_p * VBASE
+    out["S_inverter"], out["S_PCC"] = s_inv * SBASE, s_pcc * SBASE
+    return out

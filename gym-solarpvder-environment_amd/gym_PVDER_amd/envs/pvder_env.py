@@ -108,7 +108,7 @@ class PVDER(EnvSpecMixin):
 
     def __init__(self, goals_list=('voltage_regulation',), n_sim_time_steps_per_env_step=15,
                  max_sim_time=40.0, DISCRETE_REWARD=True, verbosity='INFO', device="cuda",
-                 integrator=None, micro_steps=None, seed=0, model_type='model_2'):
+                 integrator=None, micro_steps=None, seed=0, model_type='model_2', record_trajectory=True):
         PVDER.count += 1                                             # :117
         self.name = 'GymDER_' + str(PVDER.count)
         self.verbosity = verbosity
@@ -119,6 +119,8 @@ class PVDER(EnvSpecMixin):
                              integrator=integrator, auto_reset=False, seed=seed, model_type=model_type,
                              env_id_base=PVDER.count - 1, **kw)
         self.max_sim_time_user = max_sim_time
+        if record_trajectory:      # the reference always keeps the solution rows (self.results, :389)
+            self._vec.record_trajectory(self._vec.max_episode_steps + 1)
         self.env_events_spec = self._vec.env_events_spec
         self._reward = 0
         self.done = False
@@ -180,18 +182,63 @@ class PVDER(EnvSpecMixin):
         self._time_stats['step_time'].append(self._step_time)
         return np.array(self.state), self._reward, self.done, {}
 
-    def render(self, mode='vector'):                                 # :336-364
-        pv, sim = self.sim.PV_model, self.sim
-        obs = {'ia': pv.ia * sim.Ibase, 'Vdc': pv.Vdc * pv.Vdcbase, 'va': pv.va * sim.Vbase,
-               'Ppv': pv.Ppv * sim.Sbase, 'S_PCC': pv.S_PCC * sim.Sbase, 'Q_ref': pv.Q_ref * sim.Sbase,
-               'Vdc_ref': pv.Vdc_ref * pv.Vdcbase, 'tStart': sim.tStart}
-        line = " ".join('{}:{:.2f},'.format(k, v) for k, v in obs.items())
+    def _physical(self):
+        """Current algebraic outputs in physical units (host, fp64) for render()."""
+        v = self._vec
+        if v._traj is not None and v._traj_n > 0:
+            t = v.trajectory(0)
+            return {k: val[-1] for k, val in t.items()}
+        y = v.fstate[:, 0].to(torch.float64).cpu().numpy()
+        ksub = int(v.istate[0, 0])
+        row = 0 if (v.ev_count == 0 or ksub < v.ev_s0) else min((ksub - v.ev_s0) // max(v.ev_ds, 1) + 1, v.ev_count)
+        d = der_model.physical_outputs(v.par, y[:v.ns], np.float64(float(v.ev_vg[row, 0])), y[v.ns], y[v.ns + 1])
+        d["Ppv"] = float(v.out[7, 0]) * der_model.SBASE
+        return d
+
+    def render(self, mode='vector', show=False):                     # :336-364
+        """``'vector'``: print the reference's observation line in physical units (:339-353);
+        ``'human'``: additionally draw the six figures of the reference's SimulationResults calls
+        (:358-364: active power, reactive power, DC-link voltage, duty cycle, LV voltages, currents)
+        from the recorded trajectory (env-step resolution) and return them as matplotlib figures."""
+        if mode not in self.metadata['render.modes']:
+            raise ValueError("render mode %r not in %r" % (mode, self.metadata['render.modes']))
+        sim = self.sim
+        p = self._physical()
+        obs = {'ma': p['ma'], 'ia': p['ia'], 'Vdc': p['Vdc'], 'vta': p['vta'], 'va': p['va'], 'Ppv': p['Ppv'],
+               'S_inverter': p['S_inverter'], 'S_PCC': p['S_PCC'], 'Q_ref': p['Q_ref'], 'Vdc_ref': p['Vdc_ref'],
+               'tStart': sim.tStart}
+        line = " ".join('{}:{:.2f},'.format(k, complex(v) if np.iscomplexobj(v) else float(v)) for k, v in obs.items())
         print(line)
         print('Reward:{:.5f}'.format(self._reward))
         print('Time for step:{:.3f}'.format(self._step_time))        # env_utilities.py:54-57
-        # mode == 'human' plots trajectories in the reference (:358-364); plotting is host-side
-        # cosmetics outside the hot path -- the vector line is printed
-        return line
+        if mode != 'human':
+            return line
+        if self._vec._traj is None:
+            raise RuntimeError("render('human') needs the recorded trajectory: PVDER(record_trajectory=True)")
+        import matplotlib
+        if not show:
+            matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        t = self._vec.trajectory(0)
+        ph = "abc"[:self._vec.phases]
+        plots = [
+            ('active_power_Ppv_Pac_PCC', 'Active power [W]', [('Ppv', t['Ppv']), ('Pac_PCC', t['S_PCC'].real)]),
+            ('reactive_power_Q_PCC', 'Reactive power [VAR]', [('Q_PCC', t['S_PCC'].imag), ('Q_ref', t['Q_ref'])]),
+            ('voltage_Vdc', 'DC link voltage [V]', [('Vdc', t['Vdc']), ('Vdc_ref', t['Vdc_ref'])]),
+            ('duty_cycle', 'Duty cycle |m|', [('m' + q, np.abs(t['m' + q])) for q in ph]),
+            ('voltage_LV', 'LV voltage |v| [V]', [('v' + q, np.abs(t['v' + q])) for q in ph]),
+            ('current', 'Current |i| [A]', [('i' + q, np.abs(t['i' + q])) for q in ph]),
+        ]
+        figs = []
+        for name, ylabel, series in plots:
+            fig, ax = plt.subplots(figsize=(6, 3))
+            for label, y in series:
+                ax.plot(t['t'], y, label=label)
+            ax.set_xlabel('Time [s]'); ax.set_ylabel(ylabel); ax.set_title(name); ax.legend(); ax.grid(True)
+            figs.append(fig)
+        if show:
+            plt.show()
+        return figs
 
     def update_env_events(self, event_spec_list):                    # :413-438
         self._vec.update_env_events(event_spec_list)

@@ -375,6 +375,10 @@ class PVDERVec(EnvSpecMixin):
                 else:
                     self.hstep.masked_fill_(mask.bool(), 0.0)
         self._needs_reset = False
+        if self._traj is not None:
+            if mask is None:
+                self._traj_n = 0           # a full reset starts a new recording (the sim object is rebuilt, :323-331)
+            self._traj_append()
         return self.obs
 
     def step(self, actions: torch.Tensor, return_tensors: bool = True):
@@ -420,6 +424,8 @@ class PVDERVec(EnvSpecMixin):
                 ev1.record()
                 self._events.append((ev0, ev1))
             _native.check(rc, "pvder_step")
+            if self._traj is not None:
+                self._traj_append()
             if not return_tensors:
                 return None
             return self.obs, self.out[11], self.out[12] != 0, {}
@@ -471,6 +477,59 @@ class PVDERVec(EnvSpecMixin):
         """Durations of the step-kernel launches recorded since kernel_timing(True) (host sync)."""
         torch.cuda.synchronize(self.device)
         return [a.elapsed_time(b) for a, b in getattr(self, "_events", [])]
+
+    # -- trajectory capture (the reference keeps every solution row in `self.results`, PVDER_env.py:389,
+    #    and plots it in render('human'), :358-364; here: an optional device ring buffer at env-step
+    #    resolution, filled by device-to-device copies behind each launch, read back only on demand) ----
+    _traj = None
+    _traj_n = 0
+
+    def record_trajectory(self, capacity: int, env_ids=None):
+        """Keep the last ``capacity`` snapshots (reset + env steps) of the listed envs (default: all)
+        on the device: states, refs, output block, time index and active grid-voltage magnitude.
+        ``capacity = 0`` turns recording off.  Not on by default: it adds three small launches per step."""
+        if capacity <= 0:
+            self._traj = None
+            return
+        ids = torch.arange(self.num_envs, device=self.device) if env_ids is None else \
+            torch.as_tensor(env_ids, dtype=torch.long, device=self.device)
+        self._traj_ids = ids
+        self._traj_rows = self.ns + 2 + 13 + 2
+        self._traj = torch.zeros((int(capacity), self._traj_rows, ids.numel()), dtype=self.fdtype, device=self.device)
+        self._traj_n = 0
+
+    def _traj_append(self):
+        ids = self._traj_ids
+        ksub = self.istate[0].index_select(0, ids)
+        # active event row at t = ksub/60 (same integer arithmetic as the kernels' event_row)
+        row = torch.where(ksub < self.ev_s0, torch.zeros_like(ksub),
+                          torch.clamp((ksub - self.ev_s0) // max(self.ev_ds, 1) + 1, max=self.ev_count)) \
+            if self.ev_count > 0 else torch.zeros_like(ksub)
+        vg = self.ev_vg.index_select(1, ids).gather(0, row[None].long())[0]
+        slot = self._traj[self._traj_n % self._traj.shape[0]]
+        slot[: self.ns + 2] = self.fstate.index_select(1, ids)
+        slot[self.ns + 2: self.ns + 15] = self.out.index_select(1, ids)
+        slot[self.ns + 15] = ksub.to(self.fdtype)
+        slot[self.ns + 16] = vg.to(self.fdtype)
+        self._traj_n += 1
+
+    def trajectory(self, env: int = 0) -> Dict[str, np.ndarray]:
+        """Recorded time series of recorded env number ``env`` in PHYSICAL units (host sync): ``t`` [s],
+        the fields of ``der_model.physical_outputs`` (m*, i*, v*, vt*, S_inverter, S_PCC, Vdc, Q_ref,
+        Vdc_ref), ``Ppv`` [W], ``vgrid`` [pu], ``reward``, ``done``.  Oldest snapshot first."""
+        if self._traj is None:
+            raise RuntimeError("record_trajectory(capacity) was not called")
+        cap = self._traj.shape[0]
+        n = min(self._traj_n, cap)
+        order = [(self._traj_n - n + k) % cap for k in range(n)]
+        a = self._traj[order, :, env].to(torch.float64).cpu().numpy().T          # [rows, n]
+        ns = self.ns
+        d = der_model.physical_outputs(self.par, a[:ns], a[ns + 16], a[ns], a[ns + 1])
+        d["t"] = a[ns + 15] * SIM_TIME_STEP
+        d["vgrid"] = a[ns + 16]                     # grid-voltage event magnitude in force [pu]
+        d["Ppv"] = a[ns + 2 + 7] * der_model.SBASE
+        d["reward"], d["done"] = a[ns + 2 + 11], a[ns + 2 + 12] != 0
+        return d
 
     def close(self):
         pass
