@@ -369,6 +369,8 @@ class PVDERVec(EnvSpecMixin):
                 mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
                 assert mask.shape == (self.num_envs,)
             self._reset_launch(mask)
+            if self.integrator == "etdrk4":
+                self._etd_coef(self._cfg())          # upload now: step() must stay capturable into a HIP graph
             if self.hstep is not None:
                 if mask is None:
                     self.hstep.zero_()

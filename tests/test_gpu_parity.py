@@ -298,3 +298,37 @@ def test_full_episode_drift_vs_converged_bridge(gpu_device):
     last = rel_l2(got[-20:].transpose(1, 0, 2).reshape(N, -1), want[-20:].transpose(1, 0, 2).reshape(N, -1), axis=1)
     assert last.max() < FP32_TOL, "last 5 s rel-L2 %.3e (drift)" % last.max()
     assert rmis <= 0.01 * N * steps                      # discrete reward: only threshold ties may differ
+
+
+def test_step_is_graph_capturable(gpu_device):
+    """The C entry points are asynchronous, allocation-free and never synchronise, so a step can be
+    captured into a HIP graph (torch.cuda.CUDAGraph) and replayed: bit-identical to eager launches."""
+    N, steps = 1024, 6
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(9)
+    acts = torch.randint(0, 5, (steps, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    eager = make_vec(N, gpu_device, seed=12, events_spec=both_events_spec(), auto_reset=True)
+    eager.reset()
+    want = []
+    for t in range(steps):
+        eager.step(acts[t], return_tensors=False)
+        want.append(eager.out.clone())
+    env = make_vec(N, gpu_device, seed=12, events_spec=both_events_spec(), auto_reset=True)
+    env.reset()
+    a0, a1 = acts[0].clone(), acts[1].clone()          # static inputs of the captured launches
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    state = env.state_dict()
+    with torch.cuda.graph(g):                          # two steps per graph: the statistics banks ping-pong
+        env.step(a0, return_tensors=False)
+        o0 = env.out.clone()
+        env.step(a1, return_tensors=False)
+        o1 = env.out.clone()
+    env.load_state_dict(state)                         # capture does not execute; start from the same state anyway
+    got = []
+    for t in range(0, steps, 2):
+        a0.copy_(acts[t]); a1.copy_(acts[t + 1])
+        g.replay()
+        got += [o0.clone(), o1.clone()]
+    torch.cuda.synchronize()
+    for t in range(steps):
+        assert torch.equal(got[t], want[t]), t
