@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--time-every", type=int, default=16,
                     help="bracket every K-th step kernel with HIP events (roofline.kernel_avg_ms); 0 = none")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: all-gather issued directly into RCCL (default) or through torch.distributed")
     ap.add_argument("--sync-gather", type=int, default=0,
                     help="1: wait for each step's all-gather before the next step (no compute/comm overlap)")
     return ap.parse_args()
@@ -181,18 +183,51 @@ def main():
     total = args.warmup + args.steps
     actions = torch.randint(0, 5, (total, N), generator=gen, device=dev, dtype=torch.uint8)
     # ONE collective per step (RCCL over xGMI): all-gather of the [13, N_local] output block.  It is
-    # double-buffered and asynchronous: the gather of step t runs on RCCL's stream while the step
+    # double-buffered and asynchronous: the gather of step t runs on its own stream while the step
     # kernel of t+1 computes (the rollout does not consume the collated block before the next
     # launch); every gather has completed inside the timed region (waited for before the final sync).
+    #   --collective rccl  (default): the env alternates between two output blocks and the gather is
+    #       issued straight into RCCL (gym_PVDER_amd.distributed.RcclAllGather) -- no staging copy, no
+    #       c10d bookkeeping on the host;
+    #   --collective torch: torch.distributed.all_gather_into_tensor(async_op=True) on a staged copy
+    #       (also the fallback if the direct communicator cannot be set up).
+    collective = "none"
+    direct = None
     if dist is not None:
-        stage = [torch.empty_like(env.out) for _ in range(2)]
         gathered = [torch.empty((world * 13, N), dtype=env.out.dtype, device=dev) for _ in range(2)]
         pending = [None, None]
+        collective = "torch.distributed.all_gather_into_tensor (RCCL), async, staged copy"
+        if args.collective == "rccl":
+            try:
+                from gym_PVDER_amd.distributed import RcclAllGather
+                direct = RcclAllGather(dev)
+                outs = [env.out, torch.empty_like(env.out)]
+                done_ev = [torch.cuda.Event(), torch.cuda.Event()]
+                collective = "ncclAllGather (RCCL) issued directly on a side stream, two output blocks"
+            except Exception as exc:          # keep the run: fall back to the c10d path on every rank
+                direct = None
+                print("bench.py: direct RCCL all-gather unavailable (%r), using torch.distributed" % (exc,), file=sys.stderr)
+            ok = torch.tensor([1 if direct is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks take the same path
+            if int(ok.item()) == 0:
+                direct = None
+                collective = "torch.distributed.all_gather_into_tensor (RCCL), async, staged copy"
+        if direct is None:
+            stage = [torch.empty_like(env.out) for _ in range(2)]
 
     def one_step(i):
+        b = i & 1
+        if direct is not None:
+            if pending[b] is not None:
+                torch.cuda.current_stream(dev).wait_event(pending[b])    # gather t-2 has read this block
+            env.use_out(outs[b])
+            env.step(actions[i], return_tensors=False)                   # results land in outs[b] ([13, N])
+            pending[b] = direct.launch(outs[b], gathered[b], done_ev[b])
+            if args.sync_gather:
+                torch.cuda.current_stream(dev).wait_event(pending[b])
+            return
         env.step(actions[i], return_tensors=False)      # results land in env.out ([13, N])
         if dist is not None:
-            b = i & 1
             if pending[b] is not None:
                 pending[b].wait()                        # stream dependency only, no host block
             stage[b].copy_(env.out)                      # 3.4 MB device copy: frees env.out for step t+1
@@ -204,7 +239,10 @@ def main():
         if dist is not None:
             for b in (0, 1):
                 if pending[b] is not None:
-                    pending[b].wait()
+                    if direct is not None:
+                        torch.cuda.current_stream(dev).wait_event(pending[b])
+                    else:
+                        pending[b].wait()
                     pending[b] = None
 
     for i in range(args.warmup):
@@ -263,8 +301,8 @@ def main():
                        "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro,
                        "micro_coarse": env.micro_coarse,
                        "integrator": args.integrator,
-                       "collective": ("all_gather_into_tensor [13, N_local] per step, %s"
-                                      % ("synchronous" if args.sync_gather else "overlapped with the next step"))
+                       "collective": ("all-gather of the [13, N_local] fp32 block per step: %s; %s"
+                                      % (collective, "synchronous" if args.sync_gather else "overlapped with the next step"))
                        if dist is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(KERNEL_NAME[args.integrator], N),

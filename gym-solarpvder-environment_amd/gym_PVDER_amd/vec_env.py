@@ -240,6 +240,17 @@ class PVDERVec(EnvSpecMixin):
     def Vdc_ref(self) -> torch.Tensor:
         return self.fstate[self.ns + 1]
 
+    def use_out(self, buf: torch.Tensor):
+        """Point the env at another [13, N] output block (same dtype/device): the next launches write
+        their observation / reward / done rows there.  For callers that hand the block of step t to a
+        consumer (e.g. an all-gather in flight) while step t+1 computes.  Rows of envs that do not run
+        (finished, auto_reset off) are not rewritten, so alternate blocks only with auto_reset on."""
+        if buf.shape != self.out.shape or buf.dtype != self.out.dtype or buf.device != self.out.device \
+                or not buf.is_contiguous():
+            raise ValueError("use_out: need a contiguous %s tensor of shape %s on %s"
+                             % (self.out.dtype, tuple(self.out.shape), self.out.device))
+        self.out = buf
+
     # -- events ---------------------------------------------------------------------------------
     def _event_grid(self):
         v = self.env_events_spec['voltage']       # grid always from the 'voltage' entry (:408-410)

@@ -332,3 +332,44 @@ def test_step_is_graph_capturable(gpu_device):
     torch.cuda.synchronize()
     for t in range(steps):
         assert torch.equal(got[t], want[t]), t
+
+
+def test_direct_rccl_all_gather_world1(gpu_device):
+    """RcclAllGather (ctypes on torch's librccl.so, own communicator and stream) at world size 1:
+    the plumbing bench.py uses for N > 1 -- unique id through the process group, communicator,
+    launch ordered behind the producer, completion event -- must reproduce the block."""
+    import os
+    import torch.distributed as dist
+    from gym_PVDER_amd.distributed import RcclAllGather
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        env = make_vec(4096, gpu_device, seed=3, auto_reset=True)
+        env.reset()
+        g = RcclAllGather(gpu_device)
+        outs = [env.out, torch.empty_like(env.out)]
+        recv = [torch.zeros((13, 4096), device=gpu_device) for _ in range(2)]
+        done = [None, None]
+        want = []
+        gen = torch.Generator(device=gpu_device); gen.manual_seed(5)
+        for t in range(6):
+            b = t & 1
+            if done[b] is not None:
+                torch.cuda.current_stream().wait_event(done[b])
+            env.use_out(outs[b])
+            env.step(torch.randint(0, 5, (4096,), generator=gen, device=gpu_device, dtype=torch.uint8), return_tensors=False)
+            done[b] = g.launch(outs[b], recv[b])
+            done[b].synchronize()
+            assert torch.equal(recv[b], outs[b]), t
+            want.append(outs[b].clone())
+        assert not torch.equal(want[-1], want[-2])
+        with pytest.raises(ValueError):
+            env.use_out(torch.empty((13, 8), device=gpu_device))
+        g.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
