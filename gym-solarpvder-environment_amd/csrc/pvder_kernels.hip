@@ -8,8 +8,9 @@
 // reward-sum / done-count statistics (env_utilities.py:32-38 aggregate).
 //
 // Integrators (fixed per launch, selected by the entry point):
-//   step_etdrk4_kernel   fp32  exponential-time-differencing RK4 (Krogstad): the stiff current
-//                              loop (i_p,u_p) is propagated exactly, everything else is classic RK4
+//   step_etdrk4_bal_kernel<PH> fp32 exponential-time-differencing RK4 (Krogstad): the stiff current
+//                              loop (i_p,u_p) is propagated exactly, everything else is classic RK4;
+//                              balanced 11-state fast path + 23-state tail (etdrk4_full_tail) in ONE launch
 //   step_rk4_pk_kernel   fp32  classic RK4 micro-stepping, packed-VALU three-phase form
 //   step_rk4_kernel<T,PH>      classic RK4 micro-stepping, generic (single phase / A-B reference)
 //   step_rk45_kernel<T,PH> fp64 adaptive Dormand-Prince 5(4)
@@ -43,7 +44,7 @@ using pvder::SubK;
 using pvder::v2;
 
 constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
-constexpr int kDeferred = -1; // transient istate status: "advance me in the follow-up launch"
+constexpr int kDeferred = -1; // transient istate status (single-phase ETDRK4 only): "advance me in the follow-up launch"
 
 template <typename T>
 struct StepK {
@@ -447,9 +448,9 @@ struct EtdK {
 };
 enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
 
-// The ONE by-value argument of the two ETDRK4 kernels (kernarg offset 0).  A single struct so that
-// the out-of-line 23-state path (etdrk4_full_path, a real function call) can read the same arguments straight from the kernarg segment instead of having ~130
-// scalars passed to it.
+// The ONE by-value argument of the ETDRK4 kernel (kernarg offset 0).  A single struct so that the
+// 23-state tail (etdrk4_full_tail) can re-read every argument through a laundered copy of the kernarg
+// pointer instead of keeping ~130 scalars of the fast path alive across the hot loop.
 struct EtdArgs {
     ModelK<float> P;
     StepK<float> C;
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             const bool input_jump = row != prev_row;
             prev_row = row;
-            // two-rate schedule, wave-uniform (see step_etdrk4_kernel)
+            // two-rate schedule, wave-uniform (see etdrk4_full_tail)
             const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
             const int nst = fine ? C.micro : C.micro2;
             const float h = (float)(1.0 / 60.0) / (float)nst;
@@ -1233,7 +1234,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
         pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), m[set][EM_C2]);
         pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), m[set][EM_C4]);
         // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
-        E.rk4_sub[set] = (4096 + mic[set] - 1) / mic[set];      // (three-phase full kernel only)
+        E.rk4_sub[set] = (4096 + mic[set] - 1) / mic[set];      // (23-state tail only)
         if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;
     }
     E.c0kp = (float)(c0 * kp);

@@ -176,13 +176,13 @@ def test_duty_cycle_saturation_anti_windup(gpu_device):
     assert np.abs(m.Kp_GCC * (st[:, 4] + 1j * st[:, 5]) + st[:, 2] + 1j * st[:, 3]).max() > m.m_limit
 
 
-def test_mixed_batch_deferral_to_full_kernel(gpu_device):
+def test_mixed_batch_deferral_to_23_state_path(gpu_device):
     """Half of the envs start unbalanced / near saturation: the balanced fast path must hand exactly
-    those to the full kernel, the others keep the fast path; both halves must match a run of the
-    full 23-state kernel alone, and the wave-reduced statistics must cover every env once."""
+    those to the 23-state path, the others keep the fast path; both halves must match a run that
+    sends every env down the 23-state path, and the wave-reduced statistics must cover every env once."""
     N, n_sub, steps = 512, 4, 4
     runs = {}
-    for knob in (0, 1):                       # 0: balanced kernel + follow-up, 1: full kernel only
+    for knob in (0, 1):                       # 0: fast path + 23-state tail for deferred envs, 1: every env through the tail
         env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator="etdrk4", seed=41,
                        auto_reset=True, max_sim_time=1.0)
         env._debug_knob = knob
@@ -207,7 +207,7 @@ def test_mixed_batch_deferral_to_full_kernel(gpu_device):
     # step 1: the perturbed envs were deferred and ran the very same kernel in both runs: bit-identical
     assert np.array_equal(fast[0, 1::2], full[0, 1::2])
     # afterwards the current controller has re-balanced the merely unbalanced ones (they return to
-    # the fast path); everything stays within the same-scheme tolerance of the full kernel,
+    # the fast path); everything stays within the same-scheme tolerance of the 23-state path,
     # the saturated ones (chattering regime, see test_duty_cycle_saturation_anti_windup) loosely
     sat = np.zeros(N, dtype=bool); sat[3::4] = True
     assert rel_l2(fast[:, ~sat].reshape(-1, 11), full[:, ~sat].reshape(-1, 11)) < 1e-5

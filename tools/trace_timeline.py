@@ -71,6 +71,11 @@ def main():
         print("slot %2d %-18s min %6.2f  med %6.2f  p90 %6.2f  max %6.2f us" % (
             s, names.get(s, "sub-step %d" % (s - 3)), np.median(x.min(1)), np.median(np.median(x, 1)),
             np.median(np.percentile(x, 90, axis=1)), np.median(x.max(1))))
+    if os.environ.get("PVDER_TRACE_DUMP"):
+        x = R[-1, :, 0]
+        print("entry time by workgroup of the last launch (us), 16 per line:")
+        for b in range(0, nblk, 16):
+            print("  %4d: " % b + " ".join("%5.2f" % v for v in x[b:b + 16]))
     # per-block durations
     d = R[:, :, 21] - R[:, :, 0]
     print("per-block entry->end: med %.2f  max %.2f us;   entry spread (max slot0) %.2f us" % (
