@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""Accuracy and speed of ETDRK4 step schedules (debug tool, GPU box only).
+
+For every schedule (micro / micro_coarse): max rel-L2 of the observation
+trajectory against (a) the committed goldens (converged fp64 RK45), (b) the fp64 C bridge RK45 on 64
+envs x random actions x both event types (n = 15, 6 steps and n = 4, 20 steps), (c) a full 160-step
+episode with 38 events (8 envs); and the env-steps/s of the default bench workload.
+"""
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+import torch  # noqa: E402
+from gym_PVDER_amd.vec_env import PVDERVec, default_events_spec  # noqa: E402
+from helpers import both_events_spec, rel_l2  # noqa: E402
+from oracle.bridge_env import BridgeVecEnv  # noqa: E402
+
+dev = torch.device("cuda", 0)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_err(kw):
+    worst = 0.0
+    for f in sorted(glob.glob(os.path.join(GOLD, "traj_*.npz"))):
+        g = np.load(f)
+        n, goal, discrete = int(g["n"]), str(g["goal"]), bool(g["discrete"])
+        env = PVDERVec(8, device=dev, n_sim_time_steps_per_env_step=n, goals_list=[goal], DISCRETE_REWARD=discrete,
+                       auto_reset=False, **kw)
+        env.reset()
+        K = env.ev_count
+        vg = np.ones((K + 1, 8)); si = np.full((K + 1, 8), 100.0)
+        vg[:] = g["vgrid"][:, None]; si[:] = g["sinsol"][:, None]
+        env.set_event_tables(torch.as_tensor(vg, dtype=torch.float32, device=dev), torch.as_tensor(si, dtype=torch.float32, device=dev))
+        obs = [env.obs.cpu().numpy().astype(np.float64)[0]]
+        for a in g["actions"]:
+            o, _, _, _ = env.step(torch.full((8,), int(a), dtype=torch.uint8, device=dev))
+            obs.append(o.cpu().numpy().astype(np.float64)[0])
+        worst = max(worst, float(rel_l2(np.array(obs), g["obs"])))
+    return worst
+
+
+_bridge_cache = {}
+
+
+def bridge_err(kw, n_sub, steps, N=64):
+    rng = np.random.default_rng(17)
+    actions = rng.integers(0, 5, size=(steps, N))
+    spec = both_events_spec()
+    spec["voltage"]["t_events_start"] = spec["insolation"]["t_events_start"] = 0.2
+    spec["voltage"]["t_events_step"] = 0.2
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=23, events_spec=spec, auto_reset=False, **kw)
+    env.reset()
+    key = (n_sub, steps)
+    if key not in _bridge_cache:
+        vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
+        ref = BridgeVecEnv(N, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11)
+        ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+        _bridge_cache[key] = np.stack([ref.step(actions[t])[0] for t in range(steps)])
+    want = _bridge_cache[key]
+    got = np.stack([env.step(torch.as_tensor(actions[t], device=dev))[0].cpu().numpy().astype(np.float64) for t in range(steps)])
+    return float(rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1).max())
+
+
+def episode_err(kw, N=8, steps=160):
+    rng = np.random.default_rng(2718)
+    actions = rng.integers(0, 5, size=(steps, N))
+    env = PVDERVec(N, device=dev, seed=1234, events_spec=both_events_spec(), auto_reset=False, **kw)
+    env.reset()
+    if "ep" not in _bridge_cache:
+        vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
+        ref = BridgeVecEnv(N, n=15, method="rk45", rtol=1e-8, atol=1e-11)
+        ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+        _bridge_cache["ep"] = np.stack([ref.step(actions[t])[0] for t in range(steps)])
+    want = _bridge_cache["ep"]
+    got = np.stack([env.step(torch.as_tensor(actions[t], device=dev))[0].cpu().numpy().astype(np.float64) for t in range(steps)])
+    e_all = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1).max()
+    e_tail = rel_l2(got[-20:].transpose(1, 0, 2).reshape(N, -1), want[-20:].transpose(1, 0, 2).reshape(N, -1), axis=1).max()
+    return float(e_all), float(e_tail)
+
+
+def speed(kw, N=65536, steps=2000):
+    spec = default_events_spec(); spec["insolation"]["ENABLE"] = True
+    env = PVDERVec(N, device=dev, events_spec=spec, seed=2024, auto_reset=True, **kw)
+    env.reset()
+    gen = torch.Generator(device=dev); gen.manual_seed(1234)
+    acts = torch.randint(0, 5, (steps + 200, N), generator=gen, device=dev, dtype=torch.uint8)
+    for i in range(200):
+        env.step(acts[i], return_tensors=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(200, steps + 200):
+        env.step(acts[i], return_tensors=False)
+    torch.cuda.synchronize()
+    return N * steps / (time.perf_counter() - t0)
+
+
+SCHEDULES = [(8, 2), (8, 1), (8, 4), (6, 2), (4, 2), (8, 0)]
+if len(sys.argv) > 1:
+    SCHEDULES = [tuple(int(x) for x in a.split("/")) for a in sys.argv[1:]]
+print("%-14s %10s %10s %10s %10s %10s %12s" % ("micro/coarse", "goldens", "n15x6", "n4x20", "episode", "ep last20", "env-steps/s"), flush=True)
+for m, c in SCHEDULES:
+    kw = dict(integrator="etdrk4", micro_steps=m, micro_coarse=c)
+    e_ep = episode_err(kw)
+    print("%-14s %10.2e %10.2e %10.2e %10.2e %10.2e %12.3e" % ("%d/%d" % (m, c), golden_err(kw), bridge_err(kw, 15, 6),
+                                                               bridge_err(kw, 4, 20), e_ep[0], e_ep[1], speed(kw)), flush=True)
