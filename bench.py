@@ -323,6 +323,8 @@ def main():
         out.update(cpu)
         print(json.dumps(out))
     if dist is not None:
+        if direct is not None:
+            direct.close()
         dist.destroy_process_group()
 
 
