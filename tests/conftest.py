@@ -18,4 +18,8 @@ def gpu_device():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
+    # the in-tree library normally travels with the snapshot; (re)build it with the box's hipcc if it
+    # is missing or older than its sources -- the same HIP code either way, never a fallback
+    from gym_PVDER_amd import _native
+    _native.build_native()
     return torch.device("cuda:0")
