@@ -145,6 +145,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank == 0:              # before anything touches the GPU (hipcc is a child process)
+        from gym_PVDER_amd import _native
+        _native.build_native()       # no-op when the in-tree library is up to date (never a fallback: same HIP code)
     dist = None
     if world > 1 or os.environ.get("PVDER_BENCH_FORCE_DIST") == "1":   # (forced: exercises RCCL at world 1)
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -170,6 +173,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if dist is not None:
+        dist.barrier()               # rank 0 has (re)built the library, see the top of main()
     from gym_PVDER_amd.vec_env import PVDERVec
     N = args.envs
     if args.micro is None:
