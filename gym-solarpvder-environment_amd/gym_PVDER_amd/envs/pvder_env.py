@@ -49,7 +49,7 @@ class _PVModelView:
         self.Vrms_ref = float(env._vec.par[der_model.IDX["VRMS_REF"]])
 
     def _o(self, k):
-        return float(self._env._vec.out[k, 0])
+        return self._env._host_out[k]
 
     @property
     def Q_ref(self):
@@ -89,7 +89,7 @@ class _SimView:
 
     @property
     def tStart(self):
-        return float(self._env._vec.istate[0, 0]) * SIM_TIME_STEP
+        return self._env._host_ist[0] * SIM_TIME_STEP
 
     @property
     def tStop(self):
@@ -119,6 +119,9 @@ class PVDER(EnvSpecMixin):
                              integrator=integrator, auto_reset=False, seed=seed, model_type=model_type,
                              env_id_base=PVDER.count - 1, **kw)
         self.max_sim_time_user = max_sim_time
+        self._actions = [torch.full((1,), a, dtype=torch.uint8, device=self._vec.device) for a in range(5)]
+        self._pack = torch.zeros(17, dtype=torch.float64, device=self._vec.device)
+        self._host_out, self._host_ist = [0.0] * 13, [0] * 4
         if record_trajectory:      # the reference always keeps the solution rows (self.results, :389)
             self._vec.record_trajectory(self._vec.max_episode_steps + 1)
         self.env_events_spec = self._vec.env_events_spec
@@ -140,16 +143,26 @@ class PVDER(EnvSpecMixin):
     unwrapped = property(lambda s: s)
     env = property(lambda s: s)            # examples use env.env.sim (gym TimeLimit wrapper idiom)
 
+    def _read_back(self):
+        """One device-to-host copy of the env's output block and counters (17 words) into the host
+        mirrors every accessor below reads -- instead of one synchronising read per attribute."""
+        v = self._vec
+        self._pack[:13].copy_(v.out[:, 0])
+        self._pack[13:].copy_(v.istate[:, 0])                        # int32 -> fp64: exact
+        h = self._pack.tolist()
+        self._host_out, self._host_ist = h[:13], [int(x) for x in h[13:]]
+
     @property
     def steps(self):                                                 # env_utilities.py:48-52
-        return int(self._vec.istate[1, 0]) if hasattr(self, 'sim') else 0
+        return self._host_ist[1] if hasattr(self, 'sim') else 0
 
     @property
     def state(self):                                                 # :531-542
-        return tuple(float(v) for v in self._vec.out[:11, 0].tolist())
+        return tuple(self._host_out[:11])
 
     def reset(self):                                                 # :316-334
         self._vec.reset()
+        self._read_back()
         self.sim = _SimView(self)
         self._reward, self.done = 0, False
         self.CONVERGENCE_FAILURE = self.RUNTIME_ERROR = False
@@ -168,19 +181,19 @@ class PVDER(EnvSpecMixin):
             logger.warning('%s:Simulation completed - Reset environment to start new simulation!', self.name)
             return np.array(self.state), self._reward, self.done, {}
         self._action_stats[int(action)] += 1                         # :209
-        a = torch.tensor([int(action)], dtype=torch.uint8, device=self._vec.device)
-        _, reward, done, _ = self._vec.step(a)
-        r = float(reward[0])
-        self.done = bool(done[0])
-        status = int(self._vec.istate[3, 0])
+        self._vec.step(self._actions[int(action)], return_tensors=False)   # device-resident action constants
+        self._read_back()                                            # the only host sync of the step
+        o, ist = self._host_out, self._host_ist
+        r, status = o[11], ist[3]
+        self.done = o[12] != 0.0
         self.CONVERGENCE_FAILURE = status == 2
         self._reward = int(round(r)) if (self.DISCRETE_REWARD and status != 2) else r   # :301 / :172
-        self._reward_stats['step'].append(self.steps)
+        self._reward_stats['step'].append(ist[1])
         self._reward_stats['reward'].append(self._reward)
         self._step_time = time.time() - t0                           # :193
-        self._time_stats['step'].append(self.steps)
+        self._time_stats['step'].append(ist[1])
         self._time_stats['step_time'].append(self._step_time)
-        return np.array(self.state), self._reward, self.done, {}
+        return np.array(o[:11]), self._reward, self.done, {}
 
     def _physical(self):
         """Current algebraic outputs in physical units (host, fp64) for render()."""

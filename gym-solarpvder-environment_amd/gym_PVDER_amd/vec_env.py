@@ -499,31 +499,27 @@ class PVDERVec(EnvSpecMixin):
 
     def record_trajectory(self, capacity: int, env_ids=None):
         """Keep the last ``capacity`` snapshots (reset + env steps) of the listed envs (default: all)
-        on the device: states, refs, output block, time index and active grid-voltage magnitude.
-        ``capacity = 0`` turns recording off.  Not on by default: it adds three small launches per step."""
+        on the device: states, refs, output block and time index.  ``capacity = 0`` turns recording
+        off.  Not on by default: it adds three small device-to-device copies per step."""
         if capacity <= 0:
             self._traj = None
             return
-        ids = torch.arange(self.num_envs, device=self.device) if env_ids is None else \
-            torch.as_tensor(env_ids, dtype=torch.long, device=self.device)
-        self._traj_ids = ids
-        self._traj_rows = self.ns + 2 + 13 + 2
-        self._traj = torch.zeros((int(capacity), self._traj_rows, ids.numel()), dtype=self.fdtype, device=self.device)
+        self._traj_ids = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device)
+        m = self.num_envs if env_ids is None else int(self._traj_ids.numel())
+        self._traj = torch.zeros((int(capacity), self.ns + 2 + 13 + 1, m), dtype=self.fdtype, device=self.device)
         self._traj_n = 0
 
     def _traj_append(self):
-        ids = self._traj_ids
-        ksub = self.istate[0].index_select(0, ids)
-        # active event row at t = ksub/60 (same integer arithmetic as the kernels' event_row)
-        row = torch.where(ksub < self.ev_s0, torch.zeros_like(ksub),
-                          torch.clamp((ksub - self.ev_s0) // max(self.ev_ds, 1) + 1, max=self.ev_count)) \
-            if self.ev_count > 0 else torch.zeros_like(ksub)
-        vg = self.ev_vg.index_select(1, ids).gather(0, row[None].long())[0]
+        ids, ns = self._traj_ids, self.ns
         slot = self._traj[self._traj_n % self._traj.shape[0]]
-        slot[: self.ns + 2] = self.fstate.index_select(1, ids)
-        slot[self.ns + 2: self.ns + 15] = self.out.index_select(1, ids)
-        slot[self.ns + 15] = ksub.to(self.fdtype)
-        slot[self.ns + 16] = vg.to(self.fdtype)
+        if ids is None:
+            slot[: ns + 2].copy_(self.fstate)
+            slot[ns + 2: ns + 15].copy_(self.out)
+            slot[ns + 15].copy_(self.istate[0])                      # int32 -> float: exact
+        else:
+            slot[: ns + 2].copy_(self.fstate.index_select(1, ids))
+            slot[ns + 2: ns + 15].copy_(self.out.index_select(1, ids))
+            slot[ns + 15].copy_(self.istate[0].index_select(0, ids))
         self._traj_n += 1
 
     def trajectory(self, env: int = 0) -> Dict[str, np.ndarray]:
@@ -537,9 +533,15 @@ class PVDERVec(EnvSpecMixin):
         order = [(self._traj_n - n + k) % cap for k in range(n)]
         a = self._traj[order, :, env].to(torch.float64).cpu().numpy().T          # [rows, n]
         ns = self.ns
-        d = der_model.physical_outputs(self.par, a[:ns], a[ns + 16], a[ns], a[ns + 1])
+        # grid-voltage magnitude in force, from the recorded PCC voltage: v_a = kvg vg + kvi i_a
+        P = der_model.IDX
+        kvg = complex(self.par[P["KVG_RE"]], self.par[P["KVG_IM"]]) * self.par[P["VG_SCALE"]]
+        kvi = complex(self.par[P["KVI_RE"]], self.par[P["KVI_IM"]])
+        va = a[ns + 2 + 2] + 1j * a[ns + 2 + 3]
+        vgrid = np.real((va - kvi * (a[0] + 1j * a[1])) / kvg)
+        d = der_model.physical_outputs(self.par, a[:ns], vgrid, a[ns], a[ns + 1])
         d["t"] = a[ns + 15] * SIM_TIME_STEP
-        d["vgrid"] = a[ns + 16]                     # grid-voltage event magnitude in force [pu]
+        d["vgrid"] = vgrid                          # grid-voltage event magnitude in force [pu]
         d["Ppv"] = a[ns + 2 + 7] * der_model.SBASE
         d["reward"], d["done"] = a[ns + 2 + 11], a[ns + 2 + 12] != 0
         return d
