@@ -6,9 +6,9 @@ Workload (BASELINE.json configs[2], the configuration the north_star target is q
 GPU, PVDER-v0 default kwargs (n = 15 sim time steps of 1/60 s per env step, discrete
 voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32 fixed-step
 4th-order Runge-Kutta, uniform random actions resident on the device, same-step auto-reset.
-Default integrator: ETDRK4 (exponential-time-differencing RK4: the stiff current loop is propagated
-exactly; 8 steps in a sim time step that starts at an input jump -- new action / event -- and 2 in
-every other one); the classic-RK4 kernel (4096 micro-steps per sim time step,
+Default integrator: ETDRK4 (exponential Runge-Kutta of stiff order 4, Hochbruck-Ostermann's 5-stage
+scheme: the stiff current loop is propagated exactly; 8 steps in a sim time step that starts at an
+input jump -- new action / event -- and 1 in every other one); the classic-RK4 kernel (4096 micro-steps per sim time step,
 the literal "fixed-step RK4" of BASELINE configs[1-3]) is timed in the same run and reported under
 "classic_rk4".  Both meet the 1e-4 rel-L2 parity bar against the fp64 oracle (tests/, -m gpu).
 A "step" is one batched env transition (one fused HIP launch over all local envs); for N > 1 each
@@ -35,10 +35,10 @@ HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
 BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, three-phase fp32
 # flop per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
-FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 731}     # etdrk4: balanced fast path (23-state tail: ~2200)
+FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907}     # etdrk4: balanced fast path, 5-stage scheme (23-state tail: ~2700)
 # instructions per integrator step of the same loops (one wave per SIMD at 65 536 envs: the loop is
 # bound by the single-wave issue rate, tools/issue_probe.hip: 2.25-2.5 ns per independent instruction)
-INSTR_PER_STEP = {"etdrk4": 326}
+INSTR_PER_STEP = {"etdrk4": 398}
 DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
 KERNEL_NAME = {"etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
 
@@ -299,7 +299,7 @@ def main():
             "config": {"workload": ("BASELINE configs[2]" if (N, args.n_sub) == (65536, 15) else "variant of BASELINE configs[2]") +
                                    ": %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
-                                   % (N, args.n_sub, {"etdrk4": "fp32 ETDRK4 (exponential RK4), %d steps per 1/60 s after an input jump, %d otherwise"
+                                   % (N, args.n_sub, {"etdrk4": "fp32 ETDRK4 (exponential RK, stiff order 4, 5 stages), %d steps per 1/60 s after an input jump, %d otherwise"
                                                                 % (args.micro, env.micro_coarse or args.micro),
                                                       "rk4": "fp32 fixed-step classic RK4, %d micro-steps per 1/60 s" % args.micro,
                                                       "rk45": "fp64 adaptive RK45"}[args.integrator]),

@@ -438,7 +438,8 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 // small device buffer filled once by the caller from pvder_etdrk4_coefficients(): as a by-value
 // kernel argument they made the kernarg segment 1.9 KB, which every workgroup re-reads at launch.
 constexpr int kMatFloats = 8;                      // 2x2 complex: (re, im) of entries 11, 12, 21, 22
-constexpr int kCoefFloats = 2 * 10 * kMatFloats;
+constexpr int kMatCount = 13;
+constexpr int kCoefFloats = 2 * kMatCount * kMatFloats;
 struct EtdK {
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
@@ -446,7 +447,8 @@ struct EtdK {
     int rk4_sub[2];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
     float i2_to_m2;         // balanced kernel: |iref|^2 * i2_to_m2 > guard  <=>  |iref| within 10 % of its limit
 };
-enum { EM_E2 = 0, EM_E, EM_P1, EM_A1, EM_A2, EM_B1, EM_B3, EM_C1, EM_C2, EM_C4 };
+// matrices of one step size, in the order they are used: those applied to (z, N1) first
+enum { EM_E2 = 0, EM_E, EM_A21, EM_A31, EM_A41, EM_A51, EM_B1, EM_A32, EM_A42, EM_A52, EM_A54, EM_B4, EM_B5, EM_COUNT };
 
 // The ONE by-value argument of the ETDRK4 kernel (kernarg offset 0).  A single struct so that the
 // 23-state tail (etdrk4_full_tail) can re-read every argument through a laundered copy of the kernarg
@@ -610,7 +612,6 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
         to_pairs(ys, y);
 #pragma unroll
         for (int k = 0; k < NP; ++k) comp[k] = pvder::bc2(0.f);
-        const v2 two = pvder::bc2(2.f);
         const pvder::PkConst K = pvder::make_pkconst(P);
         // slow pairs of the packed layout: x_a, x_b, x_c, (Vdc,xDC), (xQ,xPLL), (delta,0)
         constexpr int SL[6] = {1, 4, 7, 9, 10, 11};
@@ -628,66 +629,81 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
             const int nst = fine ? C.micro : C.micro2;
             const int rk4_sub = fine ? Ec.rk4_sub[0] : Ec.rk4_sub[1];
             const float h = (float)(1.0 / 60.0) / (float)nst;
-            const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+            const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
+                     h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
             const float tq = 2.f / (float)nst;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < nst; ++j) {
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
                 // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
                 // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
-                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 20);
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 2 * kMatCount);
                 asm volatile("" : "+v"(Mq));
                 const float t0 = (float)j * tq, t1 = ((float)j + 0.5f) * tq, t2 = ((float)j + 1.f) * tq;
-                v2 n1f[6], nf[6], nsl[6], ks[6], yt[NP], n23[6];
-                v2 u3[6], u4[6], zn[6];    // running sums of U3, U4, z+   (index 2p = i_p, 2p+1 = u_p)
-                const float m2a = etd_eval(P, K, Ec, S, y, t0, L.qref, L.vdcref, n1f, nsl);
+                v2 n1f[6], nf[6], ns1[6], nsl[6], s23[6], k14[6], yt[NP], n23[6];
+                v2 u3[6], u4[6], u5[6], zn[6];    // running sums of U3, U4, U5, z+   (index 2p = i_p, 2p+1 = u_p)
+                const float m2a = etd_eval(P, K, Ec, S, y, t0, L.qref, L.vdcref, n1f, ns1);      // N1
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     const v2 zi = y[3 * p], zu = y[3 * p + 2];
+                    const v2 n1i = n1f[2 * p], n1u = n1f[2 * p + 1];
                     v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
                     matvec(load_mat(Mq, EM_E2), zi, zu, e2i, e2u);                    // E2 z
                     matvec(load_mat(Mq, EM_E), zi, zu, ei, eu);                       // E z
                     v2 ai = e2i, au = e2u;
-                    matvec(load_mat(Mq, EM_P1), n1f[2 * p], n1f[2 * p + 1], ai, au);  // U2
+                    matvec(load_mat(Mq, EM_A21), n1i, n1u, ai, au);                   // U2
                     yt[3 * p] = ai; yt[3 * p + 2] = au;
                     u3[2 * p] = e2i; u3[2 * p + 1] = e2u;
-                    matvec(load_mat(Mq, EM_A1), n1f[2 * p], n1f[2 * p + 1], u3[2 * p], u3[2 * p + 1]);
+                    matvec(load_mat(Mq, EM_A31), n1i, n1u, u3[2 * p], u3[2 * p + 1]);
                     u4[2 * p] = ei; u4[2 * p + 1] = eu;
-                    matvec(load_mat(Mq, EM_B1), n1f[2 * p], n1f[2 * p + 1], u4[2 * p], u4[2 * p + 1]);
+                    matvec(load_mat(Mq, EM_A41), n1i, n1u, u4[2 * p], u4[2 * p + 1]);
+                    u5[2 * p] = e2i; u5[2 * p + 1] = e2u;
+                    matvec(load_mat(Mq, EM_A51), n1i, n1u, u5[2 * p], u5[2 * p + 1]);
                     zn[2 * p] = ei; zn[2 * p + 1] = eu;
-                    matvec(load_mat(Mq, EM_C1), n1f[2 * p], n1f[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                    matvec(load_mat(Mq, EM_B1), n1i, n1u, zn[2 * p], zn[2 * p + 1]);
                 }
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { ks[q] = nsl[q]; yt[SL[q]] = pvder::fma2(h2, nsl[q], y[SL[q]]); }
+                for (int q = 0; q < 6; ++q) yt[SL[q]] = pvder::fma2(h2, ns1[q], y[SL[q]]);
                 etd_eval(P, K, Ec, S, yt, t1, L.qref, L.vdcref, nf, nsl);             // N2
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     n23[2 * p] = nf[2 * p]; n23[2 * p + 1] = nf[2 * p + 1];
-                    v2 ai = u3[2 * p], au = u3[2 * p + 1];
-                    matvec(load_mat(Mq, EM_A2), nf[2 * p], nf[2 * p + 1], ai, au);    // U3
-                    yt[3 * p] = ai; yt[3 * p + 2] = au;
+                    matvec(load_mat(Mq, EM_A32), nf[2 * p], nf[2 * p + 1], u3[2 * p], u3[2 * p + 1]);   // U3
+                    yt[3 * p] = u3[2 * p]; yt[3 * p + 2] = u3[2 * p + 1];
                 }
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { ks[q] = pvder::fma2(two, nsl[q], ks[q]); yt[SL[q]] = pvder::fma2(h2, nsl[q], y[SL[q]]); }
+                for (int q = 0; q < 6; ++q) { s23[q] = nsl[q]; yt[SL[q]] = pvder::fma2(h2, nsl[q], y[SL[q]]); }
                 etd_eval(P, K, Ec, S, yt, t1, L.qref, L.vdcref, nf, nsl);             // N3
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     n23[2 * p] += nf[2 * p]; n23[2 * p + 1] += nf[2 * p + 1];
-                    v2 ai = u4[2 * p], au = u4[2 * p + 1];
-                    matvec(load_mat(Mq, EM_B3), nf[2 * p], nf[2 * p + 1], ai, au);    // U4
-                    yt[3 * p] = ai; yt[3 * p + 2] = au;
-                    matvec(load_mat(Mq, EM_C2), n23[2 * p], n23[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                    matvec(load_mat(Mq, EM_A42), n23[2 * p], n23[2 * p + 1], u4[2 * p], u4[2 * p + 1]);   // U4
+                    matvec(load_mat(Mq, EM_A52), n23[2 * p], n23[2 * p + 1], u5[2 * p], u5[2 * p + 1]);
+                    yt[3 * p] = u4[2 * p]; yt[3 * p + 2] = u4[2 * p + 1];
                 }
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { ks[q] = pvder::fma2(two, nsl[q], ks[q]); yt[SL[q]] = pvder::fma2(h1, nsl[q], y[SL[q]]); }
+                for (int q = 0; q < 6; ++q) { s23[q] += nsl[q]; yt[SL[q]] = pvder::fma2(h2, s23[q], y[SL[q]]); }
                 etd_eval(P, K, Ec, S, yt, t2, L.qref, L.vdcref, nf, nsl);             // N4
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    matvec(load_mat(Mq, EM_C4), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                    matvec(load_mat(Mq, EM_A54), nf[2 * p], nf[2 * p + 1], u5[2 * p], u5[2 * p + 1]);   // U5
+                    matvec(load_mat(Mq, EM_B4), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+                    yt[3 * p] = u5[2 * p]; yt[3 * p + 2] = u5[2 * p + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    k14[q] = ns1[q] + nsl[q];
+                    yt[SL[q]] = pvder::fma2(h8, s23[q], pvder::fma2(h4, ns1[q], y[SL[q]]));
+                }
+                etd_eval(P, K, Ec, S, yt, t1, L.qref, L.vdcref, nf, nsl);             // N5
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    matvec(load_mat(Mq, EM_B5), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
                     yt[3 * p] = zn[2 * p]; yt[3 * p + 2] = zn[2 * p + 1];
                 }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) yt[SL[q]] = pvder::fma2(h6, ks[q] + nsl[q], y[SL[q]]);   // x_p candidate
+                for (int q = 0; q < 3; ++q)                                            // x_p candidate
+                    yt[SL[q]] = pvder::fma2(h23, nsl[q], pvder::fma2(h6, k14[q], y[SL[q]]));
                 const float m2b = max_m2(P, yt);
                 if (fmaxf(m2a, m2b) > guard) {
                     // duty cycle near its limit: anti-windup may switch the fast dynamics -> redo
@@ -700,7 +716,7 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) {
                         const int g = SL[q];
-                        const v2 inc = pvder::fma2(h6, ks[q] + nsl[q], -comp[g]);
+                        const v2 inc = pvder::fma2(h23, nsl[q], pvder::fma2(h6, k14[q], -comp[g]));
                         const v2 tsum = y[g] + inc;
                         comp[g] = (tsum - y[g]) - inc;
                         y[g] = tsum;
@@ -815,7 +831,6 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             defer |= ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
         }
         v2 cx = pvder::bc2(0.f), cv = pvder::bc2(0.f), cq = pvder::bc2(0.f), cd = pvder::bc2(0.f);   // Kahan
-        const v2 two = pvder::bc2(2.f);
         const pvder::PkConst K = pvder::make_pkconst(P);
         // outer-loop gains (Kp_DC, -Kp_Q), (Ki_DC, -Ki_Q), pinned to SGPRs.  Left to itself hipcc
         // merges the adjacent kernarg fields into one 12-byte memcpy to a private slot, promotes that
@@ -845,58 +860,65 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
             const int nst = fine ? C.micro : C.micro2;
             const float h = (float)(1.0 / 60.0) / (float)nst;
-            const v2 h2 = pvder::bc2(0.5f * h), h1 = pvder::bc2(h), h6 = pvder::bc2(h * (float)(1.0 / 6.0));
+            const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
+                     h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < nst; ++j) {
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
-                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 20);
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 2 * kMatCount);
                 asm volatile("" : "+v"(Mq));
-                v2 n1i, n1u, ni, nu, ns[4], ks[4];
+                v2 n1i, n1u, ni, nu, ns1[4], ns[4], s23[4];
                 float ir2a, ir2x;
-                // software prefetch: issue the LDS reads of the six matrices applied to (z, N1) now,
+                // software prefetch: issue the LDS reads of the seven matrices applied to (z, N1) now,
                 // the model evaluation below hides their latency (one wave per SIMD: nobody else will)
-                const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mP1 = load_mat(Mq, EM_P1);
-                const Mat4 mA1 = load_mat(Mq, EM_A1), mB1 = load_mat(Mq, EM_B1), mC1 = load_mat(Mq, EM_C1);
+                const Mat4 mE2 = load_mat(Mq, EM_E2), mE = load_mat(Mq, EM_E), mA21 = load_mat(Mq, EM_A21);
+                const Mat4 mA31 = load_mat(Mq, EM_A31), mA41 = load_mat(Mq, EM_A41), mA51 = load_mat(Mq, EM_A51),
+                           mB1 = load_mat(Mq, EM_B1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the reads up here (hipcc would sink them to their uses)
-                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, pa, pb, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns, ir2a);
+                const float m2a = bal_eval<PH>(P, K, Ec, S, ia, xa, ua, pa, pb, dl.x, L.qref, L.vdcref, kpo, kio, n1i, n1u, ns1, ir2a);
                 v2 e2i = pvder::bc2(0.f), e2u = pvder::bc2(0.f), ei = pvder::bc2(0.f), eu = pvder::bc2(0.f);
                 matvec(mE2, ia, ua, e2i, e2u);
                 matvec(mE, ia, ua, ei, eu);
                 v2 ti = e2i, tu = e2u;                                          // U2
-                matvec(mP1, n1i, n1u, ti, tu);
-                v2 u3i = e2i, u3u = e2u, u4i = ei, u4u = eu, zi = ei, zu = eu;
-                matvec(mA1, n1i, n1u, u3i, u3u);
-                matvec(mB1, n1i, n1u, u4i, u4u);
-                matvec(mC1, n1i, n1u, zi, zu);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ks[q] = ns[q];
-                const Mat4 mA2 = load_mat(Mq, EM_A2), mB3 = load_mat(Mq, EM_B3), mC2 = load_mat(Mq, EM_C2),
-                           mC4 = load_mat(Mq, EM_C4);          // prefetched behind evaluations 2-4
-                __builtin_amdgcn_sched_barrier(0);
-                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], pa),
-                         pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);   // N2
+                matvec(mA21, n1i, n1u, ti, tu);
+                v2 u3i = e2i, u3u = e2u, u4i = ei, u4u = eu, u5i = e2i, u5u = e2u, zi = ei, zu = eu;
+                matvec(mA31, n1i, n1u, u3i, u3u);
+                matvec(mA41, n1i, n1u, u4i, u4u);
+                matvec(mA51, n1i, n1u, u5i, u5u);
+                matvec(mB1, n1i, n1u, zi, zu);
+                const Mat4 mA32 = load_mat(Mq, EM_A32), mA42 = load_mat(Mq, EM_A42), mA52 = load_mat(Mq, EM_A52),
+                           mA54 = load_mat(Mq, EM_A54), mB4 = load_mat(Mq, EM_B4), mB5 = load_mat(Mq, EM_B5);
+                __builtin_amdgcn_sched_barrier(0);                              // prefetched behind evaluations 2-5
+                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns1[0], xa), tu, pvder::fma2(h2, ns1[1], pa),
+                         pvder::fma2(h2, ns1[2], pb), dl.x + 0.5f * h * ns1[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);   // N2
                 v2 n23i = ni, n23u = nu;
-                ti = u3i; tu = u3u;                                             // U3
-                matvec(mA2, ni, nu, ti, tu);
+                matvec(mA32, ni, nu, u3i, u3u);                                 // U3
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
-                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h2, ns[0], xa), tu, pvder::fma2(h2, ns[1], pa),
+                for (int q = 0; q < 4; ++q) s23[q] = ns[q];
+                bal_eval<PH>(P, K, Ec, S, u3i, pvder::fma2(h2, ns[0], xa), u3u, pvder::fma2(h2, ns[1], pa),
                          pvder::fma2(h2, ns[2], pb), dl.x + 0.5f * h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);   // N3
                 n23i += ni; n23u += nu;
-                ti = u4i; tu = u4u;                                             // U4
-                matvec(mB3, ni, nu, ti, tu);
-                matvec(mC2, n23i, n23u, zi, zu);
+                matvec(mA42, n23i, n23u, u4i, u4u);                             // U4
+                matvec(mA52, n23i, n23u, u5i, u5u);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ks[q] = pvder::fma2(two, ns[q], ks[q]);
-                bal_eval<PH>(P, K, Ec, S, ti, pvder::fma2(h1, ns[0], xa), tu, pvder::fma2(h1, ns[1], pa),
-                         pvder::fma2(h1, ns[2], pb), dl.x + h * ns[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);         // N4
-                matvec(mC4, ni, nu, zi, zu);
-                // Kahan-compensated slow update
+                for (int q = 0; q < 4; ++q) s23[q] += ns[q];
+                bal_eval<PH>(P, K, Ec, S, u4i, pvder::fma2(h2, s23[0], xa), u4u, pvder::fma2(h2, s23[1], pa),
+                         pvder::fma2(h2, s23[2], pb), dl.x + 0.5f * h * s23[3].x, L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);   // N4
+                matvec(mA54, ni, nu, u5i, u5u);                                 // U5
+                matvec(mB4, ni, nu, zi, zu);
+                v2 k14[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) k14[q] = ns1[q] + ns[q];
+                bal_eval<PH>(P, K, Ec, S, u5i, pvder::fma2(h8, s23[0], pvder::fma2(h4, ns1[0], xa)), u5u,
+                         pvder::fma2(h8, s23[1], pvder::fma2(h4, ns1[1], pa)), pvder::fma2(h8, s23[2], pvder::fma2(h4, ns1[2], pb)),
+                         dl.x + h * (0.25f * ns1[3].x + 0.125f * s23[3].x), L.qref, L.vdcref, kpo, kio, ni, nu, ns, ir2x);         // N5
+                matvec(mB5, ni, nu, zi, zu);
+                // Kahan-compensated slow update:  y+ = y + h (N1 + N4)/6 + 2h N5/3
                 v2 inc, tsum;
-                inc = pvder::fma2(h6, ks[0] + ns[0], -cx); tsum = xa + inc; cx = (tsum - xa) - inc; const v2 xn = tsum;
-                inc = pvder::fma2(h6, ks[1] + ns[1], -cv); tsum = pa + inc; cv = (tsum - pa) - inc; const v2 vn = tsum;
-                inc = pvder::fma2(h6, ks[2] + ns[2], -cq); tsum = pb + inc; cq = (tsum - pb) - inc; const v2 qn = tsum;
-                inc = pvder::fma2(h6, ks[3] + ns[3], -cd); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
+                inc = pvder::fma2(h23, ns[0], pvder::fma2(h6, k14[0], -cx)); tsum = xa + inc; cx = (tsum - xa) - inc; const v2 xn = tsum;
+                inc = pvder::fma2(h23, ns[1], pvder::fma2(h6, k14[1], -cv)); tsum = pa + inc; cv = (tsum - pa) - inc; const v2 vn = tsum;
+                inc = pvder::fma2(h23, ns[2], pvder::fma2(h6, k14[2], -cq)); tsum = pb + inc; cq = (tsum - pb) - inc; const v2 qn = tsum;
+                inc = pvder::fma2(h23, ns[3], pvder::fma2(h6, k14[3], -cd)); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
                 const v2 mn = pvder::fma2(pvder::bc2(P.KpG), zu, xn);
                 // near duty-cycle saturation or the current limit: the 23-state path redoes this env step
                 defer |= fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
@@ -1213,7 +1235,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
     const cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
     EtdK E;
     float scratch[kCoefFloats];
-    float(*m)[10][kMatFloats] = reinterpret_cast<float(*)[10][kMatFloats]>(coef ? coef : scratch);
+    float(*m)[kMatCount][kMatFloats] = reinterpret_cast<float(*)[kMatCount][kMatFloats]>(coef ? coef : scratch);
     const M2 Z{};
     const int mic[2] = {micro, micro_coarse};
     for (int set = 0; set < 2; ++set) {
@@ -1223,16 +1245,24 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
             ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
             pf[k] = fun2(L, l1, l2, phi(k, h * l1), phi(k, h * l2));
         }
+        // Hochbruck-Ostermann (2005, eq. 5.19) coefficient functions, h folded in
+        const M2 a52 = lin(0.5, ph[2], -1.0, pf[3], 0.25, pf[2]);           // phi2,5/2 - phi3,4 + phi2,4/4 ...
+        const M2 a52f = lin(1.0, a52, -0.5, ph[3], 0, Z);                    // ... - phi3,5/2
+        const M2 a54 = lin(0.25, ph[2], -1.0, a52f, 0, Z);
+        const M2 a51 = lin(0.5, ph[1], -2.0, a52f, -1.0, a54);
         pack_m2(ph[0], m[set][EM_E2]);
         pack_m2(pf[0], m[set][EM_E]);
-        pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), m[set][EM_P1]);
-        pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), m[set][EM_A1]);
-        pack_m2(lin(h, ph[2], 0, Z, 0, Z), m[set][EM_A2]);
-        pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), m[set][EM_B1]);
-        pack_m2(lin(2 * h, pf[2], 0, Z, 0, Z), m[set][EM_B3]);
-        pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), m[set][EM_C1]);
-        pack_m2(lin(2 * h, pf[2], -4 * h, pf[3], 0, Z), m[set][EM_C2]);
-        pack_m2(lin(4 * h, pf[3], -h, pf[2], 0, Z), m[set][EM_C4]);
+        pack_m2(lin(0.5 * h, ph[1], 0, Z, 0, Z), m[set][EM_A21]);
+        pack_m2(lin(0.5 * h, ph[1], -h, ph[2], 0, Z), m[set][EM_A31]);
+        pack_m2(lin(h, ph[2], 0, Z, 0, Z), m[set][EM_A32]);
+        pack_m2(lin(h, pf[1], -2 * h, pf[2], 0, Z), m[set][EM_A41]);
+        pack_m2(lin(h, pf[2], 0, Z, 0, Z), m[set][EM_A42]);
+        pack_m2(lin(h, a51, 0, Z, 0, Z), m[set][EM_A51]);
+        pack_m2(lin(h, a52f, 0, Z, 0, Z), m[set][EM_A52]);
+        pack_m2(lin(h, a54, 0, Z, 0, Z), m[set][EM_A54]);
+        pack_m2(lin(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), m[set][EM_B1]);
+        pack_m2(lin(-h, pf[2], 4 * h, pf[3], 0, Z), m[set][EM_B4]);
+        pack_m2(lin(4 * h, pf[2], -8 * h, pf[3], 0, Z), m[set][EM_B5]);
         // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
         E.rk4_sub[set] = (4096 + mic[set] - 1) / mic[set];      // (23-state tail only)
         if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;

@@ -30,7 +30,7 @@ MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
 # by the current loop (h <= ~4.5 us); ETDRK4 propagates that loop exactly and is accuracy-bound
 DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
 # ETDRK4 two-rate schedule: sim time steps that do not start at an input jump (new action / event)
-DEFAULT_MICRO_COARSE = 2
+DEFAULT_MICRO_COARSE = 1
 
 OBSERVED_QUANTITIES = ['iaR', 'iaI', 'vaR', 'vaI', 'P_PCC', 'Q_PCC', 'Vdc', 'Ppv', 'Vdc_ref', 'Q_ref',
                        'tStart']         # PVDER_env.py:44-49
@@ -131,7 +131,7 @@ class PVDERVec(EnvSpecMixin):
                     Dormand-Prince)
         micro_steps: integrator steps per 1/60 s sim time step (default 8 / 4096)
         micro_coarse: ETDRK4 only -- steps per sim time step that does not start at an input jump
-                    (new action or event); default 2, 0 = uniform micro_steps
+                    (new action or event); default 1, 0 = uniform micro_steps
         auto_reset: reset finished envs inside ``step`` (their returned obs is the reset obs)
         model_type: 'model_2' (three phase, derId 50, the PVDER-v0 default) or 'model_1'
         seed / env_id_base: key of the on-device event generator (env_id_base = global index of

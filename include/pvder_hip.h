@@ -103,7 +103,7 @@ typedef struct pvder_step_cfg {
     double rtol, atol;    /* RK45 only */
     int32_t micro_coarse; /* ETDRK4 two-rate schedule: a sim time step that starts at an input jump (new
                              action or new event row) takes `micro` steps, every other one
-                             `micro_coarse` (0 = same as micro).  PVDER defaults: 8 / 2 */
+                             `micro_coarse` (0 = same as micro).  PVDER defaults: 8 / 1 */
     int32_t pad_;
 } pvder_step_cfg;
 
@@ -159,9 +159,10 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
  *     the next launch (alternate 2, 3, 2, ... and no memset is ever enqueued; the bank that is
  *     accumulated into must have been cleared by the previous launch or by the caller).
  *
- * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (exponential-time-differencing Runge-Kutta 4,
- *   Krogstad form): the stiff filter-current/controller pair of each phase is propagated with
- *   the exact matrix exponential, the other 11 states by classic RK4; cfg->micro ~ 8.
+ * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (explicit exponential Runge-Kutta method of stiff
+ *   order 4: Hochbruck & Ostermann 2005, five stages): the stiff filter-current/controller pair of
+ *   each phase is propagated with the exact matrix exponential, the other 11 states by the
+ *   scheme's non-stiff limit (a 5-stage 4th-order Runge-Kutta method); cfg->micro ~ 8.
  * pvder_step_rk4_f32: fp32 fixed-step classic RK4 micro-stepping (cfg->micro ~ 4096),
  *   Kahan-compensated state update. */
 int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
