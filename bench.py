@@ -7,8 +7,8 @@ GPU, PVDER-v0 default kwargs (n = 15 sim time steps of 1/60 s per env step, disc
 voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32 fixed-step
 4th-order Runge-Kutta, uniform random actions resident on the device, same-step auto-reset.
 Default integrator: ETDRK4 (exponential Runge-Kutta of stiff order 4, Hochbruck-Ostermann's 5-stage
-scheme: the stiff current loop is propagated exactly; 8 steps in a sim time step that starts at an
-input jump -- new action / event -- and 1 in every other one); the classic-RK4 kernel (4096 micro-steps per sim time step,
+scheme: the stiff current loop is propagated exactly; a sim time step that starts at an input jump --
+new action / event -- takes a first step of 1/1920 s and one over the remainder, every other one 1 step); the classic-RK4 kernel (4096 micro-steps per sim time step,
 the literal "fixed-step RK4" of BASELINE configs[1-3]) is timed in the same run and reported under
 "classic_rk4".  Both meet the 1e-4 rel-L2 parity bar against the fp64 oracle (tests/, -m gpu).
 A "step" is one batched env transition (one fused HIP launch over all local envs); for N > 1 each
@@ -38,8 +38,8 @@ BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, 
 FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907}     # etdrk4: balanced fast path, 5-stage scheme (23-state tail: ~2700)
 # instructions per integrator step of the same loops (one wave per SIMD at 65 536 envs: the loop is
 # bound by the single-wave issue rate, tools/issue_probe.hip: 2.25-2.5 ns per independent instruction)
-INSTR_PER_STEP = {"etdrk4": 398}
-DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
+INSTR_PER_STEP = {"etdrk4": 396}
+DEFAULT_MICRO = {"etdrk4": 32, "rk4": 4096, "rk45": 1}
 KERNEL_NAME = {"etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
 
 
@@ -50,7 +50,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--n-sub", type=int, default=15)
-    ap.add_argument("--micro", type=int, default=None, help="integrator steps per 1/60 s (default 8 / 4096)")
+    ap.add_argument("--micro", type=int, default=None,
+                    help="ETDRK4: first step behind an input jump = 1/(60*micro) s (default 32); classic RK4: steps per 1/60 s (4096)")
+    ap.add_argument("--graded", type=int, default=1,
+                    help="ETDRK4: 1 = two steps (first + remainder) in a sim time step that starts at a jump, 0 = micro uniform steps")
     ap.add_argument("--micro-coarse", type=int, default=None,
                     help="ETDRK4: steps per sim time step that does not start at an input jump (default 2)")
     ap.add_argument("--integrator", default="etdrk4", choices=["etdrk4", "rk4", "rk45"])
@@ -180,7 +183,7 @@ def main():
     if args.micro is None:
         args.micro = DEFAULT_MICRO[args.integrator]
     env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=args.n_sub, micro_steps=args.micro,
-                   micro_coarse=args.micro_coarse, integrator=args.integrator, seed=2024, env_id_base=rank * N, events_spec=events_on_spec(),
+                   micro_coarse=args.micro_coarse, graded=bool(args.graded), integrator=args.integrator, seed=2024, env_id_base=rank * N, events_spec=events_on_spec(),
                    auto_reset=True)
     env.reset()
     gen = torch.Generator(device=dev)
@@ -285,7 +288,7 @@ def main():
         # steps that start at an input jump (the first of each env step + one event per second)
         if args.integrator == "etdrk4":
             n_fine = 1.0 + (args.n_sub - 1) / 60.0
-            steps_per_env_step = n_fine * args.micro + (args.n_sub - n_fine) * env.micro_coarse \
+            steps_per_env_step = n_fine * (2 if env.graded else args.micro) + (args.n_sub - n_fine) * env.micro_coarse \
                 if env.micro_coarse > 0 else args.micro * args.n_sub
         else:
             steps_per_env_step = args.micro * args.n_sub
@@ -299,12 +302,13 @@ def main():
             "config": {"workload": ("BASELINE configs[2]" if (N, args.n_sub) == (65536, 15) else "variant of BASELINE configs[2]") +
                                    ": %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
-                                   % (N, args.n_sub, {"etdrk4": "fp32 ETDRK4 (exponential RK, stiff order 4, 5 stages), %d steps per 1/60 s after an input jump, %d otherwise"
-                                                                % (args.micro, env.micro_coarse or args.micro),
+                                   % (N, args.n_sub, {"etdrk4": ("fp32 ETDRK4 (exponential RK, stiff order 4, 5 stages), sim time step behind an input jump: "
+                                                                 + ("first step 1/(60*%d) s + one over the remainder" if env.graded else "%d uniform steps")
+                                                                 + ", every other one: %d step(s)") % (args.micro, env.micro_coarse or args.micro),
                                                       "rk4": "fp32 fixed-step classic RK4, %d micro-steps per 1/60 s" % args.micro,
                                                       "rk45": "fp64 adaptive RK45"}[args.integrator]),
                        "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro,
-                       "micro_coarse": env.micro_coarse,
+                       "micro_coarse": env.micro_coarse, "graded": bool(env.graded),
                        "integrator": args.integrator,
                        "collective": ("all-gather of the [13, N_local] fp32 block per step: %s; %s"
                                       % (collective, "synchronous" if args.sync_gather else "overlapped with the next step"))

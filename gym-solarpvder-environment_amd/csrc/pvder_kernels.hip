@@ -48,7 +48,7 @@ constexpr int kDeferred = -1; // transient istate status (single-phase ETDRK4 on
 
 template <typename T>
 struct StepK {
-    int n_sub, micro, micro2, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it;
+    int n_sub, micro, micro2, graded, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it;
     T dq, dv, inv_tmax, p_t, q_t, rtol, atol;
 };
 
@@ -432,19 +432,22 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 // While a duty cycle is near its limit the conditional-integration anti-windup changes the fast
 // dynamics; such (rare) steps are redone by classic RK4 micro-steps from the saved state.
 // =============================================================================================
-// The coefficient matrices themselves (2 step sizes x 10 matrices x 8 floats: set 0 for
-// h = 1/(60*micro), the sim time steps that start at an input jump, set 1 for h = 1/(60*micro_coarse);
+// The coefficient matrices themselves (3 step sizes x 13 matrices x 8 floats: set 0 for
+// h = 1/(60*micro), the first step behind an input jump, set 1 for h = 1/(60*micro_coarse), set 2 for
+// the remainder (1 - 1/micro)/60 of the graded schedule;
 // order E2,E,P1,A1,A2,B1,B3,C1,C2,C4; per complex entry (re, im) for 11,12,21,22) live in a
 // small device buffer filled once by the caller from pvder_etdrk4_coefficients(): as a by-value
 // kernel argument they made the kernarg segment 1.9 KB, which every workgroup re-reads at launch.
 constexpr int kMatFloats = 8;                      // 2x2 complex: (re, im) of entries 11, 12, 21, 22
 constexpr int kMatCount = 13;
-constexpr int kCoefFloats = 2 * kMatCount * kMatFloats;
+constexpr int kCoefSets = 3;                       // step sizes: first behind a jump / coarse / remainder
+constexpr int kCoefFloats = kCoefSets * kMatCount * kMatFloats;
 struct EtdK {
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
-    int rk4_sub[2];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
+    int rk4_sub[3];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
+    float hset[3];          // step sizes [s]: 1/(60 micro), 1/(60 micro_coarse), (1 - 1/micro)/60
     float i2_to_m2;         // balanced kernel: |iref|^2 * i2_to_m2 > guard  <=>  |iref| within 10 % of its limit
 };
 // matrices of one step size, in the order they are used: those applied to (z, N1) first
@@ -626,20 +629,23 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
             // (wave-uniform: if any env of the wave has a jump here the whole wave takes the fine rate --
             // never less accurate, and the step loop keeps a scalar trip count)
             const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
-            const int nst = fine ? C.micro : C.micro2;
-            const int rk4_sub = fine ? Ec.rk4_sub[0] : Ec.rk4_sub[1];
-            const float h = (float)(1.0 / 60.0) / (float)nst;
-            const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
-                     h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
-            const float tq = 2.f / (float)nst;
+            const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
+            float t0 = 0.f;                                   // 2*theta (turns) since the start of this sim time step
             for (int j = 0; j < nst; ++j) {
+                // graded schedule: first step 1/(60 micro), then ONE step over the remainder
+                const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
+                const int rk4_sub = set == 0 ? Ec.rk4_sub[0] : (set == 1 ? Ec.rk4_sub[1] : Ec.rk4_sub[2]);
+                const float h = set == 0 ? Ec.hset[0] : (set == 1 ? Ec.hset[1] : Ec.hset[2]);
+                const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
+                         h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
+                const float tq = 120.f * h;                   // 2*theta advances 2 turns per 1/60 s
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
                 // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
                 // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
-                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 2 * kMatCount);
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + 2 * kMatCount * set;
                 asm volatile("" : "+v"(Mq));
-                const float t0 = (float)j * tq, t1 = ((float)j + 0.5f) * tq, t2 = ((float)j + 1.f) * tq;
+                const float t1 = t0 + 0.5f * tq, t2 = t0 + tq;
                 v2 n1f[6], nf[6], ns1[6], nsl[6], s23[6], k14[6], yt[NP], n23[6];
                 v2 u3[6], u4[6], u5[6], zn[6];    // running sums of U3, U4, U5, z+   (index 2p = i_p, 2p+1 = u_p)
                 const float m2a = etd_eval(P, K, Ec, S, y, t0, L.qref, L.vdcref, n1f, ns1);      // N1
@@ -722,6 +728,7 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
                         y[g] = tsum;
                     }
                 }
+                t0 = t2;
             }
         }
         from_pairs(y, ys);
@@ -858,14 +865,16 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             prev_row = row;
             // two-rate schedule, wave-uniform (see etdrk4_full_tail)
             const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
-            const int nst = fine ? C.micro : C.micro2;
-            const float h = (float)(1.0 / 60.0) / (float)nst;
-            const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
-                     h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
+            const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
             for (int j = 0; j < nst; ++j) {
+                // graded schedule: first step 1/(60 micro), then ONE step over the remainder
+                const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
+                const float h = set == 0 ? Ec.hset[0] : (set == 1 ? Ec.hset[1] : Ec.hset[2]);
+                const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
+                         h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
-                const lds_v4 *Mq = (const lds_v4 *)Mlds + (fine ? 0 : 2 * kMatCount);
+                const lds_v4 *Mq = (const lds_v4 *)Mlds + 2 * kMatCount * set;
                 asm volatile("" : "+v"(Mq));
                 v2 n1i, n1u, ni, nu, ns1[4], ns[4], s23[4];
                 float ir2a, ir2x;
@@ -1154,6 +1163,7 @@ StepK<T> fold_cfg(const pvder_step_cfg *c) {
     StepK<T> C;
     C.n_sub = c->n_sub; C.micro = c->micro; C.max_ksub = c->max_ksub;
     C.micro2 = c->micro_coarse > 0 ? c->micro_coarse : c->micro; C.max_steps = c->max_steps;
+    C.graded = (c->graded != 0 && c->micro > 1) ? 1 : 0;
     C.goal = c->goal; C.discrete = c->discrete; C.ev_s0 = c->ev_s0; C.ev_ds = c->ev_ds;
     C.ev_count = c->ev_count;
     C.max_it = c->reserved > 0 ? c->reserved : 20000000;   // RK45: attempts per sim time step
@@ -1223,7 +1233,7 @@ void pack_m2(const M2 &M, float *o) {
     const cd e[4] = {M.a, M.b, M.c, M.d};
     for (int k = 0; k < 4; ++k) { o[2 * k] = (float)e[k].real(); o[2 * k + 1] = (float)e[k].imag(); }
 }
-EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* host, kCoefFloats, may be NULL */) {
+EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float *coef /* host, kCoefFloats, may be NULL */) {
     const double iLf = 1.0 / par[PVDER_PAR_LF];
     const cd kvi(par[PVDER_PAR_KVI_RE], par[PVDER_PAR_KVI_IM]);
     const cd Z0 = iLf * (kvi + par[PVDER_PAR_RF]) + cd(0.0, 1.0);
@@ -1237,9 +1247,11 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
     float scratch[kCoefFloats];
     float(*m)[kMatCount][kMatFloats] = reinterpret_cast<float(*)[kMatCount][kMatFloats]>(coef ? coef : scratch);
     const M2 Z{};
-    const int mic[2] = {micro, micro_coarse};
-    for (int set = 0; set < 2; ++set) {
-        const double h = 1.0 / (60.0 * mic[set]);
+    // step sizes of the schedule: first step behind a jump, coarse step, remainder of the jump's sim time step
+    const double hs[kCoefSets] = {1.0 / (60.0 * micro), 1.0 / (60.0 * micro_coarse),
+                                  (graded && micro > 1) ? (1.0 - 1.0 / micro) / 60.0 : 1.0 / (60.0 * micro)};
+    for (int set = 0; set < kCoefSets; ++set) {
+        const double h = hs[set];
         M2 ph[4], pf[4];      // phi_k(h L/2), phi_k(h L)
         for (int k = 0; k < 4; ++k) {
             ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
@@ -1264,8 +1276,9 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, float *coef /* hos
         pack_m2(lin(-h, pf[2], 4 * h, pf[3], 0, Z), m[set][EM_B4]);
         pack_m2(lin(4 * h, pf[2], -8 * h, pf[3], 0, Z), m[set][EM_B5]);
         // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
-        E.rk4_sub[set] = (4096 + mic[set] - 1) / mic[set];      // (23-state tail only)
+        E.rk4_sub[set] = (int)std::ceil(4096.0 * 60.0 * h - 1e-9);      // (23-state tail only)
         if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;
+        E.hset[set] = (float)h;
     }
     E.c0kp = (float)(c0 * kp);
     // Anti-windup switches the fast dynamics only while |m_p| > m_limit.  On a step that starts at
@@ -1357,7 +1370,7 @@ int pvder_etdrk4_coef_count(void) { return kCoefFloats; }
 
 int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, float *coef_host) {
     if (!par || !cfg || !coef_host || cfg->micro < 1) return PVDER_EINVAL;
-    make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, coef_host);
+    make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, cfg->graded, coef_host);
     return 0;
 }
 
@@ -1377,7 +1390,7 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     A.P = fold_params<float>(par, true);
     A.C = fold_cfg<float>(cfg);
     A.R = R;
-    A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, nullptr);
+    A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, cfg->graded, nullptr);
     A.force_full = 0;
     hipStream_t st = (hipStream_t)stream;
     float *acc, *clr;

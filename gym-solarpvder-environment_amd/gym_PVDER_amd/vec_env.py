@@ -28,8 +28,9 @@ SIM_TIME_STEP = 1.0 / 60.0               # env_sim_spec['sim_time_step'], PVDER_
 MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
 # integrator steps per 1/60 s sim time step (DESIGN.md "Kernels"): classic RK4 is stability-bound
 # by the current loop (h <= ~4.5 us); ETDRK4 propagates that loop exactly and is accuracy-bound
-DEFAULT_MICRO = {"etdrk4": 8, "rk4": 4096, "rk45": 1}
-# ETDRK4 two-rate schedule: sim time steps that do not start at an input jump (new action / event)
+DEFAULT_MICRO = {"etdrk4": 32, "rk4": 4096, "rk45": 1}
+# ETDRK4 step schedule: a sim time step that starts at an input jump (new action / event) takes a first
+# step of 1/(60*micro) s and one more over the remainder (graded), every other one DEFAULT_MICRO_COARSE
 DEFAULT_MICRO_COARSE = 1
 
 OBSERVED_QUANTITIES = ['iaR', 'iaI', 'vaR', 'vaI', 'P_PCC', 'Q_PCC', 'Vdc', 'Ppv', 'Vdc_ref', 'Q_ref',
@@ -129,9 +130,13 @@ class PVDERVec(EnvSpecMixin):
         integrator: 'etdrk4' (fp32 fixed-step exponential RK4, default),
                     'rk4' (fp32 fixed-step classic RK4 micro-stepping) or 'rk45' (fp64 adaptive
                     Dormand-Prince)
-        micro_steps: integrator steps per 1/60 s sim time step (default 8 / 4096)
+        micro_steps: classic RK4: steps per 1/60 s sim time step (default 4096); ETDRK4: the first step
+                    behind an input jump is 1/(60*micro_steps) s (default 32)
         micro_coarse: ETDRK4 only -- steps per sim time step that does not start at an input jump
                     (new action or event); default 1, 0 = uniform micro_steps
+        graded: ETDRK4 only -- True (default): the sim time step that starts at an input jump takes
+                    two steps, 1/(60*micro_steps) s and the remainder (the size of the first step
+                    behind a jump sets the error); False: micro_steps uniform steps
         auto_reset: reset finished envs inside ``step`` (their returned obs is the reset obs)
         model_type: 'model_2' (three phase, derId 50, the PVDER-v0 default) or 'model_1'
         seed / env_id_base: key of the on-device event generator (env_id_base = global index of
@@ -144,6 +149,7 @@ class PVDERVec(EnvSpecMixin):
                  n_sim_time_steps_per_env_step: int = 15, max_sim_time: float = 40.0,
                  DISCRETE_REWARD: bool = True, device="cuda", integrator: Optional[str] = None,
                  micro_steps: Optional[int] = None, micro_coarse: Optional[int] = None, auto_reset: bool = True,
+                 graded: bool = True,
                  model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
                  events_spec: Optional[dict] = None):
@@ -166,6 +172,9 @@ class PVDERVec(EnvSpecMixin):
         if isinstance(micro_coarse, bool) or not isinstance(micro_coarse, int) or micro_coarse < 0:
             raise ValueError("micro_coarse must be a non-negative integer")
         self.micro_coarse = int(micro_coarse)
+        if not isinstance(graded, bool):
+            raise ValueError("graded must be a bool")
+        self.graded = bool(graded) and integrator == "etdrk4" and self.micro_coarse > 0
         self.num_envs = num_envs
         self._set_n(n_sim_time_steps_per_env_step)
         self.max_sim_time_user = max_sim_time
@@ -316,6 +325,7 @@ class PVDERVec(EnvSpecMixin):
         c.n_sub = self._n
         c.micro = self.micro_steps
         c.micro_coarse = self.micro_coarse
+        c.graded = 1 if self.graded else 0
         c.max_ksub = int(math.ceil(self._max_sim_time * 60.0 - 1e-6))
         c.max_steps = self.max_episode_steps
         c.goal = GOAL_IDS[self._goals_list[0]]                 # only the first goal counts (:234)
@@ -342,7 +352,7 @@ class PVDERVec(EnvSpecMixin):
     def _etd_coef(self, cfg) -> torch.Tensor:
         """Device copy of the ETDRK4 coefficient block (host-folded in fp64 by the library), refreshed
         only when the step sizes change."""
-        key = (cfg.micro, cfg.micro_coarse)
+        key = (cfg.micro, cfg.micro_coarse, cfg.graded)
         if getattr(self, "_coef_key", None) != key:
             n = self._lib.pvder_etdrk4_coef_count()
             host = (C.c_float * n)()

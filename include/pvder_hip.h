@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 3
+#define PVDER_ABI_VERSION 4
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -85,7 +85,7 @@ enum pvder_goal { /* goals_list[0], PVDER_env.py:78-93, :234 */
 typedef struct pvder_step_cfg {
     int32_t n_sub;        /* n_sim_time_steps_per_env_step (PVDER_env.py:603-620) */
     int32_t micro;        /* integrator steps per 1/60 s sim time step (h = 1/(60*micro)): classic RK4
-                             needs ~4096 (stiff current loop), ETDRK4 8; ignored by RK45 */
+                             needs ~4096 (stiff current loop); ETDRK4: see `graded`; ignored by RK45 */
     int32_t max_ksub;     /* done when ksub >= max_ksub  (tStop >= max_sim_time, :183) */
     int32_t max_steps;    /* TimeLimit max_episode_steps (gym_PVDER/__init__.py:10); 0 = none */
     int32_t goal;         /* enum pvder_goal */
@@ -101,10 +101,13 @@ typedef struct pvder_step_cfg {
     double p_target;      /* P_ref/Sbase (:245) */
     double q_target;      /* Q_ref/Sbase (:241) */
     double rtol, atol;    /* RK45 only */
-    int32_t micro_coarse; /* ETDRK4 two-rate schedule: a sim time step that starts at an input jump (new
-                             action or new event row) takes `micro` steps, every other one
-                             `micro_coarse` (0 = same as micro).  PVDER defaults: 8 / 1 */
-    int32_t pad_;
+    int32_t micro_coarse; /* ETDRK4 step schedule: a sim time step that starts at an input jump (new
+                             action or new event row) takes `micro` uniform steps, every other one
+                             `micro_coarse` (0 = same as micro) ... */
+    int32_t graded;       /* ... or, with graded != 0, the sim time step that starts at a jump takes TWO
+                             steps: h = 1/(60*micro) -- the size of the FIRST step behind a jump is
+                             what sets the error -- then the remainder (1 - 1/micro)/60.
+                             PVDER defaults: micro 32, micro_coarse 1, graded 1 */
 } pvder_step_cfg;
 
 /* ---- event generator spec for reset (PVDER_env.py:60-61, :400-411) */
@@ -171,10 +174,11 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
                           int zero_stats, int n_env, void *stream);
 
 /* ETDRK4 coefficient block: pvder_etdrk4_coef_count() floats (phi-function matrices of the constant
- * stiff 2x2 block for the two step sizes 1/(60*micro) and 1/(60*micro_coarse), folded in fp64).
+ * stiff 2x2 block for the step sizes of the schedule -- 1/(60*micro), 1/(60*micro_coarse) and
+ * (1 - 1/micro)/60 --, folded in fp64).
  * pvder_etdrk4_coefficients() computes it on the HOST into coef_host; the caller uploads it once
  * to a device buffer and passes that buffer as `coef` to every pvder_step_etdrk4_f32() call with the
- * same par / micro / micro_coarse (kept out of the kernel-argument segment, which every workgroup
+ * same par / micro / micro_coarse / graded (kept out of the kernel-argument segment, which every workgroup
  * re-reads at launch). */
 int pvder_etdrk4_coef_count(void);
 int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, float *coef_host);

@@ -95,12 +95,12 @@ def test_rk45_f64_trajectory_vs_bridge(gpu_device):
         assert np.array_equal(rew.cpu().numpy(), r2)
 
 
-@pytest.mark.parametrize("n_sub,steps,micro,coarse", [(4, 20, 8, 1), (15, 6, 8, 1), (15, 6, 8, 0), (15, 6, 4, 1),
-                                                        (15, 6, 8, 2)])
-def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, micro, coarse):
-    """fp32 ETDRK4 vs the converged fp64 solution (C bridge RK45, rtol 1e-8): default two-rate
-    schedule (8 steps in a sim time step that starts at an input jump, 1 otherwise), uniform 8
-    (coarse = 0), and other variants."""
+@pytest.mark.parametrize("n_sub,steps,micro,coarse,graded", [(4, 20, 32, 1, True), (15, 6, 32, 1, True), (15, 6, 8, 0, False),
+                                                               (15, 6, 8, 1, True), (15, 6, 8, 2, False), (15, 6, 4, 1, False)])
+def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, micro, coarse, graded):
+    """fp32 ETDRK4 vs the converged fp64 solution (C bridge RK45, rtol 1e-8): the default schedule (a
+    sim time step that starts at an input jump takes a first step of 1/(60*32) s and one over the
+    remainder, every other one a single step), uniform 8 (coarse = 0), and other variants."""
     N = 64
     rng = np.random.default_rng(17)
     actions = rng.integers(0, 5, size=(steps, N))
@@ -108,7 +108,7 @@ def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, mic
     spec["voltage"]["t_events_start"] = spec["insolation"]["t_events_start"] = 0.2
     spec["voltage"]["t_events_step"] = 0.2
     env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator="etdrk4", micro_steps=micro,
-                   micro_coarse=coarse, seed=23, events_spec=spec, auto_reset=False)
+                   micro_coarse=coarse, graded=graded, seed=23, events_spec=spec, auto_reset=False)
     env.reset()
     vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
     ref = BridgeVecEnv(N, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11)
@@ -141,7 +141,7 @@ def test_duty_cycle_saturation_anti_windup(gpu_device):
     vdc = np.linspace(0.975, 0.99, N)
     m = pm.build_model("50")
     envs = {}
-    for integrator, micro in (("rk4", 4096), ("etdrk4", 8)):
+    for integrator, micro in (("rk4", 4096), ("etdrk4", 32)):
         env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, integrator=integrator,
                        micro_steps=micro, seed=5, auto_reset=False)
         env.reset()

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.pvder_version() == 3
+    assert L.pvder_version() == 4
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
     assert L.pvder_block_size() % 64 == 0
@@ -56,14 +56,14 @@ def test_ctypes_structs_match_header_layout(tmp_path):
                    'offsetof(pvder_step_cfg, atol), sizeof(pvder_event_spec), offsetof(pvder_event_spec, v_min),'
                    'offsetof(pvder_event_spec, s_max), (int)PVDER_PAR_COUNT, sizeof(pvder_autoreset),'
                    'offsetof(pvder_autoreset, seed), offsetof(pvder_autoreset, spec), offsetof(pvder_autoreset, y0));'
-                   'printf("%zu\\n", offsetof(pvder_step_cfg, micro_coarse));return 0;}')
+                   'printf("%zu %zu\\n", offsetof(pvder_step_cfg, micro_coarse), offsetof(pvder_step_cfg, graded));return 0;}')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     S, E, A = _native.StepCfg, _native.EventSpec, _native.AutoReset
     assert vals[:6] == [ctypes.sizeof(S), S.del_qref.offset, S.atol.offset, ctypes.sizeof(E), E.v_min.offset, E.s_max.offset]
     assert vals[7:11] == [ctypes.sizeof(A), A.seed.offset, A.spec.offset, A.y0.offset]
-    assert vals[11] == S.micro_coarse.offset
+    assert vals[11:13] == [S.micro_coarse.offset, S.graded.offset]
     from gym_PVDER_amd import der_model
     assert vals[6] == len(der_model.PAR)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Accuracy and speed of ETDRK4 step schedules (debug tool, GPU box only).
 
-For every schedule (micro / micro_coarse): max rel-L2 of the observation
+For every schedule (micro / micro_coarse / graded): max rel-L2 of the observation
 trajectory against (a) the committed goldens (converged fp64 RK45), (b) the fp64 C bridge RK45 on 64
 envs x random actions x both event types (n = 15, 6 steps and n = 4, 20 steps), (c) a full 160-step
 episode with 38 events (8 envs); and the env-steps/s of the default bench workload.
@@ -102,12 +102,12 @@ def speed(kw, N=65536, steps=2000):
     return N * steps / (time.perf_counter() - t0)
 
 
-SCHEDULES = [(8, 2), (8, 1), (8, 4), (6, 2), (4, 2), (8, 0)]
+SCHEDULES = [(16, 1, 1), (8, 1, 1), (32, 1, 1), (12, 1, 1), (8, 1, 0), (8, 0, 0)]
 if len(sys.argv) > 1:
     SCHEDULES = [tuple(int(x) for x in a.split("/")) for a in sys.argv[1:]]
 print("%-14s %10s %10s %10s %10s %10s %12s" % ("micro/coarse", "goldens", "n15x6", "n4x20", "episode", "ep last20", "env-steps/s"), flush=True)
-for m, c in SCHEDULES:
-    kw = dict(integrator="etdrk4", micro_steps=m, micro_coarse=c)
+for m, c, g in SCHEDULES:
+    kw = dict(integrator="etdrk4", micro_steps=m, micro_coarse=c, graded=bool(g))
     e_ep = episode_err(kw)
-    print("%-14s %10.2e %10.2e %10.2e %10.2e %10.2e %12.3e" % ("%d/%d" % (m, c), golden_err(kw), bridge_err(kw, 15, 6),
+    print("%-14s %10.2e %10.2e %10.2e %10.2e %10.2e %12.3e" % ("%d/%d/%s" % (m, c, "graded" if g else "uniform"), golden_err(kw), bridge_err(kw, 15, 6),
                                                                bridge_err(kw, 4, 20), e_ep[0], e_ep[1], speed(kw)), flush=True)
