@@ -858,9 +858,16 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
         // the state update needs no mask; a wave whose lanes are ALL deferred leaves
         float i2m = Ec.i2_to_m2;
         asm volatile("" : "+v"(i2m));          // keep it in a VGPR (it would be re-read from the kernarg segment every step)
+        // event row of sim time step ksub + s, tracked incrementally (event_row() is an integer division:
+        // ~40 issue slots of a lone wave, per sim time step): `until` = sim time steps to the next row change
+        int row = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count);
+        int until = 0x7fffffff;
+        if (C.ev_count > 0) {
+            const int d = L.ksub - C.ev_s0;
+            until = d < 0 ? -d : C.ev_ds - (d - (d / C.ev_ds) * C.ev_ds);
+        }
         for (int s = 0; s < C.n_sub && !__builtin_amdgcn_readfirstlane(__all((int)defer)); ++s) {
             if (s < 16) PVDER_TRACE_AT(3 + s);
-            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             const bool input_jump = row != prev_row;
             prev_row = row;
             // two-rate schedule, wave-uniform (see etdrk4_full_tail)
@@ -932,6 +939,11 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 // near duty-cycle saturation or the current limit: the 23-state path redoes this env step
                 defer |= fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
                 ia = zi; ua = zu; xa = xn; pa = vn; pb = qn; dl = dn;
+            }
+            {   // branch-free (a per-lane branch here costs an exec-mask save in an SGPR-starved kernel)
+                const bool chg = --until == 0;
+                row += (chg && row < C.ev_count) ? 1 : 0;
+                until = chg ? C.ev_ds : until;
             }
         }
         if (!defer) {
