@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--graded", type=int, default=1,
                     help="ETDRK4: 1 = two steps (first + remainder) in a sim time step that starts at a jump, 0 = micro uniform steps")
     ap.add_argument("--micro-coarse", type=int, default=None,
-                    help="ETDRK4: steps per sim time step that does not start at an input jump (default 2)")
+                    help="ETDRK4: steps per sim time step that does not start at an input jump (default 1)")
     ap.add_argument("--integrator", default="etdrk4", choices=["etdrk4", "rk4", "rk45"])
     ap.add_argument("--classic-steps", type=int, default=3, help="classic-RK4 steps timed beside the main run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
@@ -284,8 +284,8 @@ def main():
         bytes_step = 533 if args.integrator == "rk45" else BYTES_PER_ENV_STEP_F32
         achieved = bytes_step * N / avg_kern_s
         fps = FLOP_PER_STEP.get(args.integrator, 0)
-        # integrator steps per env step: ETDRK4's two-rate schedule takes `micro` steps in the sim time
-        # steps that start at an input jump (the first of each env step + one event per second)
+        # integrator steps per env step: a sim time step that starts at an input jump (the first of each
+        # env step + one event per second) takes 2 steps (graded) or `micro` uniform ones, the others micro_coarse
         if args.integrator == "etdrk4":
             n_fine = 1.0 + (args.n_sub - 1) / 60.0
             steps_per_env_step = n_fine * (2 if env.graded else args.micro) + (args.n_sub - n_fine) * env.micro_coarse \
