@@ -117,10 +117,21 @@ __device__ __forceinline__ int event_row(int g, int s0, int ds, int K) {
     return j > K ? K : j;
 }
 
-// ---- wave64 all-reduce sum by butterfly shuffles (no LDS allocation, no barrier)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- wave64 sum, total in lane 63, by DPP row operations (quad swaps, half-row / row mirror, then
+// row_bcast:15 / row_bcast:31 across the four rows): six VALU instructions with DPP operands -- no
+// LDS crossbar round trips (six dependent ds_bpermute of __shfl_xor cost a lone wave ~0.3 us per sum)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);        // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);        // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);       // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);       // row_mirror: every lane holds its row's sum
+    v = dpp_add<0x142, 0xA>(v);       // row_bcast:15 into rows 1, 3
+    v = dpp_add<0x143, 0xC>(v);       // row_bcast:31 into rows 2, 3: lane 63 holds the wave's sum
     return v;
 }
 
@@ -218,6 +229,9 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
     T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
     pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
     T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc);
+#ifdef PVDER_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 32 + 22] = wall_clock64() + (reward > (T)1e30 ? 1 : 0);
+#endif
     T chk = (T)0;
 #pragma unroll
     for (int q = 0; q < NS; ++q) chk += fabs(y[q]);
@@ -261,17 +275,18 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
         out[PVDER_O_REWARD * N + e] = reward;
         out[PVDER_O_DONE * N + e] = (T)done_f;
     }
+    PVDER_TRACE_AT(23);
     // ---- statistics: wave-level butterfly reduction, the 4 waves of the workgroup combined through
     // LDS, then ONE atomic per workgroup and statistic (same-address float atomics serialise at the
     // memory side, ~12 ns each: 256 instead of 1024 of them per statistic)
     if (stats) {
         __shared__ float wsum[4][kBlock / 64];
-        const float r = wave_sum(L.run ? (float)reward : 0.f);
-        const float d = wave_sum(done_f);
-        const float nf = wave_sum(nonfinite);
-        const float ba = wave_sum(L.live ? L.bad_action : 0.f);
+        const float r = wave_sum_to_lane63(L.run ? (float)reward : 0.f);
+        const float d = wave_sum_to_lane63(done_f);
+        const float nf = wave_sum_to_lane63(nonfinite);
+        const float ba = wave_sum_to_lane63(L.live ? L.bad_action : 0.f);
         const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { wsum[0][w] = r; wsum[1][w] = d; wsum[2][w] = nf; wsum[3][w] = ba; }
+        if ((threadIdx.x & 63) == 63) { wsum[0][w] = r; wsum[1][w] = d; wsum[2][w] = nf; wsum[3][w] = ba; }
         __syncthreads();
         if (threadIdx.x < 4) {
             float t = 0.f;

@@ -7,7 +7,7 @@ workgroups of the 100 MHz wall clock relative to the earliest workgroup's kernel
 HIP-event duration of the same launch.
 
   slot 0 entry | 1 coefficients staged in LDS | 2 state loads landed | 3+s start of sim time step s |
-  20 integration done | 21 epilogue stores issued
+  20 integration done | 22 outputs and reward computed | 23 stores issued | 21 statistics reduced, end
 """
 import ctypes as C
 import os
@@ -65,8 +65,8 @@ def main():
         evs.append(e0.elapsed_time(e1) * 1e3)
     R = np.stack(rows)                     # [launch, block, slot]
     print("N=%d blocks=%d   event-timed step (both launches) median %.1f us" % (N, nblk, float(np.median(evs))))
-    names = {0: "entry", 1: "lds staged", 2: "state loaded", 20: "integration done", 21: "epilogue issued"}
-    for s in [0, 1, 2] + list(range(3, 18)) + [20, 21]:
+    names = {0: "entry", 1: "lds staged", 2: "state loaded", 20: "integration done", 22: "outputs+reward done", 23: "stores issued", 21: "epilogue issued"}
+    for s in [0, 1, 2] + list(range(3, 18)) + [20, 22, 23, 21]:
         x = R[:, :, s]
         print("slot %2d %-18s min %6.2f  med %6.2f  p90 %6.2f  max %6.2f us" % (
             s, names.get(s, "sub-step %d" % (s - 3)), np.median(x.min(1)), np.median(np.median(x, 1)),
