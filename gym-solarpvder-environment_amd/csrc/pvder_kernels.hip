@@ -234,13 +234,10 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
                                          T *y, T *__restrict__ fstate, int32_t *__restrict__ istate,
                                          float *__restrict__ ev_vg, float *__restrict__ ev_si,
                                          T *__restrict__ out, float *__restrict__ stats, int n_env,
-                                         float *__restrict__ stats_clear = nullptr) {
+                                         int stats_fresh = 0) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     const int ec = L.ec;
-    // ping-pong statistics: this launch accumulates into `stats` and clears the OTHER bank for the
-    // next launch (nobody writes that bank now; the kernel boundary orders the clear before its use)
-    if (stats_clear && blockIdx.x == 0 && threadIdx.x < 4) stats_clear[threadIdx.x] = 0.f;
     SubK<T, PH> S;
     {
         const int row = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count);
@@ -296,9 +293,11 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
         st(&out[PVDER_O_DONE * N + e], (T)done_f);
     }
     PVDER_TRACE_AT(23);
-    // ---- statistics: wave-level butterfly reduction, the 4 waves of the workgroup combined through
-    // LDS, then ONE atomic per workgroup and statistic (same-address float atomics serialise at the
-    // memory side, ~12 ns each: 256 instead of 1024 of them per statistic)
+    // ---- statistics: DPP wave reduction, the 4 waves of the workgroup combined through LDS, then ONE
+    // plain store per statistic into THIS workgroup's slot stats[4*blockIdx.x + k] -- no atomics: 256
+    // workgroups finishing together on four same-address float atomics (~10 ns each, serialised at the
+    // memory side) held every launch back by 2.7 us.  stats_fresh: overwrite the slot (first launch
+    // of an env step) or add to it (a follow-up launch / the 23-state tail of the same step).
     if (stats) {
         __shared__ float wsum[4][kBlock / 64];
         const float r = wave_sum_to_lane63(L.run ? (float)reward : 0.f);
@@ -312,7 +311,8 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < kBlock / 64; ++k) t += wsum[threadIdx.x][k];
-            if (t != 0.f) atomicAdd(&stats[threadIdx.x], t);
+            float *slot = stats + 4 * (size_t)blockIdx.x + threadIdx.x;
+            *slot = stats_fresh ? t : *slot + t;
         }
     }
 }
@@ -324,7 +324,7 @@ template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
     const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
     float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
-    T *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear,
+    T *__restrict__ out, float *__restrict__ stats, int n_env, int stats_fresh,
     int run_status) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    epilogue<T, PH>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
+    epilogue<T, PH>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
 }
 
 // ---- packed pair layout <-> pvder state order
@@ -425,7 +425,7 @@ __device__ __forceinline__ void rk4_pk_steps(const ModelK<float> &P, const pvder
 __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
     const ModelK<float> P, const StepK<float> C, const ResetK R, float *__restrict__ fstate,
     int32_t *__restrict__ istate, float *__restrict__ ev_vg, float *__restrict__ ev_si,
-    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
+    const uint8_t *__restrict__ action, float *__restrict__ out, float *__restrict__ stats, int n_env, int stats_fresh) {
     constexpr int NS = 23, NP = pvder::NP;
     const size_t N = (size_t)n_env;
     Lane<float> L;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
 }
 
 // =============================================================================================
@@ -502,7 +502,8 @@ struct EtdArgs {
     float *ev_vg, *ev_si;
     const uint8_t *action;
     float *out;
-    float *stats, *stats_clear;
+    float *stats;
+    int stats_fresh;         // 1: this launch starts the step's statistics (overwrites its slots), 0: adds
     int n_env;
     int force_full;          // A/B and tests: every env takes the 23-state path
 };
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
     const uint8_t *__restrict__ action = A.action;
     float *__restrict__ out = A.out;
     float *__restrict__ stats = A.stats;
-    float *__restrict__ stats_clear = A.stats_clear;
+    const int stats_fresh = A.stats_fresh;
     const int n_env = A.n_env;
     constexpr int NS = 6 * PH + 5, B = 6 * PH;      // PH = 1: the single-phase model is this reduction itself
     const size_t N = (size_t)n_env;
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
         L.run = false;
         L.live = false;
     }
-    epilogue<float, PH>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
+    epilogue<float, PH>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
     PVDER_TRACE_AT(21);
     if constexpr (PH == 3) {
         // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the
@@ -1027,7 +1028,7 @@ template <typename T, int PH>
 __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
     const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
     float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
-    T *__restrict__ out, T *__restrict__ hstep, float *__restrict__ stats, int n_env, float *__restrict__ stats_clear) {
+    T *__restrict__ out, T *__restrict__ hstep, float *__restrict__ stats, int n_env, int stats_fresh) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     Lane<T> L;
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
     const bool ran = L.run;
     // no in-kernel auto-reset here: this kernel sits at the 256-VGPR + AGPR limit; the launcher
     // enqueues reset_kernel<..., true> (reset where status != 0) right behind it instead
-    epilogue<T, PH, false>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_clear);
+    epilogue<T, PH, false>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
     if (ran) hstep[L.e] = (L.status != 0) ? (T)0 : hn;       // a finished env restarts the controller
 }
 
@@ -1244,18 +1245,6 @@ int check_common(const double *par, const pvder_step_cfg *cfg, int n_env) {
 }
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
-
-// zero_stats: 0 accumulate into stats[0..3]; 1 memset stats[0..3] first; 2 / 3 ping-pong over an
-// 8-float buffer: accumulate into bank 0 / 1 (stats[0..3] / stats[4..7]) and let the kernel clear the
-// other bank for the next launch (no memset node on the stream)
-int stats_setup(float *stats, int zero_stats, hipStream_t st, float *&acc, float *&clr) {
-    acc = stats; clr = nullptr;
-    if (!stats) return 0;
-    if (zero_stats == 1) return hip_rc(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
-    if (zero_stats == 2) { acc = stats; clr = stats + 4; }
-    if (zero_stats == 3) { acc = stats + 4; clr = stats; }
-    return 0;
-}
 
 // ---- ETDRK4 coefficient matrices: functions of the constant 2x2 complex Lz, by the Lagrange
 // (Sylvester) formula  f(L) = f(l1)(L - l2 I)/(l1-l2) + f(l2)(L - l1 I)/(l2-l1)   (fp64, host)
@@ -1395,21 +1384,20 @@ int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder
     const ModelK<float> P = fold_params<float>(par, true);
     const StepK<float> C = fold_cfg<float>(cfg);
     hipStream_t st = (hipStream_t)stream;
-    float *acc, *clr;
-    rc = stats_setup(stats, zero_stats, st, acc, clr);
-    if (rc) return rc;
+    float *acc = stats;
+    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     // PVDER_RK4_VARIANT=generic selects the un-packed template (A/B runs); default = packed kernel
     static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
     if (ph == 3 && !generic)
         hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si, action,
-                           out, acc, n_env, clr);
+                           out, acc, n_env, fresh);
     else if (ph == 3)
         hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, clr, 0);
+                           action, out, acc, n_env, fresh, 0);
     else
         hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, clr, 0);
+                           action, out, acc, n_env, fresh, 0);
     return hip_rc(hipGetLastError());
 }
 
@@ -1440,11 +1428,10 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
     A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, cfg->graded, nullptr);
     A.force_full = 0;
     hipStream_t st = (hipStream_t)stream;
-    float *acc, *clr;
-    rc = stats_setup(stats, zero_stats, st, acc, clr);
-    if (rc) return rc;
+    float *acc = stats;
+    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
     A.coef = coef; A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
-    A.action = action; A.out = out; A.stats = acc; A.stats_clear = clr; A.n_env = n_env;
+    A.action = action; A.out = out; A.stats = acc; A.stats_fresh = fresh; A.n_env = n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     // Three-phase: ONE launch -- the balanced fast path, whose workgroups run the 23-state path
     // themselves for the envs they must defer (unbalanced state or duty cycle near its limit; none in
@@ -1458,7 +1445,7 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
         StepK<float> C4 = A.C;
         C4.micro = 8192;
         hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, A.P, C4, A.R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, (float *)nullptr, (int)kDeferred);
+                           action, out, acc, n_env, 0, (int)kDeferred);
     } else {
         A.force_full = full_only ? 1 : 0;
         hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
@@ -1480,16 +1467,15 @@ int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvde
     const ModelK<double> P = fold_params<double>(par, false);
     const StepK<double> C = fold_cfg<double>(cfg);
     hipStream_t st = (hipStream_t)stream;
-    float *acc, *clr;
-    rc = stats_setup(stats, zero_stats, st, acc, clr);
-    if (rc) return rc;
+    float *acc = stats;
+    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     if (ph == 3)
         hipLaunchKernelGGL((step_rk45_kernel<double, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, hstep, acc, n_env, clr);
+                           action, out, hstep, acc, n_env, fresh);
     else
         hipLaunchKernelGGL((step_rk45_kernel<double, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, hstep, acc, n_env, clr);
+                           action, out, hstep, acc, n_env, fresh);
     if (R.enabled) {      // same-step auto-reset as a second pass (see step_rk45_kernel)
         if (ph == 3)
             hipLaunchKernelGGL((reset_kernel<double, 3, true>), grid, block, 0, st, P, R, fstate, istate, ev_vg,

@@ -204,8 +204,9 @@ class PVDERVec(EnvSpecMixin):
         self.fstate = torch.zeros((self.ns + 2, N), dtype=self.fdtype, device=self.device)
         self.istate = torch.zeros((4, N), dtype=torch.int32, device=self.device)
         self.out = torch.zeros((13, N), dtype=self.fdtype, device=self.device)
-        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)    # two banks (ping-pong)
-        self._bank = 0
+        # per-workgroup partial statistics of the last step ([n_wg, 4]; summed on demand by step_stats)
+        n_wg = (num_envs + self._lib.pvder_block_size() - 1) // self._lib.pvder_block_size()
+        self.stats = torch.zeros((n_wg, 4), dtype=torch.float32, device=self.device)
         self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator == "rk45" else None
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
@@ -432,9 +433,7 @@ class PVDERVec(EnvSpecMixin):
                 ev0.record()          # same stream the kernel is launched on (torch's current stream)
             # ONE launch: action -> integrate -> reward/done/obs -> same-step auto-reset of finished
             # envs (their obs rows hold the reset observation, reward/done rows the ended transition)
-            # statistics: accumulate into bank `_bank`, the kernel clears the other one for the next step
-            self._bank ^= 1
-            zs = 2 + self._bank
+            zs = 1            # statistics: every workgroup overwrites its slot (no atomics, nothing to clear)
             if self.integrator == "etdrk4":
                 rc = self._lib.pvder_step_etdrk4_f32(*a[:3], self._etd_coef(cfg).data_ptr(), *a[3:],
                                                      self.stats.data_ptr(), zs, self.num_envs, self._stream())
@@ -456,16 +455,15 @@ class PVDERVec(EnvSpecMixin):
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,
         #invalid actions -- the batched counterpart of update_reward_stats (env_utilities.py:32-38)."""
-        s = self.stats[4 * self._bank: 4 * self._bank + 4].tolist()
+        s = self.stats.sum(dim=0, dtype=torch.float64).tolist()
         return {"reward_sum": s[0], "n_done": int(s[1]), "n_nonfinite": int(s[2]), "n_bad_action": int(s[3])}
 
     # -- checkpoint / resume (the reference has none: reset() rebuilds the sim) ----
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Everything a bit-exact resume needs: ODE states + refs, counters, event tables, RK45 step
-        sizes and the statistics banks (clones, safe to torch.save)."""
+        sizes and the per-workgroup statistics (clones, safe to torch.save)."""
         d = {"fstate": self.fstate.clone(), "istate": self.istate.clone(), "ev_vg": self.ev_vg.clone(),
-             "ev_si": self.ev_si.clone(), "out": self.out.clone(), "stats": self.stats.clone(),
-             "bank": torch.tensor(self._bank)}
+             "ev_si": self.ev_si.clone(), "out": self.out.clone(), "stats": self.stats.clone()}
         if self.hstep is not None:
             d["hstep"] = self.hstep.clone()
         return d
@@ -479,7 +477,6 @@ class PVDERVec(EnvSpecMixin):
             t.copy_(d[k])
         if self.hstep is not None:
             self.hstep.copy_(d["hstep"])
-        self._bank = int(d["bank"])
         self._needs_reset = False
 
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------

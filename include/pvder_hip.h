@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 4
+#define PVDER_ABI_VERSION 5
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -155,12 +155,11 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
  *   Envs whose status != 0 on entry are not advanced (stale tuple, :145-152).
  *   ar (may be NULL): when ar->enabled, envs that finish in this step are reset in the same
  *     launch: obs rows = reset observation, reward/done rows = the transition that ended.
- *   stats (device, may be NULL): [0] sum of rewards, [1] #done, [2] #non-finite, [3] #invalid
- *     actions -- wave-level reduction + one atomic per wave.  zero_stats: 0 = accumulate into
- *     stats[0..3]; 1 = enqueue a memset of stats[0..3] first; 2 / 3 = ping-pong over an 8-float
- *     buffer: accumulate into stats[0..3] / stats[4..7] while the kernel clears the other bank for
- *     the next launch (alternate 2, 3, 2, ... and no memset is ever enqueued; the bank that is
- *     accumulated into must have been cleared by the previous launch or by the caller).
+ *   stats (device, may be NULL): float[4 * n_wg], n_wg = ceil(n_env / pvder_block_size()): slot
+ *     [4*g + k] holds workgroup g's partial of [k=0] sum of rewards, [1] #done, [2] #non-finite,
+ *     [3] #invalid actions (wave-level reduction, one plain store per workgroup and statistic, no
+ *     atomics); the caller sums the n_wg slots when it wants the totals.  zero_stats != 0: this
+ *     call starts the statistics of an env step (every slot is overwritten); 0: it adds to them.
  *
  * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (explicit exponential Runge-Kutta method of stiff
  *   order 4: Hochbruck & Ostermann 2005, five stages): the stiff filter-current/controller pair of

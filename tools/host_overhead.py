@@ -43,7 +43,7 @@ env2 = PVDERVec(256, device=dev, seed=1, auto_reset=True); env2.reset()
 cfg2, ar2 = env2._cfg(), env2._autoreset(True)
 a2 = torch.zeros(256, dtype=torch.uint8, device=dev)
 args2 = (env2._par_c, C.byref(cfg2), C.byref(ar2), env2._etd_coef(cfg2).data_ptr(), env2.fstate.data_ptr(), env2.istate.data_ptr(),
-         env2.ev_vg.data_ptr(), env2.ev_si.data_ptr(), a2.data_ptr(), env2.out.data_ptr(), env2.stats.data_ptr(), 2, 256, env2._stream())
+         env2.ev_vg.data_ptr(), env2.ev_si.data_ptr(), a2.data_ptr(), env2.out.data_ptr(), env2.stats.data_ptr(), 1, 256, env2._stream())
 print("C call alone, 256 envs %.2f us" % t(lambda: env2._lib.pvder_step_etdrk4_f32(*args2), 200))
 print("step() 256 envs        %.2f us" % t(lambda: env2.step(a2, return_tensors=False), 200))
 k = [0]
