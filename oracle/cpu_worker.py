@@ -13,6 +13,8 @@ def run(seed: int, seconds: float) -> float:
     from oracle.pvder_oracle_env import OraclePVDER
     env = OraclePVDER(solver="reference", seed=seed)      # PVDER-v0 defaults, voltage events on
     env.reset()
+    env.step(0)               # untimed: the first step builds the analytic Jacobian (sympy -> lambdify, one-off;
+    env.reset()               # tens of seconds on a box whose page cache is cold)
     rng = np.random.default_rng(seed)
     n, used = 0, 0.0
     while used < seconds:
