@@ -1280,14 +1280,18 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float 
     const cd disc = std::sqrt(tr * tr - 4.0 * det);
     const cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
     EtdK E;
-    float scratch[kCoefFloats];
-    float(*m)[kMatCount][kMatFloats] = reinterpret_cast<float(*)[kMatCount][kMatFloats]>(coef ? coef : scratch);
+    float(*m)[kMatCount][kMatFloats] = reinterpret_cast<float(*)[kMatCount][kMatFloats]>(coef);
     const M2 Z{};
     // step sizes of the schedule: first step behind a jump, coarse step, remainder of the jump's sim time step
     const double hs[kCoefSets] = {1.0 / (60.0 * micro), 1.0 / (60.0 * micro_coarse),
                                   (graded && micro > 1) ? (1.0 - 1.0 / micro) / 60.0 : 1.0 / (60.0 * micro)};
     for (int set = 0; set < kCoefSets; ++set) {
         const double h = hs[set];
+        E.rk4_sub[set] = (int)std::ceil(4096.0 * 60.0 * h - 1e-9);      // (23-state tail only)
+        if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;
+        E.hset[set] = (float)h;
+        if (!coef) continue;              // per-launch call: only the scalars are needed (the phi matrices
+                                          // cost ~3 us of complex exponentials; they live in the caller's buffer)
         M2 ph[4], pf[4];      // phi_k(h L/2), phi_k(h L)
         for (int k = 0; k < 4; ++k) {
             ph[k] = fun2(L, l1, l2, phi(k, 0.5 * h * l1), phi(k, 0.5 * h * l2));
@@ -1312,9 +1316,6 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float 
         pack_m2(lin(-h, pf[2], 4 * h, pf[3], 0, Z), m[set][EM_B4]);
         pack_m2(lin(4 * h, pf[2], -8 * h, pf[3], 0, Z), m[set][EM_B5]);
         // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
-        E.rk4_sub[set] = (int)std::ceil(4096.0 * 60.0 * h - 1e-9);      // (23-state tail only)
-        if (E.rk4_sub[set] < 1) E.rk4_sub[set] = 1;
-        E.hset[set] = (float)h;
     }
     E.c0kp = (float)(c0 * kp);
     // Anti-windup switches the fast dynamics only while |m_p| > m_limit.  On a step that starts at

@@ -11,6 +11,7 @@ buffers, validates arguments and launches.  There is no CPU fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 import ctypes as C
 import logging
@@ -198,6 +199,8 @@ class PVDERVec(EnvSpecMixin):
         if self.device.type != "cuda":
             raise RuntimeError("PVDERVec runs on a ROCm GPU only (device=%s); there is no CPU path" % device)
         self._lib = _native.lib()
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.fdtype = torch.float64 if integrator == "rk45" else torch.float32
         N = num_envs
         self._alloc_event_tables()
@@ -362,6 +365,12 @@ class PVDERVec(EnvSpecMixin):
             self._coef_key = key
         return self._coef
 
+    def _device_ctx(self):
+        """``torch.cuda.device(self.device)``, or nothing when it is the current device already."""
+        if torch.cuda.current_device() == self.device.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -422,7 +431,7 @@ class PVDERVec(EnvSpecMixin):
         cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
         a = (self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
              self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr())
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             timed = False
             if self._timing:
                 self._timing_k += 1
