@@ -453,17 +453,21 @@ __global__ __launch_bounds__(kBlock) void step_rk4_pk_kernel(
 }
 
 // =============================================================================================
-// ETDRK4 (Krogstad 2005): exponential time differencing for the stiff current loop.
+// ETDRK4: explicit exponential Runge-Kutta integration with the stiff current loop in the exponential.
 //
 // Per phase the pair z_p = (i_p, u_p) obeys  dz_p/dt = Lz z_p + N_p(y)  with the CONSTANT complex
 // 2x2 matrix  Lz = [[-Z0, c0 Kp_GCC], [-wp, -wp]]  (Z0 = (kvi+Rf)/Lf + j, c0 = Vdc_ref0/(2 Lf)):
 // its eigenvalues -1e5 +- j5.8e5 1/s are what forces classic RK4 down to h ~ 4 us.  Everything
-// else (x_p, Vdc, xDC, xQ, xPLL, delta: poles <= 90 1/s) has Lz = 0, for which ETDRK4 *is* classic
-// RK4.  With  N_i = cm x + D + (cm-c0) Kp_GCC u - j (winv/wbase - 1) i,  N_u = wp iref_p  the scheme
-//   U2 = E2 z + P1 N1;   U3 = E2 z + A1 N1 + A2 N2;   U4 = E z + B1 N1 + B3 N3
-//   z+ = E z + C1 N1 + C2 (N2+N3) + C4 N4
+// else (x_p, Vdc, xDC, xQ, xPLL, delta: poles <= 90 1/s) has Lz = 0.  With
+// N_i = cm x + D + (cm-c0) Kp_GCC u - j (winv/wbase - 1) i,  N_u = wp iref_p  the scheme of
+// Hochbruck & Ostermann (SIAM J. Numer. Anal. 43, 2005, eq. 5.19; 5 stages, c = 0, 1/2, 1/2, 1, 1/2;
+// stiff order 4 -- Krogstad's 4-stage ETDRK4, used first, lost order on this slaved fast block)
+//   U2 = E2 z + A21 N1;   U3 = E2 z + A31 N1 + A32 N2;   U4 = E z + A41 N1 + A42 (N2+N3)
+//   U5 = E2 z + A51 N1 + A52 (N2+N3) + A54 N4;           z+ = E z + B1 N1 + B4 N4 + B5 N5
 // propagates the fast loop exactly (E = exp(h Lz), phi-function matrices folded on the host in
-// fp64) and h is set by the slow dynamics: 8 steps per 1/60 s instead of 4096.
+// fp64); for the Lz = 0 states the same tableau is a 5-stage 4th-order Runge-Kutta method,
+// y+ = y + h (N1 + N4)/6 + 2h N5/3.  h is set by the slow dynamics: 16 steps per env step (n = 15)
+// instead of 61 440 (DESIGN.md "Step schedule").
 // While a duty cycle is near its limit the conditional-integration anti-windup changes the fast
 // dynamics; such (rare) steps are redone by classic RK4 micro-steps from the saved state.
 // =============================================================================================
