@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--integrator", default="etdrk4", choices=["etdrk4", "rk4", "rk45"])
     ap.add_argument("--classic-steps", type=int, default=3, help="classic-RK4 steps timed beside the main run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
-    ap.add_argument("--time-every", type=int, default=16,
+    ap.add_argument("--time-every", type=int, default=64,
                     help="bracket every K-th step kernel with HIP events (roofline.kernel_avg_ms); 0 = none")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: all-gather issued directly into RCCL (default) or through torch.distributed")
