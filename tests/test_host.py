@@ -171,3 +171,58 @@ def test_no_step_kernel_reads_the_dispatch_packet(tmp_path):
         # turned into VGPR lanes (no scratch instruction in the kernel; measured: no effect on throughput)
         assert private_seg <= 32, (name, "uses scratch", private_seg)
         assert not props & 0x2, (name, "ENABLE_SGPR_DISPATCH_PTR")
+
+
+def test_etdrk4_coefficient_block_matches_independent_phi_functions():
+    """pvder_etdrk4_coefficients (host code, no GPU): the 3 x 13 complex 2x2 matrices of the 5-stage
+    Hochbruck-Ostermann scheme against an independent evaluation -- phi functions of h*Lz from
+    scipy.linalg.expm on the augmented matrix -- plus the scheme's own consistency conditions."""
+    import torch  # noqa: F401
+    from scipy.linalg import expm
+    from gym_PVDER_amd import _native, der_model
+    L_ = _native.lib() if os.path.exists(_native.LIB_PATH) else ctypes.CDLL(_native.build_native())
+    par = der_model.param_vector("50")
+    P = der_model.IDX
+    iLf = 1.0 / par[P["LF"]]
+    kvi = complex(par[P["KVI_RE"]], par[P["KVI_IM"]])
+    Z0 = iLf * (kvi + par[P["RF"]]) + 1j
+    c0 = iLf * par[P["VDC_REF0"]] / 2.0
+    Lz = np.array([[-Z0, c0 * par[P["KP_GCC"]]], [-par[P["WP"]], -par[P["WP"]]]], dtype=complex)
+
+    def phis(h):                       # phi_0..phi_3 of h*Lz
+        out = [expm(h * Lz)]
+        for k in (1, 2, 3):
+            M = np.zeros((2 * (k + 1), 2 * (k + 1)), dtype=complex)
+            M[:2, :2] = h * Lz
+            for j in range(k):
+                M[2 * j:2 * j + 2, 2 * j + 2:2 * j + 4] = np.eye(2)
+            out.append(expm(M)[:2, 2 * k:2 * k + 2])
+        return out
+
+    micro, coarse = 32, 1
+    cfg = _native.StepCfg()
+    cfg.n_sub, cfg.micro, cfg.micro_coarse, cfg.graded = 15, micro, coarse, 1
+    n = L_.pvder_etdrk4_coef_count()
+    assert n == 3 * 13 * 8
+    host = (ctypes.c_float * n)()
+    par_c = (ctypes.c_double * len(par))(*par)
+    assert L_.pvder_etdrk4_coefficients(par_c, ctypes.byref(cfg), host) == 0
+    got = np.array(list(host), dtype=np.float64).reshape(3, 13, 4, 2)
+    got = got[..., 0] + 1j * got[..., 1]                                   # [set, matrix, entry 11,12,21,22]
+    for s, h in enumerate((1.0 / (60 * micro), 1.0 / (60 * coarse), (1.0 - 1.0 / micro) / 60.0)):
+        f, g = phis(h), phis(h / 2)                                        # phi_k(hL), phi_k(hL/2)
+        a52 = 0.5 * g[2] - f[3] + 0.25 * f[2] - 0.5 * g[3]
+        a54 = 0.25 * g[2] - a52
+        a51 = 0.5 * g[1] - 2 * a52 - a54
+        want = [g[0], f[0], 0.5 * h * g[1], h * (0.5 * g[1] - g[2]), h * (f[1] - 2 * f[2]), h * a51,
+                h * (f[1] - 3 * f[2] + 4 * f[3]), h * g[2], h * f[2], h * a52, h * a54,
+                h * (-f[2] + 4 * f[3]), h * (4 * f[2] - 8 * f[3])]      # order of the EM_* enum in pvder_kernels.hip
+        for k, W in enumerate(want):
+            w = W.reshape(4)
+            assert np.abs(got[s, k] - w).max() <= 2e-6 * max(np.abs(w).max(), 1e-12) + 1e-12, (s, k)
+        # consistency of the tableau: sum_j a_ij = c_i phi_1(c_i h L) h, sum_j b_j = h phi_1(h L)
+        G = got[s].reshape(13, 2, 2)
+        assert np.abs(G[3] + G[7] - 0.5 * h * g[1]).max() < 1e-6 * h                     # a31 + a32
+        assert np.abs(G[4] + 2 * G[8] - h * f[1]).max() < 1e-6 * h                       # a41 + a42 + a43
+        assert np.abs(G[5] + 2 * G[9] + G[10] - 0.5 * h * g[1]).max() < 1e-6 * h         # a51 + 2 a52 + a54
+        assert np.abs(G[6] + G[11] + G[12] - h * f[1]).max() < 1e-6 * h                  # b1 + b4 + b5
