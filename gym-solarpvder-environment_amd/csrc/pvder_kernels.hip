@@ -43,7 +43,10 @@ using pvder::ModelK;
 using pvder::SubK;
 using pvder::v2;
 
-constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
+#ifndef PVDER_BLOCK
+#define PVDER_BLOCK 256
+#endif
+constexpr int kBlock = PVDER_BLOCK;   // 4 waves: one per SIMD of a CU
 constexpr int kDeferred = -1; // transient istate status (single-phase ETDRK4 only): "advance me in the follow-up launch"
 
 template <typename T>
