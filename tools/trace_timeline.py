@@ -63,6 +63,18 @@ def main():
         t0 = t[:, 0].min()
         rows.append((t - t0) * 0.01)      # us
         evs.append(e0.elapsed_time(e1) * 1e3)
+    if os.environ.get("PVDER_TRACE_BURST"):
+        # steady state: a burst of un-synchronised launches, the trace of the LAST one only
+        rows, evs = [], []
+        for rep in range(10):
+            for i in range(340, 400):
+                env.step(acts[i], return_tensors=False)
+            torch.cuda.synchronize()
+            rc = L.pvder_debug_trace(buf.ctypes.data, buf.size)
+            assert rc == 0, rc
+            t = buf.reshape(4096, 32)[:nblk].astype(np.int64)
+            rows.append((t - t[:, 0].min()) * 0.01)
+            evs.append(float("nan"))
     R = np.stack(rows)                     # [launch, block, slot]
     print("N=%d blocks=%d   event-timed step (both launches) median %.1f us" % (N, nblk, float(np.median(evs))))
     names = {0: "entry", 1: "lds staged", 2: "state loaded", 20: "integration done", 22: "outputs+reward done", 23: "stores issued", 21: "epilogue issued"}
