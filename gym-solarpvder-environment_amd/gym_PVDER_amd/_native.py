@@ -64,11 +64,17 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())          # build aside, then rename: never a half-written library
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC, "-o", LIB_PATH] + srcs
+           "-I" + INCLUDE, "-I" + CSRC, "-o", tmp] + srcs
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
