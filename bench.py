@@ -4,23 +4,28 @@
 Workload (BASELINE.json configs[2], the configuration the north_star target is quoted on; with
 --gpus N it is the per-GPU shard of configs[3] = weak scaling): 65 536 parallel PVDER-v0 envs per
 GPU, PVDER-v0 default kwargs (n = 15 sim time steps of 1/60 s per env step, discrete
-voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32 fixed-step
-4th-order Runge-Kutta, uniform random actions resident on the device, same-step auto-reset.
-Default integrator: ETDRK4 (exponential Runge-Kutta of stiff order 4, Hochbruck-Ostermann's 5-stage
-scheme: the stiff current loop is propagated exactly; a sim time step that starts at an input jump --
-new action / event -- takes a first step of 1/1920 s and one over the remainder, every other one 1 step); the classic-RK4 kernel (4096 micro-steps per sim time step,
-the literal "fixed-step RK4" of BASELINE configs[1-3]) is timed in the same run and reported under
-"classic_rk4".  Both meet the 1e-4 rel-L2 parity bar against the fp64 oracle (tests/, -m gpu).
-A "step" is one batched env transition (one fused HIP launch over all local envs); for N > 1 each
-step ends with ONE RCCL all-gather of the [13, N_local] output block (11 obs + reward + done).
+voltage_regulation reward), grid-voltage AND insolation perturbation events on, fp32, uniform random
+actions resident on the device, same-step auto-reset.  A "step" is one batched env transition (one
+fused HIP launch over all local envs); for N > 1 each step ends with ONE RCCL all-gather of the
+[13, N_local] output block (11 obs + reward + done).
 
-Prints ONE JSON line on rank 0.  `value` counts env transitions of all ranks / max-over-ranks time.
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (fresh child
+processes, one per GPU, before this process makes any GPU call) and relays rank 0's line; under
+`python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
+
+Prints ONE JSON line on rank 0.  `value` counts env transitions of all ranks / max-over-ranks time of
+exactly --steps steps; `sustained` repeats the measurement over >= 1 s of steps in the same process
+(a 20-step window is 0.5 ms of GPU time); `roofline` prices the step kernel's algorithmic bytes
+against HBM, `valu_roofline` its flops against the fp32 vector peak (the roof that binds this path).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,21 +34,19 @@ sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
 sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: -4 us per launch
-import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12                 # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
-BYTES_PER_ENV_STEP_F32 = 269      # 116 B read + 153 B written, three-phase fp32
-# flop per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
-FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907}     # etdrk4: balanced fast path, 5-stage scheme (23-state tail: ~2700)
-# instructions per integrator step of the same loops (one wave per SIMD at 65 536 envs: the loop is
-# bound by the single-wave issue rate, tools/issue_probe.hip: 2.25-2.5 ns per independent instruction)
+VALU_PEAK_F64 = 78.6e12           # FLOP/s, MI355X_MICROARCH.md "Peak FP64 (vector)"
+BYTES_PER_ENV_STEP = {"f32": 269, "f64": 533}      # three-phase, carried words + obs + reward + done
+# flop / instructions per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
+FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907}
 INSTR_PER_STEP = {"etdrk4": 396}
 DEFAULT_MICRO = {"etdrk4": 32, "rk4": 4096, "rk45": 1}
 KERNEL_NAME = {"etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel", "rk45": "step_rk45_kernel<double,3>"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
@@ -60,14 +63,79 @@ def parse():
     ap.add_argument("--classic-steps", type=int, default=3, help="classic-RK4 steps timed beside the main run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--time-every", type=int, default=64,
-                    help="bracket every K-th step kernel with HIP events (roofline.kernel_avg_ms); 0 = none")
+                    help="bracket every K-th step kernel with HIP events (clamped so that even a short run gets samples); 0 = none")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0,
+                    help="length of the sustained leg that follows the --steps window (0 = skip)")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: all-gather issued directly into RCCL (default) or through torch.distributed")
     ap.add_argument("--sync-gather", type=int, default=0,
                     help="1: wait for each step's all-gather before the next step (no compute/comm overlap)")
-    return ap.parse_args()
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the rank launcher: every rank joins a gloo group, rank 0 prints ranks_seen")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------
+# rank launcher: `python bench.py --gpus N` outside torchrun
+# ---------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start n fresh child processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), relay
+    their output (rank 0 prints the JSON line), return the worst exit code.  The parent makes no GPU
+    call: a process that has initialised the GPU must not be replaced or forked into ranks."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PVDER_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:            # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def selftest_rank():
+    """--selftest-launcher: what a rank does, minus the GPU (gloo all-reduce of the rank ids)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.zeros(world, dtype=torch.int64)
+    t[rank] = 1
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.sum())}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------
+# measurement helpers
+# ---------------------------------------------------------------------------------------------------
 def events_on_spec():
     from gym_PVDER_amd.vec_env import default_events_spec
     s = default_events_spec()
@@ -89,7 +157,6 @@ def cpu_baseline_all_cores(seconds: float):
     """BASELINE.md plan: one oracle env per process on every host core (the reference itself is
     single-threaded; this is the most its CPU path can do on this box).  Plain child processes,
     started before this process touches the GPU."""
-    import subprocess
     # the GPU box gives one GPU's job a 16-core CPU share (os.cpu_count() reports the whole host)
     n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py")]
@@ -102,7 +169,7 @@ def cpu_baseline_all_cores(seconds: float):
             "sample": "%d processes x 1 env, %.1f s of CPU each, same settings as cpu_baseline" % (n, seconds)}
 
 
-def classic_rk4_leg(dev, N, n_sub, steps):
+def classic_rk4_leg(torch, dev, N, n_sub, steps):
     """The literal fixed-step classic RK4 kernel (4096 micro-steps per 1/60 s) on the same workload."""
     from gym_PVDER_amd.vec_env import PVDERVec
     env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, integrator="rk4", seed=2024,
@@ -124,32 +191,63 @@ def classic_rk4_leg(dev, N, n_sub, steps):
     fl = FLOP_PER_STEP["rk4"] * 4096 * n_sub * N / avg
     return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "micro_steps": 4096,
             "kernel": KERNEL_NAME["rk4"], "kernel_avg_ms": avg * 1e3,
-            "valu_frac": fl / VALU_PEAK_F32, "hbm_frac": BYTES_PER_ENV_STEP_F32 * N / avg / HBM_PEAK}
+            "valu_frac": fl / VALU_PEAK_F32, "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / avg / HBM_PEAK}
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: a PMC summary under profiles/ is only valid for the code it
+    was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gym-solarpvder-environment_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "pvder_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel, n_env):
-    """HBM bytes per launch from the committed PMC pass (separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes); PMC counters
-    cannot be read from inside the timed process, so the newest summary under profiles/ is reported,
-    or null when it does not match this kernel / size."""
+    """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes; PMC counters
+    cannot be read from inside the timed process).  Only a summary stamped with the hash of the
+    kernel sources it was measured on counts: anything else -- stale code, other kernel, other size
+    -- reports null."""
     import glob
+    sha = kernel_source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if d.get("kernel") == kernel and int(d.get("envs", -1)) == n_env:
-                return float(d["traffic_bytes_per_launch"])
+            if (d.get("kernel") == kernel and int(d.get("envs", -1)) == n_env
+                    and d.get("kernel_src_sha") == sha):
+                return float(d["traffic_bytes_per_launch"]), os.path.basename(f)
         except Exception:
             continue
-    return None
+    return None, None
 
 
-def main():
-    args = parse()
+def finite(x):
+    """JSON has no NaN/Infinity: unusable numbers become null."""
+    return x if (x is not None and x == x and abs(x) != float("inf")) else None
+
+
+def sample_period(time_every: int, steps: int) -> int:
+    """Every how many launches a step kernel is bracketed with HIP events: the requested period,
+    clamped so that even the shortest run records >= 4 samples (an event pair costs ~9 us of stream
+    time, so short runs are not bracketed on every launch either)."""
+    if time_every <= 0:
+        return 0
+    return max(1, min(time_every, steps // 4 if steps < 256 else steps // 8))
+
+
+# ---------------------------------------------------------------------------------------------------
+def run_rank(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if local_rank == 0:              # before anything touches the GPU (hipcc is a child process)
-        from gym_PVDER_amd import _native
+    warnings = []
+    if local_rank == 0 and os.environ.get("PVDER_BENCH_CHILD") != "1":   # (the self-launcher built it already)
+        from gym_PVDER_amd import _native        # before anything touches the GPU (hipcc is a child process)
         _native.build_native()       # no-op when the in-tree library is up to date (never a fallback: same HIP code)
     dist = None
     if world > 1 or os.environ.get("PVDER_BENCH_FORCE_DIST") == "1":   # (forced: exercises RCCL at world 1)
@@ -160,10 +258,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = world
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        warnings.append("--gpus %d but WORLD_SIZE %d: measured %d rank(s)" % (args.gpus, world, world))
+        if rank == 0:
+            print("bench.py: warning: " + warnings[-1], file=sys.stderr)
     # CPU legs first: they start child processes, which must happen before this process touches the GPU
     cpu = {}
     if world == 1 and dist is None and args.cpu_seconds > 0:
@@ -176,20 +275,25 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    ranks_seen = 1
     if dist is not None:
-        dist.barrier()               # rank 0 has (re)built the library, see the top of main()
+        dist.barrier()               # rank 0 has (re)built the library, see above
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)        # through RCCL: how many GPUs really take part
+        ranks_seen = int(seen.item())
     from gym_PVDER_amd.vec_env import PVDERVec
     N = args.envs
     if args.micro is None:
         args.micro = DEFAULT_MICRO[args.integrator]
     env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=args.n_sub, micro_steps=args.micro,
-                   micro_coarse=args.micro_coarse, graded=bool(args.graded), integrator=args.integrator, seed=2024, env_id_base=rank * N, events_spec=events_on_spec(),
-                   auto_reset=True)
+                   micro_coarse=args.micro_coarse, graded=bool(args.graded), integrator=args.integrator, seed=2024,
+                   env_id_base=rank * N, events_spec=events_on_spec(), auto_reset=True)
     env.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     total = args.warmup + args.steps
-    actions = torch.randint(0, 5, (total, N), generator=gen, device=dev, dtype=torch.uint8)
+    pool = max(total, 4096) if args.sustained_seconds > 0 else total    # the sustained leg cycles through the pool
+    actions = torch.randint(0, 5, (pool, N), generator=gen, device=dev, dtype=torch.uint8)
     # ONE collective per step (RCCL over xGMI): all-gather of the [13, N_local] output block.  It is
     # double-buffered and asynchronous: the gather of step t runs on its own stream while the step
     # kernel of t+1 computes (the rollout does not consume the collated block before the next
@@ -223,25 +327,28 @@ def main():
         if direct is None:
             stage = [torch.empty_like(env.out) for _ in range(2)]
 
-    def one_step(i):
+    def one_step(i, gather=True):
         b = i & 1
+        a = actions[i % pool]
+        if dist is None or not gather:
+            env.step(a, return_tensors=False)           # results land in env.out ([13, N])
+            return
         if direct is not None:
             if pending[b] is not None:
                 torch.cuda.current_stream(dev).wait_event(pending[b])    # gather t-2 has read this block
             env.use_out(outs[b])
-            env.step(actions[i], return_tensors=False)                   # results land in outs[b] ([13, N])
+            env.step(a, return_tensors=False)                            # results land in outs[b] ([13, N])
             pending[b] = direct.launch(outs[b], gathered[b], done_ev[b])
             if args.sync_gather:
                 torch.cuda.current_stream(dev).wait_event(pending[b])
             return
-        env.step(actions[i], return_tensors=False)      # results land in env.out ([13, N])
-        if dist is not None:
-            if pending[b] is not None:
-                pending[b].wait()                        # stream dependency only, no host block
-            stage[b].copy_(env.out)                      # 3.4 MB device copy: frees env.out for step t+1
-            pending[b] = dist.all_gather_into_tensor(gathered[b], stage[b], async_op=True)
-            if args.sync_gather:
-                pending[b].wait()
+        env.step(a, return_tensors=False)
+        if pending[b] is not None:
+            pending[b].wait()                        # stream dependency only, no host block
+        stage[b].copy_(env.out)                      # 3.4 MB device copy: frees env.out for step t+1
+        pending[b] = dist.all_gather_into_tensor(gathered[b], stage[b], async_op=True)
+        if args.sync_gather:
+            pending[b].wait()
 
     def drain():
         if dist is not None:
@@ -253,36 +360,75 @@ def main():
                         pending[b].wait()
                     pending[b] = None
 
+    def timed(first, count, every, gather=True):
+        """`count` steps starting at action row `first`, bracketed by barrier + synchronize on both
+        sides; returns (max-over-ranks seconds, host enqueue seconds, per-launch event samples in ms,
+        ms per step by ONE HIP-event pair around the whole region on the launch stream)."""
+        env.kernel_timing(every > 0, max(1, every))
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        r0.record()
+        for i in range(first, first + count):
+            one_step(i, gather)
+        if gather:
+            drain()
+        r1.record()
+        host = time.perf_counter() - t0        # host side of the loop (launches are asynchronous)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        k = env.kernel_times_ms()
+        env.kernel_timing(False)
+        return el, host, k, r0.elapsed_time(r1) / count
+
     for i in range(args.warmup):
         one_step(i)
     drain()
-    env.kernel_timing(args.time_every > 0, max(1, args.time_every))
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        one_step(i)
-    drain()
-    host_enqueue = time.perf_counter() - t0        # host side of the loop (launches are asynchronous)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kern_ms = env.kernel_times_ms()
+    every = sample_period(args.time_every, args.steps)
+    elapsed, host_enqueue, kern_ms, region_ms = timed(args.warmup, args.steps, every)
     st = env.step_stats()
 
+    # sustained leg: the same loop for >= sustained_seconds (a 20-step window is 0.5 ms of GPU time)
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = int(min(400000, max(args.steps, args.sustained_seconds / max(elapsed / args.steps, 1e-7))))
+        el_s, host_s, k_s, region_s = timed(total, n_sus, sample_period(max(args.time_every, 1), n_sus))
+        sustained = {"value": world * N * n_sus / el_s, "unit": "env-steps/s", "steps": n_sus, "seconds": el_s,
+                     "ms_per_step": 1e3 * el_s / n_sus, "host_enqueue_ms_per_step": 1e3 * host_s / n_sus,
+                     "kernel_avg_ms": finite(sum(k_s) / len(k_s)) if k_s else None, "kernel_samples": len(k_s),
+                     "region_ms_per_step": region_s}
+    compute_only = None
+    if dist is not None:        # the same steps without the collective: what the gather costs
+        el_c, host_c, _, _ = timed(total, args.steps, 0, gather=False)
+        compute_only = {"value": world * N * args.steps / el_c, "unit": "env-steps/s", "steps": args.steps,
+                        "ms_per_step": 1e3 * el_c / args.steps, "host_enqueue_ms_per_step": 1e3 * host_c / args.steps}
+
     if rank == 0:
+        prec = "f64" if args.integrator == "rk45" else "f32"
         value = world * N * args.steps / elapsed
-        avg_kern_s = (sum(kern_ms) / len(kern_ms)) * 1e-3 if kern_ms else float("nan")
-        bytes_step = 533 if args.integrator == "rk45" else BYTES_PER_ENV_STEP_F32
-        achieved = bytes_step * N / avg_kern_s
+        ms_per_step = 1e3 * elapsed / args.steps
+        # kernel duration: per-launch HIP-event samples of THIS window; a window too short to hold any
+        # falls back to the sustained leg's samples (same process, same config) and says so
+        src = "hip events around %d of the %d timed launches" % (len(kern_ms), args.steps)
+        if not kern_ms and sustained and sustained["kernel_avg_ms"]:
+            kern_ms = [sustained["kernel_avg_ms"]]
+            src = "hip events in the sustained leg (%d samples)" % sustained["kernel_samples"]
+        avg_kern_s = (sum(kern_ms) / len(kern_ms)) * 1e-3 if kern_ms else None
+        bytes_step = BYTES_PER_ENV_STEP[prec]
+        achieved = bytes_step * N / avg_kern_s if avg_kern_s else None
+        if avg_kern_s and world == 1 and avg_kern_s * 1e3 > ms_per_step * 1.15:
+            warnings.append("kernel_avg_ms %.4f > 1.15 x ms_per_step %.4f: the event-bracketed launches run slower "
+                            "than the un-bracketed step period" % (avg_kern_s * 1e3, ms_per_step))
         fps = FLOP_PER_STEP.get(args.integrator, 0)
         # integrator steps per env step: a sim time step that starts at an input jump (the first of each
         # env step + one event per second) takes 2 steps (graded) or `micro` uniform ones, the others micro_coarse
@@ -292,13 +438,15 @@ def main():
                 if env.micro_coarse > 0 else args.micro * args.n_sub
         else:
             steps_per_env_step = args.micro * args.n_sub
-        flops = fps * steps_per_env_step * N / avg_kern_s
+        flops = fps * steps_per_env_step * N / avg_kern_s if (fps and avg_kern_s) else None
+        traffic, traffic_src = pmc_traffic(KERNEL_NAME[args.integrator], N)
+        valu_peak = VALU_PEAK_F64 if prec == "f64" else VALU_PEAK_F32
         out = {
             "metric": "env-steps/sec (batched PVDER-v0)", "value": value, "unit": "env-steps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
+            "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.integrator == "rk45" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]" if (N, args.n_sub) == (65536, 15) else "variant of BASELINE configs[2]") +
                                    ": %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
@@ -313,29 +461,69 @@ def main():
                        "collective": ("all-gather of the [13, N_local] fp32 block per step: %s; %s"
                                       % (collective, "synchronous" if args.sync_gather else "overlapped with the next step"))
                        if dist is not None else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(KERNEL_NAME[args.integrator], N),
+            "roofline": {"bound": "hbm", "achieved": finite(achieved / 1e9) if achieved else None, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": finite(achieved / HBM_PEAK) if achieved else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL_NAME[args.integrator],
-                         "kernel_avg_ms": avg_kern_s * 1e3, "algorithmic_bytes_per_env_step": bytes_step},
-            # the binding roof of this path is the fp32 VALU, not HBM
-            "valu_roofline": {"bound": "valu_f32", "achieved": flops / 1e12, "peak": VALU_PEAK_F32 / 1e12,
-                              "unit": "TFLOP/s", "frac": flops / VALU_PEAK_F32,
+                         "kernel_avg_ms": finite(avg_kern_s * 1e3) if avg_kern_s else None,
+                         "kernel_avg_source": src, "kernel_samples": len(kern_ms),
+                         "region_ms_per_step": finite(region_ms),
+                         "algorithmic_bytes_per_env_step": bytes_step, "kernel_src_sha": kernel_source_hash()},
+            # the binding roof of this path is the vector ALU, not HBM
+            "valu_roofline": {"bound": "valu_" + prec, "achieved": finite(flops / 1e12), "peak": valu_peak / 1e12,
+                              "unit": "TFLOP/s", "frac": finite(flops / valu_peak),
                               "flop_per_integrator_step": fps,
                               "integrator_steps_per_env_step": steps_per_env_step,
                               "instr_per_integrator_step": INSTR_PER_STEP.get(args.integrator),
                               "ns_per_instr_per_wave": (avg_kern_s * 1e9 / (steps_per_env_step * INSTR_PER_STEP[args.integrator])
-                                                        if args.integrator in INSTR_PER_STEP else None)} if fps else None,
+                                                        if args.integrator in INSTR_PER_STEP else None)} if flops else None,
+            "sustained": sustained,
+            "ranks_seen": ranks_seen,
             "last_step_stats": st,
         }
+        if dist is not None:
+            # what the collective must move and the bound xGMI puts on it (MI355X_MICROARCH.md: 7 links x
+            # ~153 GB/s bidirectional per GPU, i.e. ~77 GB/s into a GPU per link, all peers in parallel)
+            blk = 13 * N * 4
+            out["compute_only"] = compute_only
+            out["xgmi_bound"] = {"bytes_received_per_step_per_gpu": (world - 1) * blk,
+                                 "link_GBps_one_direction": 76.5,
+                                 "min_us_per_step": blk / 76.5e9 * 1e6 if world > 1 else 0.0,
+                                 "note": "each peer's block arrives over its own link (fully connected mesh): the "
+                                         "gather of one step cannot finish faster than one block over one link"}
         if world == 1 and args.classic_steps > 0 and args.integrator == "etdrk4":
-            out["classic_rk4"] = classic_rk4_leg(dev, N, args.n_sub, args.classic_steps)
+            out["classic_rk4"] = classic_rk4_leg(torch, dev, N, args.n_sub, args.classic_steps)
         out.update(cpu)
-        print(json.dumps(out))
+        if warnings:
+            out["warnings"] = warnings
+        print(json.dumps(out, allow_nan=False))
     if dist is not None:
         if direct is not None:
             direct.close()
         dist.destroy_process_group()
 
 
+def main():
+    args = parse()
+    in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.selftest_launcher:
+        if in_group:
+            selftest_rank()
+            return 0
+        return launch_ranks(max(1, args.gpus), sys.argv[1:])
+    if not in_group and args.gpus > 1:
+        # outside torchrun: start the ranks ourselves -- BEFORE this process makes any GPU call
+        import torch
+        have = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+        if have < args.gpus:
+            print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+            return 2
+        from gym_PVDER_amd import _native
+        _native.build_native()                      # once, by the parent (hipcc is a child process)
+        return launch_ranks(args.gpus, sys.argv[1:])
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,65 @@
+"""CPU tests (-m "not gpu") of bench.py's host logic: the rank launcher, the kernel-timing sampling
+period, JSON hygiene and the PMC-summary stamp.  No compute call, no GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_launcher_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` outside torchrun must run TWO ranks (it ran one and
+    printed n_gpus 1).  The selftest does what a rank does minus the GPU: gloo group of WORLD_SIZE."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+
+
+def test_launcher_propagates_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    code = "import sys, os, bench; sys.exit(bench.launch_ranks(2, ['--definitely-not-an-option']))"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode != 0
+
+
+@pytest.mark.parametrize("steps,every,lo,hi", [(20, 64, 4, 20), (5, 64, 4, 5), (1, 64, 1, 1), (4000, 64, 62, 63),
+                                                (100, 64, 4, 100), (300, 64, 8, 300)])
+def test_every_run_records_kernel_samples(steps, every, lo, hi):
+    """the driver's 5 + 20 steps recorded zero samples at --time-every 64 -> NaN."""
+    p = bench.sample_period(every, steps)
+    assert p >= 1
+    n = steps // p
+    assert lo <= n <= hi, (p, n)
+    assert bench.sample_period(0, steps) == 0
+
+
+def test_json_line_never_carries_nan():
+    assert bench.finite(float("nan")) is None and bench.finite(float("inf")) is None and bench.finite(None) is None
+    assert bench.finite(0.25) == 0.25
+    with pytest.raises(ValueError):
+        json.dumps({"x": float("nan")}, allow_nan=False)
+
+
+def test_pmc_summary_counts_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    sha = bench.kernel_source_hash()
+    assert len(sha) == 16
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: sha)
+    (prof / "r09_pmc_x_traffic.json").write_text(json.dumps(
+        {"kernel": "k", "envs": 8, "traffic_bytes_per_launch": 123.0, "kernel_src_sha": "stale"}))
+    assert bench.pmc_traffic("k", 8) == (None, None)
+    (prof / "r10_pmc_x_traffic.json").write_text(json.dumps(
+        {"kernel": "k", "envs": 8, "traffic_bytes_per_launch": 456.0, "kernel_src_sha": sha}))
+    assert bench.pmc_traffic("k", 8) == (456.0, "r10_pmc_x_traffic.json")
+    assert bench.pmc_traffic("k", 16) == (None, None)

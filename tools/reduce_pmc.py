@@ -12,7 +12,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "step_etdrk4_bal_kernel"
+sys.path.insert(0, ROOT)
+KERNEL = os.environ.get("PVDER_PMC_KERNEL", "step_etdrk4_bal_kernel")
 ENVS = 65536
 ALGO_BYTES = 269 * ENVS
 
@@ -47,6 +48,7 @@ def main():
     rd, wr = fkb * 1024 * 2, wkb * 1024
     out = {
         "kernel": KERNEL, "envs": ENVS,
+        "kernel_src_sha": __import__("bench").kernel_source_hash(),   # bench.py reports this traffic only for the same sources
         "command_fetch": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py " + bargs,
         "command_write": "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py " + bargs,
         "command_stats": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py " + bargs,
