@@ -4,12 +4,16 @@
 // SGPRs (kernel argument); the whole env transition
 //     action_calc -> integrate n_sub sim time steps -> reward_calc -> done -> state [-> auto-reset]
 // (PVDER_env.py:138-196, :198-229, :231-301, :531-542, :316-334) is ONE launch with the 23 states
-// held in registers for the entire step; wave-level reduction + one atomic per wave for the
-// reward-sum / done-count statistics (env_utilities.py:32-38 aggregate).
+// held in registers for the entire step; wave-level (DPP) reduction of the reward-sum / done-count
+// statistics into one plain store per workgroup and statistic, no atomics (env_utilities.py:32-38
+// aggregate).
 //
-// Integrators (fixed per launch, selected by the entry point):
-//   step_etdrk4_bal_kernel<PH> fp32 exponential-time-differencing RK4 (Krogstad): the stiff current
-//                              loop (i_p,u_p) is propagated exactly, everything else is classic RK4;
+// Integrators (fixed per launch, selected by the entry point / plan):
+//   step_etdlin_kernel<PH>     fp32 ETD3RK (Cox-Matthews) on dy/dt = L y + N(y), L = the full 11x11
+//                              Jacobian at the nominal operating point: two steps per env step;
+//                              balanced 11-state fast path + 23-state tail in ONE launch (default)
+//   step_etdrk4_bal_kernel<PH> fp32 exponential Runge-Kutta method of stiff order 4 (Hochbruck-Ostermann,
+//                              5 stages): only the stiff current loop (i_p,u_p) is in the exponential;
 //                              balanced 11-state fast path + 23-state tail (etdrk4_full_tail) in ONE launch
 //   step_rk4_pk_kernel   fp32  classic RK4 micro-stepping, packed-VALU three-phase form
 //   step_rk4_kernel<T,PH>      classic RK4 micro-stepping, generic (single phase / A-B reference)
@@ -21,10 +25,12 @@
 #include <math.h>
 #include <stdlib.h>
 #include <complex>
+#include <new>
 
 #include "pvder_hip.h"
 #include "pvder_model.hpp"
 #include "pvder_model_pk.hpp"
+#include "pvder_etdlin.hpp"
 
 namespace {
 // Debug-only in-kernel timeline (tools/trace_timeline.py builds a separate library with
@@ -217,6 +223,9 @@ __device__ __forceinline__ void prologue(const StepK<T> &C, const T *__restrict_
     else if (a == 3) L.vdcref += C.dv;
     else if (a == 4) L.vdcref -= C.dv;
     else if (a != 0) L.bad_action = 1.f;
+    // a follow-up launch (run_status != 0) counts invalid actions only for the lanes it advances: the
+    // launch that handed them over has counted everyone else already
+    if (run_status != 0 && !L.run) L.bad_action = 0.f;
 }
 
 template <typename T>
@@ -1029,6 +1038,274 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
 }
 
 // =============================================================================================
+// etdlin: linearised exponential integrator, balanced fast path (pvder_etdlin.hpp).  Same frame as
+// step_etdrk4_bal_kernel -- balance check on entry, 11 of 23 states integrated, phases b/c written
+// back by rotation, envs near a limit or whose embedded error indicator trips are left untouched
+// and advanced by the 23-state path at the end of the kernel -- but the integrator is ETD3RK on
+// dy/dt = L y + N(y) with L the FULL 11x11 Jacobian at the nominal operating point: the exponential
+// carries the whole linear response, so a segment between two input jumps (new action, new event
+// row) takes a first step of one tick = 1/(60*micro) s and then the LARGEST steps of the launch's
+// coefficient sets that fit -- for PVDER-v0 (events on env-step boundaries) two steps per env step.
+//
+// The step schedule is PER LANE (each env's own jump positions, its own coefficient set: LDS reads
+// with per-lane addresses, a broadcast while the envs of a wave run in lockstep); only the trip
+// count is wave-uniform (lanes that have arrived idle), so an env's trajectory does not depend on
+// which envs share its wave.
+// =============================================================================================
+struct LinK {
+    const float *lcoef;              // device: tick matrix (kLinMatFloats) + (n_sets-1) * kLinSetFloats floats
+    int n_sets;
+    int len_ticks[pvder::kLinMaxSets];   // step length of set s in ticks; set 0 = the tick behind a jump (exponential
+                                     // Euler, one matrix), sets 1.. = ETD3RK sets sorted by decreasing length
+    float est_refine;                // an ETD3RK step whose indicator max |y+ - b| over (i_a, Vdc) exceeds this is
+                                     // redone as two steps of half the length (once) ...
+    int setmask;                     // ... if both halves of the set are in the menu.  Bits per set s (fill_plan):
+                                     // bit s: length = whole sim time steps; bit 8+s: one tick short of that (usable
+                                     // while the env is one tick behind a boundary); neither: a half, used only for
+                                     // redoing a rejected step; bit 16+s: both halves of set s are in the menu
+    float est_guard;                 // a step accepted above this hands the env to the 23-state path
+};
+struct LinArgs {
+    EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
+    LinK Lk;
+};
+
+template <int PH>
+__global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
+    using namespace pvder;
+    const EtdArgs &A = G.A;
+    const ModelK<float> &P = A.P;
+    const StepK<float> &C = A.C;
+    const ResetK &R = A.R;
+    const EtdK &Ec = A.Ec;
+    float *__restrict__ fstate = A.fstate;
+    int32_t *__restrict__ istate = A.istate;
+    float *__restrict__ ev_vg = A.ev_vg;
+    float *__restrict__ ev_si = A.ev_si;
+    const uint8_t *__restrict__ action = A.action;
+    float *__restrict__ out = A.out;
+    float *__restrict__ stats = A.stats;
+    const int stats_fresh = A.stats_fresh;
+    const int n_env = A.n_env;
+    constexpr int NS = 6 * PH + 5, B = 6 * PH;
+    constexpr int kBig = 0x3fffffff;
+    const size_t N = (size_t)n_env;
+    PVDER_TRACE_AT(0);
+    // coefficient block: staged once per launch (16-byte loads), re-read every step with ds_read_b128.
+    // The step lengths too: eight more wave-uniform values do not fit the scalar register file next to
+    // the model constants (unused entries hold INT_MAX, see fill_plan).
+    __shared__ __attribute__((aligned(16))) float Llds[kLinMatFloats + (kLinMaxSets - 1) * kLinSetFloats];
+    __shared__ __attribute__((aligned(16))) int Llen[kLinMaxSets];
+    // the state rows first: their loads are in flight while the block is staged
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
+    {
+        const int nv4 = (kLinMatFloats + (G.Lk.n_sets - 1) * kLinSetFloats) / 4;
+        const v4 *src = (const v4 *)G.Lk.lcoef;
+        for (int k = threadIdx.x; k < nv4; k += kBlock) ((v4 *)Llds)[k] = src[k];
+        if (threadIdx.x < kLinMaxSets) Llen[threadIdx.x] = G.Lk.len_ticks[threadIdx.x];
+    }
+    __syncthreads();
+    PVDER_TRACE_AT(1);
+    bool defer = PH == 3 && A.force_full != 0;
+    if (L.run) {
+        v2 y[6] = {mk2(ys[0], ys[1]), mk2(ys[2], ys[3]), mk2(ys[4], ys[5]), mk2(ys[B], ys[B + 1]),
+                   mk2(ys[B + 2], ys[B + 3]), mk2(ys[B + 4], 0.f)};
+        if constexpr (PH == 3) {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
+            const float ei = unbalance2(y[0], mk2(ys[6], ys[7]), mk2(ys[12], ys[13]));
+            const float ex = unbalance2(y[1], mk2(ys[8], ys[9]), mk2(ys[14], ys[15]));
+            const float eu = unbalance2(y[2], mk2(ys[10], ys[11]), mk2(ys[16], ys[17]));
+            const v2 i2 = y[0] * y[0], x2 = y[1] * y[1];
+            defer |= ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
+        }
+        const PkConst K = make_pkconst(P);
+        // outer-loop gains pinned to SGPRs (see step_etdrk4_bal_kernel: the dispatch-packet trap)
+        float g_kpdc = P.KpDC, g_kpq = -P.KpQ, g_kidc = P.KiDC, g_kiq = -P.KiQ;
+        asm volatile("" : "+s"(g_kpdc), "+s"(g_kpq), "+s"(g_kidc), "+s"(g_kiq));
+        const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
+        float i2m = Ec.i2_to_m2;
+        asm volatile("" : "+v"(i2m));
+        // ---- per-lane schedule, in ticks of 1/(60*micro) s.  One integer division per launch gives the
+        // event row in force at ksub, whether an event starts exactly there, and `until` = sim time steps
+        // from the start of the current segment to the next event-row change.
+        const int micro = C.micro;
+        const int end = C.n_sub * micro;
+        int row = 0, until = kBig;
+        bool evjump = false;                 // the current segment starts at an EVENT (not just a new action)
+        if (C.ev_count > 0) {
+            const int d = L.ksub - C.ev_s0;
+            if (d < 0) {
+                until = -d;
+            } else {
+                const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
+                row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
+                evjump = rd == 0 && qd < C.ev_count;
+                until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
+            }
+        }
+        int pos = 0, seg_end = 0, spos = 0, cap = kBig;
+        bool behind = false;
+        SubPk S;
+        PVDER_TRACE_AT(2);
+        for (int it = 0;; ++it) {
+            const bool active = pos < end;
+            if (!__builtin_amdgcn_readfirstlane(__any((int)(active && !defer)))) break;
+            if (it < 16) PVDER_TRACE_AT(3 + it);
+            typedef int i4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) const i4 lds_ci4;
+            const lds_ci4 *lt = (const lds_ci4 *)Llen;
+            asm volatile("" : "+v"(lt));
+            const i4 l0 = lt[0], l1 = lt[1];
+            const int lens[kLinMaxSets] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            v2 F[6];
+            float m2a, ir2a;
+            const bool newseg = active && pos == seg_end;
+            if (__builtin_amdgcn_readfirstlane(__any((int)newseg))) {
+                // ---- a segment starts (new action at pos 0, or a new event row): inputs, then the TICK
+                if (newseg) {
+                    if (pos > 0) {                       // an event row starts here
+                        row += 1;
+                        until = row < C.ev_count ? C.ev_ds : kBig;
+                        evjump = true;
+                    }
+                    const int left = C.n_sub - spos;
+                    const int seg = until < left ? until : left;
+                    until -= seg;
+                    spos += seg;
+                    seg_end = pos + seg * micro;
+                    cap = kBig;
+                }
+                // (lanes that stay in their segment re-read the row they have: same values)
+                make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
+                // the tick behind the jump: exponential Euler, y+ = y + h phi1(hL) f(y).  The jump kicks the
+                // stiff loop; the exponential carries that transient exactly, and over one tick the rest of
+                // f hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  An EVENT may
+                // make |m| overshoot inside the tick: 3 % clearance there (see make_etd).
+                const lds_cv4 *tk = (const lds_cv4 *)Llds;
+                asm volatile("" : "+v"(tk));
+                bal_f<PH>(P, K, S, y, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
+                v2 acc1[1][6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc1[0][q] = y[q];
+                const int m1[1] = {0};
+                lin_matvec<1>(tk, m1, F, acc1);
+                const v2 mn = fma2(bc2(P.KpG), acc1[0][2], acc1[0][1]);
+                const float guard = evjump ? Ec.sat2_event : Ec.sat2_smooth;
+                const bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+                if (newseg) {
+                    defer |= trip;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) y[q] = acc1[0][q];
+                    pos += lens[0];
+                    evjump = false;
+                    behind = true;                        // one tick past a sim-time-step boundary
+                }
+            }
+            // ---- ETD3RK in f-form with the largest step that fits the segment (and the cap a rejected
+            // step left behind)
+            const bool stepping = pos < seg_end;          // (a segment of one tick is finished already)
+            const int rem = seg_end - pos;
+            const int lim = rem < cap ? rem : cap;
+            int sidx = 1, len = 0;
+            const int sm = G.Lk.setmask;
+#pragma unroll
+            for (int s = kLinMaxSets - 1; s >= 1; --s) {        // largest eligible length (sets sorted by decreasing length)
+                const bool whole = (sm >> s) & 1, short1 = (sm >> (8 + s)) & 1;
+                const bool ok = whole || (short1 && behind) || (!whole && !short1 && cap != kBig);
+                if (lens[s] <= lim && ok) { sidx = s; len = lens[s]; }
+            }
+            const lds_cv4 *set = (const lds_cv4 *)(Llds + kLinMatFloats) + (sidx - 1) * (kLinSetFloats / 4);
+            asm volatile("" : "+v"(set));
+            float m2x, ir2x, m2b;
+            bal_f<PH>(P, K, S, y, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
+            v2 acc3[3][6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { acc3[0][q] = y[q]; acc3[1][q] = y[q]; acc3[2][q] = y[q]; }
+            {
+                const int m3[3] = {LM21, LM31, LM41};
+                lin_matvec<3>(set, m3, F, acc3);                      // a = y + M21 F1; b, y+ started
+            }
+            bal_f<PH>(P, K, S, acc3[0], L.qref, L.vdcref, kpo, kio, F, m2x, ir2x);
+            v2 acc2[2][6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { acc2[0][q] = acc3[1][q]; acc2[1][q] = acc3[2][q]; }
+            {
+                const int m2[2] = {LM32, LM42};
+                lin_matvec<2>(set, m2, F, acc2);                      // b complete
+            }
+            bal_f<PH>(P, K, S, acc2[0], L.qref, L.vdcref, kpo, kio, F, m2b, ir2x);
+            v2 acc1[1][6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc1[0][q] = acc2[1][q];
+            {
+                const int m1[1] = {LM43};
+                lin_matvec<1>(set, m1, F, acc1);                      // y+
+            }
+            // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
+            const v2 di = acc1[0][0] - acc2[0][0];
+            const float est = fmaxf(fmaxf(fabsf(di.x), fabsf(di.y)), fabsf(acc1[0][3].x - acc2[0][3].x));
+            const v2 mn = fma2(bc2(P.KpG), acc1[0][2], acc1[0][1]);
+            // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
+            const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+            const bool trip = fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
+            // a step whose indicator is too large is redone as two of half the length -- once
+            const bool retry = cap == kBig && est > G.Lk.est_refine && ((sm >> (16 + sidx)) & 1) != 0;
+            if (stepping) {
+                if (len == 0) {
+                    defer = true;                         // (a menu that cannot tile this segment: 23-state path)
+                } else if (retry) {
+                    cap = (len + 1) >> 1;
+                } else {
+                    defer |= trip;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) y[q] = acc1[0][q];
+                    pos += len;
+                    if ((sm >> (8 + sidx)) & 1) behind = false;      // back on a sim-time-step boundary
+                }
+            }
+        }
+        if (!defer) {
+            const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ys[2 * k] = y[k].x; ys[2 * k + 1] = y[k].y;
+                if constexpr (PH == 3) {
+                    const v2 hz = bc2(-0.5f) * y[k], jz = swp(y[k]) * jh3;
+                    const v2 zb = hz - jz, zc = hz + jz;
+                    ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
+                    ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
+                }
+            }
+            ys[B] = y[3].x; ys[B + 1] = y[3].y; ys[B + 2] = y[4].x; ys[B + 3] = y[4].y; ys[B + 4] = y[5].x;
+            L.ksub += C.n_sub;
+            L.steps += 1;
+        }
+    }
+    PVDER_TRACE_AT(20);
+    // The epilogue re-reads its arguments through a laundered copy of the kernarg pointer: kept live
+    // across the step loop they do not fit the scalar register file next to the loop's own constants
+    // (hipcc then spills SGPRs and gives the kernel a private segment).
+    KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const EtdArgs &E = *(const EtdArgs *)ka;
+    if (defer) {
+        if constexpr (PH == 1) E.istate[PVDER_I_STATUS * (size_t)E.n_env + L.e] = kDeferred;   // marker for the follow-up launch
+        L.run = false;
+        L.live = false;
+    }
+    epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out, E.stats, E.n_env, E.stats_fresh);
+    PVDER_TRACE_AT(21);
+    if constexpr (PH == 3) {
+        if (__syncthreads_or((int)defer)) {
+            KernargPtr kb = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kb));
+            etdrk4_full_tail(*(const EtdArgs *)kb, defer);
+        }
+    }
+}
+
+// =============================================================================================
 // adaptive Dormand-Prince RK45 (per-lane step size; fp64 tolerance-match path)
 // =============================================================================================
 template <typename T, int PH>
@@ -1359,6 +1636,148 @@ int reset_impl(const double *par, const pvder_step_cfg *cfg, const pvder_autores
     return hip_rc(hipGetLastError());
 }
 
+// ---- plans: everything a step launch needs that does not change from step to step, folded once
+// (parameter folding, phi-function scalars, reset arguments).  The per-call entry points below build
+// one on the stack; pvder_plan_create() keeps one on the heap for callers that step many times.
+}  // namespace
+
+struct pvder_plan {
+    int integrator, ph, n_env;
+    LinArgs lin;                     // etdlin; lin.A alone is the ETDRK4 argument block
+    ModelK<float> Pf;                // classic RK4 / single-phase follow-up
+    StepK<float> Cf, C4;
+    ModelK<double> Pd;               // RK45
+    StepK<double> Cd;
+    ResetK R;
+};
+
+namespace {
+
+int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+              const float *coef, const pvder_lin_coef *lin, int n_env) {
+    int rc = check_common(par, cfg, n_env);
+    if (rc) return rc;
+    if (integrator < PVDER_INT_ETDLIN || integrator > PVDER_INT_RK45) return PVDER_EINVAL;
+    p.integrator = integrator;
+    p.ph = (int)par[PVDER_PAR_PHASES];
+    p.n_env = n_env;
+    rc = fold_reset(par, cfg, ar, p.R);
+    if (rc) return rc;
+    if (integrator == PVDER_INT_RK45) {
+        if (!(cfg->rtol > 0.0) || !(cfg->atol > 0.0)) return PVDER_EINVAL;
+        p.Pd = fold_params<double>(par, false);
+        p.Cd = fold_cfg<double>(cfg);
+        return 0;
+    }
+    p.Pf = fold_params<float>(par, true);
+    p.Cf = fold_cfg<float>(cfg);
+    p.C4 = p.Cf;
+    p.C4.micro = 8192;               // single-phase follow-up: classic RK4, poles at 1.0e6 rad/s
+    if (integrator == PVDER_INT_RK4) return 0;
+    if (!coef) return PVDER_EINVAL;
+    EtdArgs &A = p.lin.A;
+    A.P = p.Pf;
+    A.C = p.Cf;
+    A.R = p.R;
+    A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, cfg->graded, nullptr);
+    A.coef = coef;
+    A.n_env = n_env;
+    // PVDER_ETD_VARIANT=full / cfg->reserved bit 0 send every env down the 23-state path (A/B, tests)
+    static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
+    A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
+    if (integrator == PVDER_INT_ETDLIN) {
+        if (!lin || !lin->sets || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
+        if (lin->len_ticks[0] < 1 || !(lin->est_guard > 0.f) || !(lin->est_refine > 0.f)) return PVDER_EINVAL;
+        for (int s = 1; s < lin->n_sets; ++s)       // sorted by decreasing length
+            if (lin->len_ticks[s] < 1 || (s > 1 && lin->len_ticks[s] >= lin->len_ticks[s - 1])) return PVDER_EINVAL;
+        LinK &K = p.lin.Lk;
+        K.lcoef = lin->sets;
+        K.n_sets = lin->n_sets;
+        for (int s = 0; s < pvder::kLinMaxSets; ++s) K.len_ticks[s] = s < lin->n_sets ? lin->len_ticks[s] : 0x7fffffff;
+        K.est_guard = lin->est_guard;
+        K.est_refine = lin->est_refine;
+        K.setmask = 0;
+        const int tick0 = lin->len_ticks[0];
+        for (int s = 1; s < lin->n_sets; ++s) {
+            const int len = lin->len_ticks[s];
+            if (len % cfg->micro == 0) K.setmask |= 1 << s;                       // whole sim time steps
+            else if ((len + tick0) % cfg->micro == 0) K.setmask |= 1 << (8 + s);  // ... minus the tick
+            bool hi = false, lo = false;
+            for (int q = 1; q < lin->n_sets; ++q) {
+                hi |= lin->len_ticks[q] == (len + 1) / 2;
+                lo |= lin->len_ticks[q] == len / 2;
+            }
+            if (len > 1 && hi && lo) K.setmask |= 1 << (16 + s);                  // can be redone as two halves
+        }
+    }
+    return 0;
+}
+
+int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action,
+                void *out, double *hstep, float *stats, int zero_stats, void *stream) {
+    if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
+    const int n_env = p.n_env;
+    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
+    switch (p.integrator) {
+    case PVDER_INT_ETDLIN:
+    case PVDER_INT_ETDRK4: {
+        LinArgs G = p.lin;
+        EtdArgs &A = G.A;
+        A.fstate = (float *)fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
+        A.action = action; A.out = (float *)out; A.stats = stats; A.stats_fresh = fresh;
+        // Three-phase: ONE launch -- the balanced fast path, whose workgroups run the 23-state path
+        // themselves for the envs they must defer (none in PVDER-v0 rollouts).  Single phase: the
+        // "balanced" kernel IS the model; an env near a limit is redone by classic RK4 micro-steps
+        // (8192 per 1/60 s) in a follow-up launch.
+        if (p.integrator == PVDER_INT_ETDLIN) {
+            if (p.ph == 3) hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, G);
+            else hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, G);
+        } else {
+            if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
+            else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
+        }
+        if (p.ph == 1)
+            hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, p.Pf, p.C4, p.R, (float *)fstate, istate,
+                               ev_vg, ev_si, action, (float *)out, stats, n_env, 0, (int)kDeferred);
+        break;
+    }
+    case PVDER_INT_RK4: {
+        // PVDER_RK4_VARIANT=generic selects the un-packed template (A/B runs); default = packed kernel
+        static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
+        if (p.ph == 3 && !generic)
+            hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, p.Pf, p.Cf, p.R, (float *)fstate, istate, ev_vg,
+                               ev_si, action, (float *)out, stats, n_env, fresh);
+        else if (p.ph == 3)
+            hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, p.Pf, p.Cf, p.R, (float *)fstate, istate,
+                               ev_vg, ev_si, action, (float *)out, stats, n_env, fresh, 0);
+        else
+            hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, p.Pf, p.Cf, p.R, (float *)fstate, istate,
+                               ev_vg, ev_si, action, (float *)out, stats, n_env, fresh, 0);
+        break;
+    }
+    default: {
+        if (!hstep) return PVDER_EINVAL;
+        if (p.ph == 3)
+            hipLaunchKernelGGL((step_rk45_kernel<double, 3>), grid, block, 0, st, p.Pd, p.Cd, p.R, (double *)fstate, istate,
+                               ev_vg, ev_si, action, (double *)out, hstep, stats, n_env, fresh);
+        else
+            hipLaunchKernelGGL((step_rk45_kernel<double, 1>), grid, block, 0, st, p.Pd, p.Cd, p.R, (double *)fstate, istate,
+                               ev_vg, ev_si, action, (double *)out, hstep, stats, n_env, fresh);
+        if (p.R.enabled) {      // same-step auto-reset as a second pass (see step_rk45_kernel)
+            if (p.ph == 3)
+                hipLaunchKernelGGL((reset_kernel<double, 3, true>), grid, block, 0, st, p.Pd, p.R, (double *)fstate, istate,
+                                   ev_vg, ev_si, (const uint8_t *)nullptr, (double *)out, n_env);
+            else
+                hipLaunchKernelGGL((reset_kernel<double, 1, true>), grid, block, 0, st, p.Pd, p.R, (double *)fstate, istate,
+                                   ev_vg, ev_si, (const uint8_t *)nullptr, (double *)out, n_env);
+        }
+    }
+    }
+    return hip_rc(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -1379,37 +1798,9 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
     return reset_impl<double>(par, cfg, ar, fstate, istate, ev_vg, ev_si, mask, out, n_env, stream);
 }
 
-int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, float *fstate,
-                       int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action, float *out,
-                       float *stats, int zero_stats, int n_env, void *stream) {
-    int rc = check_common(par, cfg, n_env);
-    if (rc) return rc;
-    if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
-    ResetK R;
-    rc = fold_reset(par, cfg, ar, R);
-    if (rc) return rc;
-    const int ph = (int)par[PVDER_PAR_PHASES];
-    const ModelK<float> P = fold_params<float>(par, true);
-    const StepK<float> C = fold_cfg<float>(cfg);
-    hipStream_t st = (hipStream_t)stream;
-    float *acc = stats;
-    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
-    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    // PVDER_RK4_VARIANT=generic selects the un-packed template (A/B runs); default = packed kernel
-    static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
-    if (ph == 3 && !generic)
-        hipLaunchKernelGGL(step_rk4_pk_kernel, grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si, action,
-                           out, acc, n_env, fresh);
-    else if (ph == 3)
-        hipLaunchKernelGGL((step_rk4_kernel<float, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, fresh, 0);
-    else
-        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, fresh, 0);
-    return hip_rc(hipGetLastError());
-}
-
 int pvder_etdrk4_coef_count(void) { return kCoefFloats; }
+int pvder_lin_set_floats(void) { return pvder::kLinSetFloats; }
+int pvder_lin_max_sets(void) { return pvder::kLinMaxSets; }
 
 int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, float *coef_host) {
     if (!par || !cfg || !coef_host || cfg->micro < 1) return PVDER_EINVAL;
@@ -1417,82 +1808,74 @@ int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, floa
     return 0;
 }
 
+// ---- per-call entry points: fold, launch, forget
+int pvder_step_etdlin_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                          const float *coef, const pvder_lin_coef *lin, float *fstate, int32_t *istate,
+                          float *ev_vg, float *ev_si, const uint8_t *action, float *out, float *stats,
+                          int zero_stats, int n_env, void *stream) {
+    pvder_plan p;
+    const int rc = fill_plan(p, PVDER_INT_ETDLIN, par, cfg, ar, coef, lin, n_env);
+    return rc ? rc : launch_plan(p, fstate, istate, ev_vg, ev_si, action, out, nullptr, stats, zero_stats, stream);
+}
+
 int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
                           const float *coef, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                           const uint8_t *action, float *out, float *stats, int zero_stats, int n_env,
                           void *stream) {
-    int rc = check_common(par, cfg, n_env);
-    if (rc) return rc;
-    if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
-    const int ph = (int)par[PVDER_PAR_PHASES];
-    ResetK R;
-    rc = fold_reset(par, cfg, ar, R);
-    if (rc) return rc;
-    if (!coef) return PVDER_EINVAL;
-    EtdArgs A;
-    A.P = fold_params<float>(par, true);
-    A.C = fold_cfg<float>(cfg);
-    A.R = R;
-    A.Ec = make_etd(par, cfg->micro, cfg->micro_coarse > 0 ? cfg->micro_coarse : cfg->micro, cfg->graded, nullptr);
-    A.force_full = 0;
-    hipStream_t st = (hipStream_t)stream;
-    float *acc = stats;
-    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
-    A.coef = coef; A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
-    A.action = action; A.out = out; A.stats = acc; A.stats_fresh = fresh; A.n_env = n_env;
-    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    // Three-phase: ONE launch -- the balanced fast path, whose workgroups run the 23-state path
-    // themselves for the envs they must defer (unbalanced state or duty cycle near its limit; none in
-    // PVDER-v0 rollouts).  PVDER_ETD_VARIANT=full sends every env down the 23-state path (A/B).
-    static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
-    const bool full_only = full_env || (cfg->reserved & 1);      // cfg->reserved bit 0: same switch per call
-    if (ph == 1) {
-        // single phase: the "balanced" kernel IS the model; an env whose duty cycle reaches the guard
-        // is redone by classic RK4 micro-steps (8192 per 1/60 s: poles at 1.0e6 rad/s) in a follow-up
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
-        StepK<float> C4 = A.C;
-        C4.micro = 8192;
-        hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, A.P, C4, A.R, fstate, istate, ev_vg, ev_si,
-                           action, out, acc, n_env, 0, (int)kDeferred);
-    } else {
-        A.force_full = full_only ? 1 : 0;
-        hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
-    }
-    return hip_rc(hipGetLastError());
+    pvder_plan p;
+    const int rc = fill_plan(p, PVDER_INT_ETDRK4, par, cfg, ar, coef, nullptr, n_env);
+    return rc ? rc : launch_plan(p, fstate, istate, ev_vg, ev_si, action, out, nullptr, stats, zero_stats, stream);
+}
+
+int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, float *fstate,
+                       int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action, float *out,
+                       float *stats, int zero_stats, int n_env, void *stream) {
+    pvder_plan p;
+    const int rc = fill_plan(p, PVDER_INT_RK4, par, cfg, ar, nullptr, nullptr, n_env);
+    return rc ? rc : launch_plan(p, fstate, istate, ev_vg, ev_si, action, out, nullptr, stats, zero_stats, stream);
 }
 
 int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, double *fstate,
                         int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action, double *out,
                         double *hstep, float *stats, int zero_stats, int n_env, void *stream) {
-    int rc = check_common(par, cfg, n_env);
-    if (rc) return rc;
-    if (!fstate || !istate || !ev_vg || !ev_si || !action || !out || !hstep) return PVDER_EINVAL;
-    if (!(cfg->rtol > 0.0) || !(cfg->atol > 0.0)) return PVDER_EINVAL;
-    ResetK R;
-    rc = fold_reset(par, cfg, ar, R);
-    if (rc) return rc;
-    const int ph = (int)par[PVDER_PAR_PHASES];
-    const ModelK<double> P = fold_params<double>(par, false);
-    const StepK<double> C = fold_cfg<double>(cfg);
-    hipStream_t st = (hipStream_t)stream;
-    float *acc = stats;
-    const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
-    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
-    if (ph == 3)
-        hipLaunchKernelGGL((step_rk45_kernel<double, 3>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, hstep, acc, n_env, fresh);
-    else
-        hipLaunchKernelGGL((step_rk45_kernel<double, 1>), grid, block, 0, st, P, C, R, fstate, istate, ev_vg, ev_si,
-                           action, out, hstep, acc, n_env, fresh);
-    if (R.enabled) {      // same-step auto-reset as a second pass (see step_rk45_kernel)
-        if (ph == 3)
-            hipLaunchKernelGGL((reset_kernel<double, 3, true>), grid, block, 0, st, P, R, fstate, istate, ev_vg,
-                               ev_si, (const uint8_t *)nullptr, out, n_env);
-        else
-            hipLaunchKernelGGL((reset_kernel<double, 1, true>), grid, block, 0, st, P, R, fstate, istate, ev_vg,
-                               ev_si, (const uint8_t *)nullptr, out, n_env);
+    if (!hstep) return PVDER_EINVAL;
+    pvder_plan p;
+    const int rc = fill_plan(p, PVDER_INT_RK45, par, cfg, ar, nullptr, nullptr, n_env);
+    return rc ? rc : launch_plan(p, fstate, istate, ev_vg, ev_si, action, out, hstep, stats, zero_stats, stream);
+}
+
+// ---- plan handles: fold once, step many times
+int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, const pvder_step_cfg *cfg,
+                      const pvder_autoreset *ar, const float *coef, const pvder_lin_coef *lin, int n_env) {
+    if (!plan) return PVDER_EINVAL;
+    *plan = nullptr;
+    pvder_plan *p = new (std::nothrow) pvder_plan;
+    if (!p) return -(int)hipErrorOutOfMemory;
+    const int rc = fill_plan(*p, integrator, par, cfg, ar, coef, lin, n_env);
+    if (rc) { delete p; return rc; }
+    *plan = p;
+    return 0;
+}
+
+void pvder_plan_destroy(pvder_plan *plan) { delete plan; }
+
+int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                    const uint8_t *action, void *out, double *hstep, float *stats, void *stream) {
+    if (!plan) return PVDER_EINVAL;
+    return launch_plan(*plan, fstate, istate, ev_vg, ev_si, action, out, hstep, stats, 1, stream);
+}
+
+int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                       const uint8_t *actions, int n_steps, void *out, size_t out_step_stride, double *hstep,
+                       float *stats, void *stream) {
+    if (!plan || n_steps < 0 || !actions || !out) return PVDER_EINVAL;
+    const size_t esz = plan->integrator == PVDER_INT_RK45 ? sizeof(double) : sizeof(float);
+    for (int k = 0; k < n_steps; ++k) {
+        const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env,
+                                   (char *)out + (size_t)k * out_step_stride * esz, hstep, stats, 1, stream);
+        if (rc) return rc;
     }
-    return hip_rc(hipGetLastError());
+    return 0;
 }
 
 #ifdef PVDER_TRACE

@@ -20,12 +20,17 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
            "pvder_reset_masked_f64", "pvder_step_etdrk4_f32", "pvder_step_rk4_f32", "pvder_step_rk45_f64",
-           "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients"]
+           "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients", "pvder_lin_set_floats", "pvder_lin_max_sets",
+           "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
+           "pvder_plan_rollout"]
+
+INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
+LIN_MAX_SETS = 8
 
 
 class StepCfg(C.Structure):
@@ -49,6 +54,12 @@ class AutoReset(C.Structure):
     """``struct pvder_autoreset`` (include/pvder_hip.h)."""
     _fields_ = [("enabled", C.c_int32), ("keep_events", C.c_int32), ("seed", C.c_uint64),
                 ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double))]
+
+
+class LinCoef(C.Structure):
+    """``struct pvder_lin_coef`` (include/pvder_hip.h)."""
+    _fields_ = [("sets", C.c_void_p), ("n_sets", C.c_int32), ("len_ticks", C.c_int32 * LIN_MAX_SETS),
+                ("est_refine", C.c_float), ("est_guard", C.c_float)]
 
 
 def hipcc_path() -> str:
@@ -114,6 +125,17 @@ def lib() -> C.CDLL:
     L.pvder_etdrk4_coefficients.argtypes = [dp, cfgp, C.POINTER(C.c_float)]
     L.pvder_step_rk45_f64.restype = i32
     L.pvder_step_rk45_f64.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    linp = C.POINTER(LinCoef)
+    L.pvder_step_etdlin_f32.restype = i32
+    L.pvder_step_etdlin_f32.argtypes = [dp, cfgp, arp, vp, linp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.pvder_plan_create.restype = i32
+    L.pvder_plan_create.argtypes = [C.POINTER(vp), i32, dp, cfgp, arp, vp, linp, i32]
+    L.pvder_plan_destroy.restype = None
+    L.pvder_plan_destroy.argtypes = [vp]
+    L.pvder_plan_step.restype = i32
+    L.pvder_plan_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pvder_plan_rollout.restype = i32
+    L.pvder_plan_rollout.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
     _lib = L
     return L
 

@@ -1,0 +1,340 @@
+"""Host-side set-up of the linearised exponential integrator ("etdlin") of the PVDER-v0 step path.
+
+What it replaces in the reference: nothing of the reference itself -- ``PVDER.step`` hands the ODE to
+``self.sim.run_simulation()`` (/root/reference/gym_PVDER/envs/PVDER_env.py:166; third-party pvder ->
+SciPy LSODA with an analytic Jacobian, :384-386).  LSODA is an implicit multistep method driven by
+that Jacobian; the device-side counterpart built here is an EXPLICIT exponential Runge-Kutta method
+driven by the same object: the Jacobian ``L`` of the (balanced, 11-state) model at its nominal
+operating point.  With ``dy/dt = f(y) = L y + N(y)`` the linear part -- stiff current loop at
+-1e5 +- j5.8e5 1/s, PLL pole at -88 1/s, DC-link and outer PI loops -- is propagated exactly by
+``exp(hL)`` and the phi-functions, and only the small, smooth remainder ``N`` is integrated by the
+Runge-Kutta stages.  Measured on the goldens (fp64 prototype): Cox-Matthews' 3-stage
+ETD3RK with TWO steps per env step (a first step of 1/(60*32) s behind the action / event jump, then
+one step over the rest of the env step) reproduces the converged trajectories to <= 7e-6 rel-L2 --
+the accuracy the round-1 kernel needed 16 five-stage steps for.
+
+The kernels evaluate the scheme in "f-form": every stage is ``U_i = y + sum_j M_ij f(U_j)`` with
+DENSE 11x11 matrices ``M_ij`` (functions of hL only), i.e. an explicit Runge-Kutta method with
+matrix-valued coefficients -- no ``N``, no ``L y`` on the device.  This module computes, in fp64,
+
+* the nominal operating point (steady state of der_model + locked PLL angle),
+* ``L`` by central differences of the balanced right-hand side below,
+* the phi-functions of ``hL`` (exponential of an augmented matrix, scaling-and-squaring Pade below),
+* the f-form matrices of a scheme given as an exponential-RK tableau, and packs them in the layout
+  the HIP kernel stages in LDS (``pack_sets``).
+
+fp64, host only, once per (parameter set, step schedule) -- not on the hot path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import der_model
+from .der_model import IDX
+
+NB = 11                       # balanced / single-phase state: iR,iI,xR,xI,uR,uI,Vdc,xDC,xQ,xPLL,delta
+ROWS_PAD = 12                 # matrix rows padded to an even count (packed fp32 pairs on the device)
+N_STAGE_MATS = 6              # ETD3RK in f-form: M21 | M31 M32 | M41 M42 M43
+
+
+# ---------------------------------------------------------------------------------------------------
+# balanced right-hand side (numpy, dtype-generic, vectorised over trailing axes)
+# ---------------------------------------------------------------------------------------------------
+def folded(par: np.ndarray) -> Dict[str, float]:
+    """The constants the kernels fold on the host (csrc/pvder_kernels.hip::fold_params), fp64."""
+    P = {k: float(par[i]) for k, i in IDX.items()}
+    scale = P["VDCBASE"] / P["SBASE"]
+    return dict(PH=int(P["PHASES"]), Rf=P["RF"], iLf=1.0 / P["LF"], iC=1.0 / P["C"],
+                kviR=P["KVI_RE"], kviI=P["KVI_IM"], GR=P["KVG_RE"] * P["VG_SCALE"], GI=P["KVG_IM"] * P["VG_SCALE"],
+                KpG=P["KP_GCC"], KiG=P["KI_GCC"], KpDC=P["KP_DC"], KiDC=P["KI_DC"], KpQ=P["KP_Q"], KiQ=P["KI_Q"],
+                wp=P["WP"], KpP=P["KP_PLL"], KiP=P["KI_PLL"], iwb=1.0 / P["WBASE"],
+                pvA=P["NP"] * P["ISCR"] * scale / 100.0, pvB=P["NP"] * P["IRS"] * scale, pvK=P["PV_VT"])
+
+
+def f_bal(c: Dict[str, float], y, vg, sinsol, qref, vdcref):
+    """dy/dt of the balanced reduction (phases b, c = phase a rotated by -/+120 degrees; for PH = 1
+    this IS the single-phase model).  Same equations as csrc/pvder_model.hpp::rhs without the
+    anti-windup branches (the fast path hands envs near a limit to the 23-state path).
+    ``y``: [11, ...]; inputs broadcast against the trailing axes."""
+    iR, iI, xR, xI, uR, uI, Vdc, xDC, xQ, xPLL, dl = y
+    ph = c["PH"]
+    mR, mI = c["KpG"] * uR + xR, c["KpG"] * uI + xI
+    aR, aI = c["GR"] * vg, c["GI"] * vg
+    vR = aR + c["kviR"] * iR - c["kviI"] * iI
+    vI = aI + c["kviR"] * iI + c["kviI"] * iR
+    Pt = ph * (mR * iR + mI * iI)
+    Q = 0.5 * ph * (vI * iR - vR * iI)
+    rR = xDC + c["KpDC"] * (vdcref - Vdc)
+    qerr = qref - Q
+    rI = xQ - c["KpQ"] * qerr
+    vd = vR * np.cos(dl) + vI * np.sin(dl)
+    dw = c["KpP"] * vd + xPLL
+    wr = 1.0 + dw * c["iwb"]
+    hV = 0.5 * Vdc
+    d_iR = c["iLf"] * (mR * hV - vR - c["Rf"] * iR) + wr * iI
+    d_iI = c["iLf"] * (mI * hV - vI - c["Rf"] * iI) - wr * iR
+    pv1 = c["pvA"] * sinsol + c["pvB"]
+    ppv = np.maximum(Vdc * (pv1 - c["pvB"] * np.exp(c["pvK"] * Vdc)), 0.0)
+    dVdc = (ppv - 0.5 * hV * Pt) / Vdc * c["iC"]
+    return np.stack([d_iR, d_iI, c["KiG"] * uR, c["KiG"] * uI,
+                     c["wp"] * (rR - iR - uR), c["wp"] * (rI - iI - uI),
+                     dVdc, c["KiDC"] * (vdcref - Vdc), -c["KiQ"] * qerr, c["KiP"] * vd, dw + 0.0 * Vdc])
+
+
+def operating_point(par: np.ndarray, der_id: str) -> np.ndarray:
+    """Nominal equilibrium of the balanced model: der_model's steady state (vgrid 1, nominal
+    insolation, Q_ref 0, Vdc_ref = Vdcmpp0) with the PLL LOCKED: vd = Re(v_a e^{-j delta}) = 0 on the
+    stable branch (d vd / d delta < 0), the 2 pi branch next to the reset angle."""
+    y0 = der_model.steady_state(par, der_id)
+    ph = int(par[IDX["PHASES"]])
+    B = 6 * ph
+    y = np.concatenate([y0[:6], y0[B:B + 5]]).astype(np.float64)
+    c = folded(par)
+    va = complex(c["GR"], c["GI"]) + complex(c["kviR"], c["kviI"]) * complex(y[0], y[1])
+    lock = math.atan2(va.imag, va.real) + 0.5 * math.pi
+    y[10] = lock + 2.0 * math.pi * round((y0[B + 4] - lock) / (2.0 * math.pi))
+    res = f_bal(c, y, 1.0, par[IDX["SINSOL0"]], 0.0, par[IDX["VDC_REF0"]])
+    scale = np.array([1e6, 1e6, 1.0, 1.0, 1e6, 1e6, 1.0, 1.0, 1.0, 1.0, 1e3])
+    if np.abs(res / scale).max() > 1e-6:
+        raise RuntimeError("operating point is not an equilibrium (residual %s)" % res)
+    return y
+
+
+def jacobian(par: np.ndarray, der_id: str) -> Tuple[np.ndarray, np.ndarray]:
+    """(L, y*): central-difference Jacobian of f_bal at the nominal operating point.  Exactness of L
+    is not required -- whatever is not in L stays in N = f - L y and is integrated by the stages --
+    only that the kernel and the phi-functions use the same L (they do: both come from here)."""
+    c = folded(par)
+    ystar = operating_point(par, der_id)
+    args = (1.0, par[IDX["SINSOL0"]], 0.0, par[IDX["VDC_REF0"]])
+    L = np.zeros((NB, NB))
+    for k in range(NB):
+        d = np.zeros(NB)
+        d[k] = 1e-6 * max(1.0, abs(ystar[k]))
+        L[:, k] = (f_bal(c, ystar + d, *args) - f_bal(c, ystar - d, *args)) / (2.0 * d[k])
+    return L, ystar
+
+
+# ---------------------------------------------------------------------------------------------------
+# phi-functions and f-form matrices
+# ---------------------------------------------------------------------------------------------------
+_PADE13 = (64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800., 129060195264000.,
+           10559470521600., 670442572800., 33522128640., 1323241920., 40840800., 960960., 16380., 182., 1.)
+
+
+def expm(A: np.ndarray) -> np.ndarray:
+    """Matrix exponential, fp64: [13/13] Pade approximant with scaling and squaring (Higham, SIAM J.
+    Matrix Anal. Appl. 26, 2005, algorithm 2.3 with theta_13 = 5.37).  numpy only."""
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    norm = np.abs(A).sum(axis=0).max()
+    s = max(0, int(math.ceil(math.log2(norm / 5.371920351148152)))) if norm > 0 else 0
+    A = A / (2.0 ** s)
+    b = _PADE13
+    I = np.eye(n)
+    A2 = A @ A
+    A4 = A2 @ A2
+    A6 = A4 @ A2
+    U = A @ (A6 @ (b[13] * A6 + b[11] * A4 + b[9] * A2) + b[7] * A6 + b[5] * A4 + b[3] * A2 + b[1] * I)
+    V = A6 @ (b[12] * A6 + b[10] * A4 + b[8] * A2) + b[6] * A6 + b[4] * A4 + b[2] * A2 + b[0] * I
+    X = np.linalg.solve(V - U, V + U)
+    for _ in range(s):
+        X = X @ X
+    return X
+
+
+def phis(L: np.ndarray, h: float, kmax: int = 3) -> List[np.ndarray]:
+    """[phi_0(hL), ..., phi_kmax(hL)] by the exponential of the augmented matrix
+    [[hL, I, 0..], [0, 0, I, ..], ...] (its first block row holds phi_0 ... phi_kmax)."""
+    n = L.shape[0]
+    M = np.zeros((n * (kmax + 1), n * (kmax + 1)))
+    M[:n, :n] = h * L
+    for j in range(kmax):
+        M[j * n:(j + 1) * n, (j + 1) * n:(j + 2) * n] = np.eye(n)
+    E = expm(M)
+    return [E[:n, k * n:(k + 1) * n] for k in range(kmax + 1)]
+
+
+def phis_eig(L: np.ndarray, h: float, kmax: int = 3) -> List[np.ndarray]:
+    """The same functions through the eigendecomposition (independent route, used by the tests)."""
+    lam, V = np.linalg.eig(L)
+    Vi = np.linalg.inv(V)
+
+    def scalar_phi(k, z):
+        out = np.empty_like(z)
+        for i, zi in enumerate(z):
+            if abs(zi) < 0.5:                  # Taylor series: sum z^j / (j + k)!
+                term, s = 1.0 / math.factorial(k), 0.0
+                for j in range(40):
+                    s += term
+                    term = term * zi / (j + k + 1)
+                out[i] = s
+            else:
+                e = np.exp(zi)
+                poly = sum(zi ** j / math.factorial(j) for j in range(k))
+                out[i] = (e - poly) / zi ** k
+        return out
+    return [np.real((V * scalar_phi(k, h * lam)) @ Vi) for k in range(kmax + 1)]
+
+
+def etd3rk_tableau(L: np.ndarray, h: float):
+    """Cox & Matthews' ETD3RK (J. Comput. Phys. 176, 2002, eq. 23-25) as (E_i, A_ij, E, B_j):
+    U_i = E_i y + sum_j A_ij N_j,  y+ = E y + sum_j B_j N_j,  c = 0, 1/2, 1."""
+    f = phis(L, h)
+    g = phis(L, 0.5 * h)
+    Z = np.zeros_like(L)
+    Es = [None, g[0], f[0]]
+    A = [[Z, Z, Z], [0.5 * h * g[1], Z, Z], [-h * f[1], 2.0 * h * f[1], Z]]
+    B = [h * (f[1] - 3.0 * f[2] + 4.0 * f[3]), h * (4.0 * f[2] - 8.0 * f[3]), h * (-f[2] + 4.0 * f[3])]
+    return Es, A, f[0], B
+
+
+def f_form(L: np.ndarray, Es, A, E, B) -> List[List[np.ndarray]]:
+    """Rewrite an exponential-RK tableau in terms of FULL right-hand sides F_j = f(U_j):
+    N_j = F_j - L U_j and, inductively, U_j = y + sum_k M_jk F_k  (the coefficient of y must come out
+    as the identity -- that is the scheme's consistency condition, asserted here).  Returns the rows
+    M[i] = [M_i1 ... M_i,i-1] for stages i = 2..s and the final row M[s+1]."""
+    n = L.shape[0]
+    s = len(A)
+    eye = np.eye(n)
+    rows: List[List[np.ndarray]] = [[]]             # stage 1: U_1 = y
+    for i in list(range(1, s)) + [s]:
+        Ei, Ai = (Es[i], A[i]) if i < s else (E, B)
+        alpha = Ei.copy()
+        M = [np.zeros((n, n)) for _ in range(i)]
+        for j in range(i):
+            Aij = Ai[j]
+            if not np.any(Aij):
+                continue
+            M[j] = M[j] + Aij
+            alpha = alpha - Aij @ L              # coefficient of y inside -A_ij L U_j
+            for k in range(len(rows[j])):
+                M[k] = M[k] - Aij @ L @ rows[j][k]
+        # consistency: E_i - sum_j A_ij L = I.  The fast eigenvalues make ||A L|| ~ 1, so compare in
+        # absolute terms with the rounding level of the augmented exponential
+        if not np.allclose(alpha, eye, atol=5e-7, rtol=0):
+            raise ArithmeticError("f-form consistency violated at stage %d (max dev %.2e)"
+                                  % (i + 1, np.abs(alpha - eye).max()))
+        rows.append(M)
+    return rows[1:]
+
+
+def etd3rk_f_matrices(L: np.ndarray, h: float) -> List[np.ndarray]:
+    """[M21, M31, M32, M41, M42, M43] of ETD3RK for step size h."""
+    if h == 0.0:
+        return [np.zeros_like(L) for _ in range(N_STAGE_MATS)]
+    r = f_form(L, *etd3rk_tableau(L, h))
+    return [r[0][0], r[1][0], r[1][1], r[2][0], r[2][1], r[2][2]]
+
+
+def pack_matrix(M: np.ndarray) -> np.ndarray:
+    """[NB, NB] -> flat [NB * ROWS_PAD] fp32, column-major with the rows padded to 12: the kernel
+    multiplies column k (12 floats = 3 ds_read_b128, row pairs (2r, 2r+1) adjacent) by f_k."""
+    out = np.zeros((NB, ROWS_PAD), dtype=np.float32)
+    out[:, :NB] = M.T.astype(np.float32)
+    return out.reshape(-1)
+
+
+def pack_sets(L: np.ndarray, hs: Sequence[float]) -> np.ndarray:
+    """One coefficient set per step size in ``hs`` (seconds; 0 = the identity step): 6 matrices each."""
+    return np.concatenate([pack_matrix(M) for h in hs for M in etd3rk_f_matrices(L, float(h))])
+
+
+MAT_FLOATS = NB * ROWS_PAD
+SET_FLOATS = N_STAGE_MATS * MAT_FLOATS
+
+
+# ---------------------------------------------------------------------------------------------------
+# reference implementation of one step (numpy; tests and the fp32 emulation of the kernel arithmetic)
+# ---------------------------------------------------------------------------------------------------
+def etd3rk_step(c, mats: Sequence[np.ndarray], y, inputs, dtype=np.float64):
+    """y+ of one ETD3RK step in f-form, arithmetic carried out in ``dtype``; also returns the
+    2nd-order stage value b (y+ - b is the step's embedded error indicator)."""
+    M21, M31, M32, M41, M42, M43 = [m.astype(dtype) for m in mats]
+    y = y.astype(dtype)
+    inp = [np.asarray(v, dtype=dtype) for v in inputs]
+    cc = {k: (dtype(v) if isinstance(v, float) else v) for k, v in c.items()}
+    F1 = f_bal(cc, y, *inp).astype(dtype)
+    a = y + M21 @ F1
+    F2 = f_bal(cc, a, *inp).astype(dtype)
+    b = y + M31 @ F1 + M32 @ F2
+    F3 = f_bal(cc, b, *inp).astype(dtype)
+    return y + M41 @ F1 + M42 @ F2 + M43 @ F3, b
+
+
+# ---------------------------------------------------------------------------------------------------
+# step-size menu of a launch
+# ---------------------------------------------------------------------------------------------------
+EST_REFINE = 1e-2     # |y+ - b| over (i_a, Vdc) above which an ETD3RK step is redone as two half steps.  The indicator
+#                       runs ~70x above the true error of the step (DESIGN.md "etdlin": 1e-2 <-> 1.4e-4 for the
+#                       largest insolation events of PVDER-v0 rollouts, median 2e-4 <-> 3e-6); halving divides it by ~8.
+#                       At one wave per SIMD a launch lasts as long as its slowest wave, so the threshold sits where
+#                       only the steps that need it trip it (event steps with both event types on), not lower.
+EST_GUARD = 5e-2      # an env that must ACCEPT a step above this (hopelessly far from the operating point) takes the
+#                       23-state path
+
+
+def choose_sets(n_sub: int, micro: int, ev_s0: int, ev_ds: int, ev_count: int, max_ksub: int,
+                max_sets: int = 8) -> List[int]:
+    """Step lengths (ticks of 1/(60*micro) s) of the coefficient sets of a launch: [tick, others sorted
+    by decreasing length].  An env takes one tick (exponential Euler) behind every input jump and then
+    the largest ETD3RK step that fits what is left of the segment, so the menu holds
+
+    * ``L*micro - 1`` for the segment lengths L (sim time steps between two jumps) that envs running in
+      lockstep with the event grid meet -- most frequent first; PVDER-v0: L = n_sub only, events sit
+      on env-step boundaries -- which makes the usual env step TWO integrator steps -- and its two
+      halves, for steps the error indicator rejects;
+    * ``micro - 1`` and ``micro``: together they tile any segment (an env reset off the grid, an event
+      spec that is not a multiple of the env step);
+    * power-of-two multiples of ``micro`` while there is room, so that such segments take O(log L) steps.
+    """
+    from collections import Counter
+    cnt: Counter = Counter()
+    events = [ev_s0 + j * ev_ds for j in range(max(0, ev_count))]
+    k = 0
+    while k < max(max_ksub, n_sub) and k < 200000:
+        cuts = [0] + [e - k for e in events if k < e < k + n_sub] + [n_sub]
+        for a, b in zip(cuts, cuts[1:]):
+            cnt[b - a] += 1
+        k += n_sub
+    lens = {micro - 1, micro} if micro > 1 else {1}
+    for L, _ in cnt.most_common():
+        t = L * micro - 1
+        want = {t, (t + 1) // 2, t // 2} - {0}
+        if len(lens | want) > max_sets - 1:
+            if len(lens | {t}) <= max_sets - 1 and t >= 1:
+                lens.add(t)
+            break
+        lens |= want
+    p = 2
+    while len(lens) < max_sets - 1 and p < n_sub:
+        lens.add(p * micro)
+        p *= 2
+    return [1] + sorted(lens, reverse=True)
+
+
+def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[int]) -> np.ndarray:
+    """fp32 coefficient block of a launch: the tick matrix  h phi1(hL)  (h = len_ticks[0] ticks), then one
+    ETD3RK set per entry of len_ticks[1:]."""
+    tick = 1.0 / (60.0 * micro)
+    h0 = len_ticks[0] * tick
+    parts = [pack_matrix(h0 * phis(L, h0, 1)[1])]
+    parts += [pack_matrix(M) for t in len_ticks[1:] for M in etd3rk_f_matrices(L, t * tick)]
+    return np.concatenate(parts)
+
+
+def build_coefficients(par: np.ndarray, der_id: str, micro: int, len_ticks: Sequence[int]) -> np.ndarray:
+    """fp32 coefficient block [MAT + (n_sets - 1) * SET_FLOATS] for the step lengths ``len_ticks`` (ticks)."""
+    L, _ = jacobian(par, der_id)
+    return pack_block(L, micro, len_ticks)
+
+
+def euler_tick(c, P1: np.ndarray, y, inputs, dtype=np.float64):
+    """The tick behind an input jump: exponential Euler  y+ = y + h phi1(hL) f(y)  (P1 = h phi1(hL))."""
+    y = y.astype(dtype)
+    inp = [np.asarray(v, dtype=dtype) for v in inputs]
+    cc = {k: (dtype(v) if isinstance(v, float) else v) for k, v in c.items()}
+    return y + P1.astype(dtype) @ f_bal(cc, y, *inp).astype(dtype)

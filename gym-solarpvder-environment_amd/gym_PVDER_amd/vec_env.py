@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import _native, der_model
+from . import _native, der_model, etd_linear
 
 logger = logging.getLogger("gym_PVDER_amd")
 
@@ -29,7 +29,7 @@ SIM_TIME_STEP = 1.0 / 60.0               # env_sim_spec['sim_time_step'], PVDER_
 MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
 # integrator steps per 1/60 s sim time step (DESIGN.md "Kernels"): classic RK4 is stability-bound
 # by the current loop (h <= ~4.5 us); ETDRK4 propagates that loop exactly and is accuracy-bound
-DEFAULT_MICRO = {"etdrk4": 32, "rk4": 4096, "rk45": 1}
+DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1}
 # ETDRK4 step schedule: a sim time step that starts at an input jump (new action / event) takes a first
 # step of 1/(60*micro) s and one more over the remainder (graded), every other one DEFAULT_MICRO_COARSE
 DEFAULT_MICRO_COARSE = 1
@@ -128,11 +128,13 @@ class PVDERVec(EnvSpecMixin):
         goals_list, n_sim_time_steps_per_env_step, max_sim_time, DISCRETE_REWARD
         num_envs:   N
         device:     torch device (a ROCm GPU)
-        integrator: 'etdrk4' (fp32 fixed-step exponential RK4, default),
-                    'rk4' (fp32 fixed-step classic RK4 micro-stepping) or 'rk45' (fp64 adaptive
-                    Dormand-Prince)
-        micro_steps: classic RK4: steps per 1/60 s sim time step (default 4096); ETDRK4: the first step
-                    behind an input jump is 1/(60*micro_steps) s (default 32)
+        integrator: 'etdlin' (default: fp32 ETD3RK on the model linearised at its operating point --
+                    the whole linear response sits in the matrix exponential; two steps per env step),
+                    'etdrk4' (fp32 exponential RK of stiff order 4 with only the stiff current loop in
+                    the exponential; 16 steps per env step), 'rk4' (fp32 fixed-step classic RK4
+                    micro-stepping) or 'rk45' (fp64 adaptive Dormand-Prince)
+        micro_steps: classic RK4: steps per 1/60 s sim time step (default 4096); ETDRK4 / etdlin: the
+                    first step behind an input jump is 1/(60*micro_steps) s (default 32)
         micro_coarse: ETDRK4 only -- steps per sim time step that does not start at an input jump
                     (new action or event); default 1, 0 = uniform micro_steps
         graded: ETDRK4 only -- True (default): the sim time step that starts at an input jump takes
@@ -159,9 +161,9 @@ class PVDERVec(EnvSpecMixin):
         if model_type not in self.env_model_spec:
             raise ValueError("model_type must be one of %s" % list(self.env_model_spec))
         if integrator is None:
-            integrator = "etdrk4"
-        if integrator not in ("etdrk4", "rk4", "rk45"):
-            raise ValueError("integrator must be 'etdrk4', 'rk4' or 'rk45'")
+            integrator = "etdlin"
+        if integrator not in _native.INTEGRATOR_IDS:
+            raise ValueError("integrator must be one of %s" % sorted(_native.INTEGRATOR_IDS))
         if micro_steps is None:
             micro_steps = DEFAULT_MICRO[integrator]
             if integrator == "rk4" and model_type == 'model_1':
@@ -169,13 +171,13 @@ class PVDERVec(EnvSpecMixin):
         if isinstance(micro_steps, bool) or not isinstance(micro_steps, int) or micro_steps < 1:
             raise ValueError("micro_steps must be a positive integer")
         if micro_coarse is None:
-            micro_coarse = min(DEFAULT_MICRO_COARSE, micro_steps) if integrator == "etdrk4" else 0
+            micro_coarse = min(DEFAULT_MICRO_COARSE, micro_steps) if integrator in ("etdrk4", "etdlin") else 0
         if isinstance(micro_coarse, bool) or not isinstance(micro_coarse, int) or micro_coarse < 0:
             raise ValueError("micro_coarse must be a non-negative integer")
         self.micro_coarse = int(micro_coarse)
         if not isinstance(graded, bool):
             raise ValueError("graded must be a bool")
-        self.graded = bool(graded) and integrator == "etdrk4" and self.micro_coarse > 0
+        self.graded = bool(graded) and integrator in ("etdrk4", "etdlin") and self.micro_coarse > 0
         self.num_envs = num_envs
         self._set_n(n_sim_time_steps_per_env_step)
         self.max_sim_time_user = max_sim_time
@@ -214,6 +216,31 @@ class PVDERVec(EnvSpecMixin):
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
         self._needs_reset = True
+        self._plan = None
+
+    def __del__(self):
+        try:
+            self._drop_plan()
+        except Exception:          # interpreter shutdown: the library may be gone already
+            pass
+
+    # -- everything a plan folds in: assigning any of these drops the plan (rebuilt at the next step)
+    _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded",
+                            "est_guard", "est_refine", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
+                            "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "integrator"))
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name in self._PLAN_KEYS and self.__dict__.get("_plan") is not None:
+            self._drop_plan()
+
+    def _drop_plan(self):
+        p = self.__dict__.get("_plan")
+        object.__setattr__(self, "_plan", None)
+        if p is not None:
+            self._lib.pvder_plan_destroy(p)
+
+    _debug_knob = 0          # pvder_step_cfg.reserved (tests only)
 
     # -- properties mirroring the reference (PVDER_env.py:544-558, env_utilities.py:48-52) -------
     @property
@@ -297,6 +324,7 @@ class PVDERVec(EnvSpecMixin):
                 if key not in self.env_events_spec[event_type]:
                     raise ValueError('{} is not a valid paramter for {} event!'.format(key, event_type))
                 self.env_events_spec[event_type][key] = val
+        self._drop_plan()
         K, s0, ds = self._event_grid()
         if (K, s0, ds) != (self.ev_count, self.ev_s0, self.ev_ds):
             self._alloc_event_tables()
@@ -316,12 +344,13 @@ class PVDERVec(EnvSpecMixin):
         self.ev_vg.copy_(vgrid)
         self.ev_si.copy_(sinsol)
         self._keep_events = True
+        self._drop_plan()
 
     def clear_event_tables(self):
         self._keep_events = False
+        self._drop_plan()
 
     _keep_events = False
-    _debug_knob = 0          # pvder_step_cfg.reserved (tests only)
 
     # -- launch plumbing --------------------------------------------------------------------------
     def _cfg(self) -> _native.StepCfg:
@@ -365,6 +394,46 @@ class PVDERVec(EnvSpecMixin):
             self._coef_key = key
         return self._coef
 
+    _lin_cache: Dict[tuple, np.ndarray] = {}      # (derId, micro, lengths) -> host block (1 s of expm per entry)
+
+    def _lin_coef(self, cfg) -> _native.LinCoef:
+        """``struct pvder_lin_coef`` of the etdlin path: the step-length menu of this env's schedule and
+        the device copy of the f-form matrices (gym_PVDER_amd/etd_linear.py), rebuilt only when the
+        schedule changes."""
+        lens = etd_linear.choose_sets(cfg.n_sub, cfg.micro, cfg.ev_s0, cfg.ev_ds, cfg.ev_count, cfg.max_ksub,
+                                      _native.LIN_MAX_SETS)
+        key = (self.der_id, cfg.micro, tuple(lens))
+        if getattr(self, "_lin_key", None) != key:
+            host = PVDERVec._lin_cache.get(key)
+            if host is None:
+                host = etd_linear.build_coefficients(self.par, self.der_id, cfg.micro, lens)
+                PVDERVec._lin_cache[key] = host
+            assert host.size == etd_linear.MAT_FLOATS + (len(lens) - 1) * self._lib.pvder_lin_set_floats()
+            self._lin_dev = torch.from_numpy(host).to(self.device)
+            self._lin_key = key
+        lc = _native.LinCoef()
+        lc.sets = self._lin_dev.data_ptr()
+        lc.n_sets = len(lens)
+        for k, t in enumerate(lens):
+            lc.len_ticks[k] = t
+        lc.est_refine, lc.est_guard = self.est_refine, self.est_guard
+        return lc
+
+    est_refine = etd_linear.EST_REFINE
+    est_guard = etd_linear.EST_GUARD
+
+    def _make_plan(self):
+        """Fold cfg / reset block / coefficients into a C-side plan (include/pvder_hip.h "plans")."""
+        cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
+        coef = self._etd_coef(cfg).data_ptr() if self.integrator in ("etdrk4", "etdlin") else None
+        lin = C.byref(self._lin_coef(cfg)) if self.integrator == "etdlin" else None
+        h = C.c_void_p()
+        _native.check(self._lib.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS[self.integrator], self._par_c,
+                                                  C.byref(cfg), C.byref(ar), coef, lin, self.num_envs),
+                      "pvder_plan_create")
+        self._plan = h
+        return h
+
     def _device_ctx(self):
         """``torch.cuda.device(self.device)``, or nothing when it is the current device already."""
         if torch.cuda.current_device() == self.device.index:
@@ -400,8 +469,8 @@ class PVDERVec(EnvSpecMixin):
                 mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
                 assert mask.shape == (self.num_envs,)
             self._reset_launch(mask)
-            if self.integrator == "etdrk4":
-                self._etd_coef(self._cfg())          # upload now: step() must stay capturable into a HIP graph
+            if self._plan is None:
+                self._make_plan()                    # coefficient uploads now: step() must stay capturable into a HIP graph
             if self.hstep is not None:
                 if mask is None:
                     self.hstep.zero_()
@@ -425,32 +494,22 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("actions must have shape (%d,)" % self.num_envs)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
-        # host structs are rebuilt per call (a few microseconds): every property the reference lets
-        # the user change between steps (events spec, goals, ...) is picked up without a cache to
-        # invalidate; the launch itself is asynchronous
-        cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
-        a = (self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
-             self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr())
+        plan = self._plan or self._make_plan()      # cfg / reset block / coefficients folded once (C side)
         with self._device_ctx():
             timed = False
             if self._timing:
                 self._timing_k += 1
                 timed = self._timing_k % self._timing_every == 0
             if timed:
-                ev0 = torch.cuda.Event(enable_timing=True)
-                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0, ev1 = self._event_pair()
                 ev0.record()          # same stream the kernel is launched on (torch's current stream)
             # ONE launch: action -> integrate -> reward/done/obs -> same-step auto-reset of finished
-            # envs (their obs rows hold the reset observation, reward/done rows the ended transition)
-            zs = 1            # statistics: every workgroup overwrites its slot (no atomics, nothing to clear)
-            if self.integrator == "etdrk4":
-                rc = self._lib.pvder_step_etdrk4_f32(*a[:3], self._etd_coef(cfg).data_ptr(), *a[3:],
-                                                     self.stats.data_ptr(), zs, self.num_envs, self._stream())
-            elif self.integrator == "rk4":
-                rc = self._lib.pvder_step_rk4_f32(*a, self.stats.data_ptr(), zs, self.num_envs, self._stream())
-            else:
-                rc = self._lib.pvder_step_rk45_f64(*a, self.hstep.data_ptr(), self.stats.data_ptr(), zs,
-                                                   self.num_envs, self._stream())
+            # envs (their obs rows hold the reset observation, reward/done rows the ended transition);
+            # statistics: every workgroup overwrites its slot (no atomics, nothing to clear)
+            rc = self._lib.pvder_plan_step(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self.ev_vg.data_ptr(),
+                                           self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr(),
+                                           self.hstep.data_ptr() if self.hstep is not None else None,
+                                           self.stats.data_ptr(), self._stream())
             if timed:
                 ev1.record()
                 self._events.append((ev0, ev1))
@@ -460,6 +519,42 @@ class PVDERVec(EnvSpecMixin):
             if not return_tensors:
                 return None
             return self.obs, self.out[11], self.out[12] != 0, {}
+
+    def rollout(self, actions: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """``K`` transitions from ONE host call: ``actions`` is a [K, N] uint8 device tensor (row k =
+        the actions of step k -- an open-loop action sequence: recorded actions, fixed policies of
+        ``calc_returns``, the synthetic random-action rollouts of bench.py).  The same fused launch as
+        ``step``, enqueued K times by the C side (pvder_plan_rollout): per-step results land in
+        ``out[k]`` ([K, 13, N]) when given, otherwise every step overwrites ``self.out``."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before rollout()")
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs:
+            raise ValueError("actions must have shape (K, %d)" % self.num_envs)
+        if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        K = int(actions.shape[0])
+        stride = 0
+        dst = self.out
+        if out is not None:
+            if tuple(out.shape) != (K, 13, self.num_envs) or out.dtype != self.out.dtype or not out.is_contiguous() \
+                    or out.device != self.device:
+                raise ValueError("out must be a contiguous %s tensor of shape (%d, 13, %d)" % (self.out.dtype, K, self.num_envs))
+            dst, stride = out, 13 * self.num_envs
+        if self._traj is not None:
+            for k in range(K):            # trajectory capture copies after every step
+                self.step(actions[k], return_tensors=False)
+                if out is not None:
+                    out[k].copy_(self.out)
+            return
+        plan = self._plan or self._make_plan()
+        with self._device_ctx():
+            rc = self._lib.pvder_plan_rollout(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self.ev_vg.data_ptr(),
+                                              self.ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
+                                              self.hstep.data_ptr() if self.hstep is not None else None,
+                                              self.stats.data_ptr(), self._stream())
+            _native.check(rc, "pvder_plan_rollout")
+            if out is not None and K > 0:
+                self.out.copy_(out[K - 1])
 
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,
@@ -487,6 +582,9 @@ class PVDERVec(EnvSpecMixin):
         if self.hstep is not None:
             self.hstep.copy_(d["hstep"])
         self._needs_reset = False
+        if self._plan is None:
+            with self._device_ctx():
+                self._make_plan()
 
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------
     _timing = False
@@ -501,6 +599,24 @@ class PVDERVec(EnvSpecMixin):
         self._timing_every = max(1, int(every))
         self._timing_k = 0
         self._events = []
+
+    _event_pool: List[tuple] = []
+
+    def reserve_timing_events(self, n: int):
+        """Create (and warm) ``n`` event pairs now: the first use of a torch event costs tens of
+        microseconds of host time, which a short timed window should not pay inside the window."""
+        with self._device_ctx():
+            self._event_pool = []
+            for _ in range(int(n)):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); b.record()
+                self._event_pool.append((a, b))
+            torch.cuda.synchronize(self.device)
+
+    def _event_pair(self):
+        if self._event_pool:
+            return self._event_pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def kernel_times_ms(self) -> List[float]:
         """Durations of the step-kernel launches recorded since kernel_timing(True) (host sync)."""

@@ -1,0 +1,195 @@
+"""CPU tests (-m "not gpu") of the host side of the etdlin integrator (gym_PVDER_amd/etd_linear.py):
+the balanced right-hand side against the oracle's, the phi-functions against two independent
+routes, the f-form rewrite against the textbook N-form, the step-size menu, and an fp32 emulation of
+the kernel arithmetic against the goldens."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from gym_PVDER_amd import der_model, etd_linear as el
+from oracle import pvder_model as pm
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def lin50():
+    par = der_model.param_vector("50")
+    L, ystar = el.jacobian(par, "50")
+    return par, el.folded(par), L, ystar
+
+
+def expand(y11, ph=3):
+    """balanced 11-state vector -> the oracle's 23-state order (phases b, c rotated by -/+120 degrees)."""
+    rot = [1.0, np.exp(-2j * np.pi / 3), np.exp(2j * np.pi / 3)][:ph]
+    out = []
+    for r in rot:
+        for k in range(3):
+            z = complex(y11[2 * k], y11[2 * k + 1]) * r
+            out += [z.real, z.imag]
+    return np.array(out + list(y11[6:]))
+
+
+@pytest.mark.parametrize("der_id", ["50", "10"])
+def test_balanced_rhs_equals_oracle_rhs(der_id):
+    par = der_model.param_vector(der_id)
+    c = el.folded(par)
+    m = pm.build_model(der_id)
+    ph = c["PH"]
+    rng = np.random.default_rng(0)
+    y0 = der_model.steady_state(par, der_id)
+    base = np.concatenate([y0[:6], y0[6 * ph:]])
+    for _ in range(20):
+        y = base * (1 + 0.05 * rng.standard_normal(11))
+        y[4:6] = 1e-6 * rng.standard_normal(2)
+        y[10] = rng.uniform(0, 7)
+        # (inputs kept inside the limits: the oracle's anti-windup branches are not part of the balanced fast path)
+        vg, si, q, v = rng.uniform(0.95, 1.05), rng.uniform(60, 100), rng.uniform(-0.1, 0.1), y[6] + rng.uniform(-2e-3, 2e-3)
+        got = el.f_bal(c, y, vg, si, q, v)
+        want = np.array(pm.rhs(m, expand(y, ph), 0.0, vg, si, q, v))          # t = 0: delta == wte
+        want[-1] -= 2 * np.pi * 60                                           # relative angle
+        ref = np.concatenate([want[:6], want[6 * ph:]])
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-7 * np.abs(ref).max()), np.abs(got - ref).max()
+
+
+def test_operating_point_and_spectrum(lin50):
+    par, c, L, ystar = lin50
+    f = el.f_bal(c, ystar, 1.0, par[der_model.IDX["SINSOL0"]], 0.0, par[der_model.IDX["VDC_REF0"]])
+    assert np.abs(f[[2, 3, 6, 7, 8, 9, 10]]).max() < 1e-9
+    ev = np.linalg.eigvals(L)
+    assert ev.real.max() < -0.3                      # locked PLL: every mode is stable
+    assert np.sum(np.abs(ev) > 5e5) == 4             # the stiff current loop
+    assert np.any(np.abs(ev + 88.4) < 1.0)           # PLL pole
+
+
+@pytest.mark.parametrize("h", [1 / 1920, 1 / 60, 479 / 1920])
+def test_phi_functions_three_routes(lin50, h):
+    from scipy.linalg import expm as sp_expm
+    _, _, L, _ = lin50
+    a, b = el.phis(L, h), el.phis_eig(L, h)
+    n = L.shape[0]
+    M = np.zeros((4 * n, 4 * n)); M[:n, :n] = h * L
+    for j in range(3):
+        M[j * n:(j + 1) * n, (j + 1) * n:(j + 2) * n] = np.eye(n)
+    E = sp_expm(M)
+    for k in range(4):
+        assert np.abs(a[k] - b[k]).max() < 1e-8
+        assert np.abs(a[k] - E[:n, k * n:(k + 1) * n]).max() < 1e-8
+    assert np.allclose(el.expm(np.zeros((3, 3))), np.eye(3))
+
+
+def test_f_form_nonstiff_limit_is_kuttas_third_order_method():
+    h = 0.1
+    M21, M31, M32, M41, M42, M43 = el.etd3rk_f_matrices(np.zeros((11, 11)), h)
+    I = np.eye(11)
+    for M, w in ((M21, h / 2), (M31, -h), (M32, 2 * h), (M41, h / 6), (M42, 2 * h / 3), (M43, h / 6)):
+        assert np.allclose(M, w * I, atol=1e-14)
+
+
+def test_f_form_equals_n_form(lin50):
+    par, c, L, ystar = lin50
+    rng = np.random.default_rng(1)
+    inp = (1.01, 92.0, 0.03, par[der_model.IDX["VDC_REF0"]] * 1.002)
+    for h in (1 / 1920, 479 / 1920):
+        y = ystar * (1 + 1e-3 * rng.standard_normal(11))
+        mats = el.etd3rk_f_matrices(L, h)
+        got, b = el.etd3rk_step(c, mats, y, inp)
+        Es, A, E, B = el.etd3rk_tableau(L, h)
+        N = lambda u: el.f_bal(c, u, *inp) - L @ u
+        N1 = N(y); U2 = Es[1] @ y + A[1][0] @ N1
+        N2 = N(U2); U3 = Es[2] @ y + A[2][0] @ N1 + A[2][1] @ N2
+        N3 = N(U3)
+        want = E @ y + B[0] @ N1 + B[1] @ N2 + B[2] @ N3
+        assert np.allclose(got, want, rtol=0, atol=2e-9)
+        assert np.allclose(b, U3, rtol=0, atol=2e-9)
+    assert all(not np.any(M) for M in el.etd3rk_f_matrices(L, 0.0))
+
+
+@pytest.mark.parametrize("n_sub,micro,s0,ds", [(15, 32, 60, 60), (4, 32, 60, 60), (15, 32, 12, 12), (1, 32, 60, 60),
+                                                (7, 16, 5, 3), (60, 32, 60, 60), (15, 1, 60, 60)])
+def test_step_menu_tiles_every_segment(n_sub, micro, s0, ds):
+    lens = el.choose_sets(n_sub, micro, s0, ds, 38, 2400)
+    assert lens[0] == 1 and 2 <= len(lens) <= 8
+    assert lens[1:] == sorted(set(lens[1:]), reverse=True)
+    whole = lambda t: t % micro == 0
+    short1 = lambda t: not whole(t) and (t + 1) % micro == 0
+
+    def walk(rem, cap=None):
+        """the kernel's rule (csrc step_etdlin_kernel): after the tick the env is one tick behind a
+        boundary; largest eligible length -- whole steps always, one-tick-short ones while behind,
+        anything else only while redoing a rejected step (cap)"""
+        steps, behind = 0, True
+        while rem > 0:
+            lim = rem if cap is None else min(rem, cap)
+            fit = [t for t in lens[1:] if t <= lim and (whole(t) or (short1(t) and behind) or
+                                                          (not whole(t) and not short1(t) and cap is not None))]
+            assert fit, (rem, cap, lens)
+            rem -= fit[0]
+            behind = behind and not short1(fit[0])
+            steps += 1
+        return steps
+
+    for L in range(1, n_sub + 1):                    # segment of L sim time steps: one tick, then the walk
+        steps = 1 + walk(L * micro - 1)
+        assert steps <= 3 + 2 * int(np.log2(max(L, 1))) + (micro if micro == 1 else 0) + 1, (L, steps)
+        ok = [t for t in lens[1:] if t <= L * micro - 1 and (whole(t) or short1(t))]
+        first = ok[0] if ok else 0
+        if first > 1 and (first + 1) // 2 in lens[1:] and first // 2 in lens[1:]:
+            walk(L * micro - 1, cap=(first + 1) // 2)        # that step rejected: redone under the cap
+    if micro > 1 and ds % n_sub == 0 and s0 % n_sub == 0:
+        t = n_sub * micro - 1                        # events on env-step boundaries: TWO steps per env step,
+        assert t in lens[1:] or n_sub == 1           # and a rejected one is redone in exactly two halves
+        if t > 1 and n_sub > 1:
+            assert walk(t, cap=(t + 1) // 2) == 2
+
+
+@pytest.mark.parametrize("name", ["random_both_n15", "random_both_n4", "vdcalt_both_n15"])
+def test_fp32_emulation_of_the_kernel_arithmetic_vs_golden(lin50, name):
+    """The kernel's scheme in numpy float32 (two steps per segment: one tick, then the rest) against
+    the converged golden: pins the ALGORITHM's accuracy on the CPU (the -m gpu tests pin the kernel)."""
+    par, c, L, _ = lin50
+    g = np.load(os.path.join(GOLD, "traj_%s.npz" % name))
+    n, acts, vgt, sit = int(g["n"]), g["actions"], g["vgrid"], g["sinsol"]
+    K = len(vgt) - 1
+    s0, ds = int(round(float(g["ev_t0"]) * 60)), int(round(float(g["ev_dt"]) * 60))
+    y0f = der_model.steady_state(par, "50")
+    y = np.concatenate([y0f[:6], y0f[18:]]).astype(np.float32)
+    f32 = np.float32
+    q, v = f32(0.0), f32(par[der_model.IDX["VDC_REF0"]])
+    dq, dv = f32(25.0 * n / 50e3), f32(0.02 * n / 500.0)
+    cache = {}
+    P1 = (1 / 1920.0) * el.phis(L, 1 / 1920.0, 1)[1]
+
+    def mats(h):
+        if h not in cache:
+            cache[h] = el.etd3rk_f_matrices(L, h)
+        return cache[h]
+
+    def observe(y, vg, si, q, v):
+        y = y.astype(np.float64)
+        i = complex(y[0], y[1]); va = complex(c["GR"], c["GI"]) * vg + complex(c["kviR"], c["kviI"]) * i
+        S = 0.5 * c["PH"] * va * i.conjugate()
+        ppv = max(0.0, y[6] * (c["pvA"] * si + c["pvB"] - c["pvB"] * np.exp(c["pvK"] * y[6])))
+        return np.array([i.real, i.imag, va.real, va.imag, S.real, S.imag, y[6], ppv, v, q])
+
+    rowof = lambda gk: 0 if gk < s0 else min((gk - s0) // ds + 1, K)
+    out, ksub, est = [observe(y, vgt[0], sit[0], q, v)], 0, 0.0
+    for a in acts:
+        q = f32(q + dq * (int(a == 1) - int(a == 2))); v = f32(v + dv * (int(a == 3) - int(a == 4)))
+        s = 0
+        while s < n:
+            row = rowof(ksub + s); e = s + 1
+            while e < n and rowof(ksub + e) == row:
+                e += 1
+            inp = (vgt[row], sit[row], q, v)
+            y = el.euler_tick(c, P1, y, inp, np.float32)                  # the tick behind the jump
+            y, b = el.etd3rk_step(c, mats(((e - s) * 32 - 1) / 1920.0), y, inp, np.float32)
+            est = max(est, float(np.abs((y - b)[[0, 1, 6]]).max()))
+            s = e
+        ksub += n
+        out.append(observe(y, vgt[rowof(ksub)], sit[rowof(ksub)], q, v))
+    got, want = np.array(out), g["obs"][:len(out), :10]
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-5
+    assert est < el.EST_GUARD                        # these cases stay clear of the hand-over guard
