@@ -19,13 +19,12 @@
 namespace pvder {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const v4f lds_cv4;
 
 constexpr int kLinN = 11;                 // states of the balanced reduction
-constexpr int kLinRows = 12;              // matrix rows padded to pairs
-constexpr int kLinMatFloats = kLinN * kLinRows;          // 132: column-major, column k = 12 floats
+constexpr int kLinRows = 12;              // matrix padded to 12 x 12 (three row groups of four; 16-byte rows)
+constexpr int kLinMatFloats = kLinRows * kLinRows;       // 144: row-major, row i = 12 floats (columns 0..10 + pad)
 constexpr int kLinMats = 6;               // M21 | M31 M32 | M41 M42 M43
-constexpr int kLinSetFloats = kLinMats * kLinMatFloats;  // 792 floats = 3168 B per step size
+constexpr int kLinSetFloats = kLinMats * kLinMatFloats;  // 864 floats = 3456 B per step size
 constexpr int kLinMaxSets = 8;
 enum { LM21 = 0, LM31, LM32, LM41, LM42, LM43 };
 
@@ -70,28 +69,67 @@ __device__ __forceinline__ void bal_f(const ModelK<float> &P, const PkConst &K, 
     m2 = __builtin_fmaf(ma.y, ma.y, ma.x * ma.x);
 }
 
-// acc[j] += M_j f  for NM matrices that share the input vector f (six pairs; entry 11 is padding).
-// `set` = LDS address of the lane's coefficient set; mat[j] = matrix number inside the set.  Per
-// column k: 3 ds_read_b128 (12 rows) and 6 v_pk_fma_f32 per matrix, f_k broadcast to both halves by
-// op_sel.  The accumulator chains of different rows / matrices are independent.
-template <int NM>
-__device__ __forceinline__ void lin_matvec(const lds_cv4 *set, const int (&mat)[NM], const v2 *__restrict__ f,
-                                           v2 (&acc)[NM][6]) {
+// ---- matrix-vector products on the matrix cores ------------------------------------------------------
+// out = M f  with a DENSE 12x11 matrix M shared by all envs and f = one vector per env (lane) is a GEMM
+// with a shared left operand: [12 x 11] x [11 x 64 lanes].  v_mfma_f32_4x4x1_16b_f32 computes, for each of
+// its 16 blocks of 4 lanes, the outer product  D[r][j] += A[r] * B[j]  (r = row = accumulator register,
+// j = lane within the block).  With B = f_k exactly as it sits in its VGPR (one env per lane) and
+// A = M[4g + r][k] in lane r of block 0, BROADCAST to all 16 blocks by the instruction itself
+// (cbsz = 4, abid = 0), the four accumulator registers of row group g receive rows 4g..4g+3 of  M f
+// for the lane's own env -- the layout the rest of the kernel uses, no shuffles.  One MFMA does the
+// work of two v_pk_fma_f32 + their operand read, on the otherwise idle matrix pipe, and each element
+// is ONE fused multiply-add in the same k order a VALU chain would use (tools/mfma_probe.hip:
+// bit-identical to fmaf; broadcast semantics checked there too).  fp32 in, fp32 out: no precision is
+// traded.  The A operands of a coefficient set (6 matrices x 3 row groups x 11 columns = 198
+// registers, only lanes 0..3 of which carry data) are read once -- three 16-byte loads per matrix row,
+// by four lanes -- and stay in the register file (512 VGPRs + AGPRs at one wave per SIMD).
+typedef float LinSetRegs[kLinMats][3][kLinRows];
+typedef float LinMatRegs[3][kLinRows];
+
+// lanes 0..3: row 4g + lane of the matrix (row-major, 12 floats per row); other lanes: not read by the MFMA
+__device__ __forceinline__ void lin_load_mat(const float *__restrict__ m, int lane, LinMatRegs &A) {
+    if (lane < 4) {
 #pragma unroll
-    for (int k = 0; k < kLinN; ++k) {
-        const v2 fb = bc2((k & 1) ? f[k >> 1].y : f[k >> 1].x);
-#pragma unroll
-        for (int j = 0; j < NM; ++j) {
-            const lds_cv4 *col = set + (mat[j] * kLinMatFloats + k * kLinRows) / 4;
-            const v4f c0 = col[0], c1 = col[1], c2 = col[2];
-            acc[j][0] = fma2(mk2(c0.x, c0.y), fb, acc[j][0]);
-            acc[j][1] = fma2(mk2(c0.z, c0.w), fb, acc[j][1]);
-            acc[j][2] = fma2(mk2(c1.x, c1.y), fb, acc[j][2]);
-            acc[j][3] = fma2(mk2(c1.z, c1.w), fb, acc[j][3]);
-            acc[j][4] = fma2(mk2(c2.x, c2.y), fb, acc[j][4]);
-            acc[j][5] = fma2(mk2(c2.z, c2.w), fb, acc[j][5]);
+        for (int g = 0; g < 3; ++g) {
+            const v4f *p = (const v4f *)(m + (4 * g + lane) * kLinRows);
+            const v4f a = p[0], b = p[1], c = p[2];
+            A[g][0] = a.x; A[g][1] = a.y; A[g][2] = a.z; A[g][3] = a.w;
+            A[g][4] = b.x; A[g][5] = b.y; A[g][6] = b.z; A[g][7] = b.w;
+            A[g][8] = c.x; A[g][9] = c.y; A[g][10] = c.z; A[g][11] = c.w;
         }
     }
+}
+__device__ __forceinline__ void lin_load_set(const float *__restrict__ set, int lane, LinSetRegs &A) {
+#pragma unroll
+    for (int m = 0; m < kLinMats; ++m) lin_load_mat(set + m * kLinMatFloats, lane, A[m]);
+}
+
+// acc[j] += M_mat[j] f  for NM matrices of the set that share the input vector f (six pairs)
+template <int NM>
+__device__ __forceinline__ void lin_mfma(const LinSetRegs &A, const int (&mat)[NM], const v2 *__restrict__ f,
+                                         v4f (&acc)[NM][3]) {
+#pragma unroll
+    for (int k = 0; k < kLinN; ++k) {
+        const float fk = (k & 1) ? f[k >> 1].y : f[k >> 1].x;
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[j][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[mat[j]][g][k], fk, acc[j][g], 4, 0, 0);
+    }
+}
+__device__ __forceinline__ void lin_mfma1(const LinMatRegs &A, const v2 *__restrict__ f, v4f (&acc)[3]) {
+#pragma unroll
+    for (int k = 0; k < kLinN; ++k) {
+        const float fk = (k & 1) ? f[k >> 1].y : f[k >> 1].x;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g][k], fk, acc[g], 4, 0, 0);
+    }
+}
+// state in accumulator layout (rows 0-3, 4-7, 8-11) -> the six pairs bal_f reads
+__device__ __forceinline__ void lin_pairs(const v4f (&Y)[3], v2 *__restrict__ y) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { y[2 * g] = mk2(Y[g].x, Y[g].y); y[2 * g + 1] = mk2(Y[g].z, Y[g].w); }
 }
 
 }  // namespace pvder

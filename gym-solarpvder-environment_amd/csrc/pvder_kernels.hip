@@ -41,8 +41,15 @@ __device__ unsigned long long g_trace[4096 * 32];
     do {                                                                                       \
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 32 + (slot)] = wall_clock64(); \
     } while (0)
+// ... after `val` (a float) has been computed
+#define PVDER_TRACE_DEP(slot, val)                                                             \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                             \
+            g_trace[blockIdx.x * 32 + (slot)] = wall_clock64() + ((val) > 1e30f ? 1 : 0);      \
+    } while (0)
 #else
 #define PVDER_TRACE_AT(slot) do { } while (0)
+#define PVDER_TRACE_DEP(slot, val) do { } while (0)
 #endif
 
 using pvder::ModelK;
@@ -1044,26 +1051,23 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
 // and advanced by the 23-state path at the end of the kernel -- but the integrator is ETD3RK on
 // dy/dt = L y + N(y) with L the FULL 11x11 Jacobian at the nominal operating point: the exponential
 // carries the whole linear response, so a segment between two input jumps (new action, new event
-// row) takes a first step of one tick = 1/(60*micro) s and then the LARGEST steps of the launch's
-// coefficient sets that fit -- for PVDER-v0 (events on env-step boundaries) two steps per env step.
+// row) takes an exponential-Euler tick of 1-2/(60*micro) s and then the ETD3RK steps the host's
+// schedule table lists for a segment of that length -- for PVDER-v0 (events on env-step boundaries)
+// two equal steps.  The matrix-vector products run on the matrix cores (MFMA, operands resident in
+// registers); the VALU only evaluates f.
 //
-// The step schedule is PER LANE (each env's own jump positions, its own coefficient set: LDS reads
-// with per-lane addresses, a broadcast while the envs of a wave run in lockstep); only the trip
-// count is wave-uniform (lanes that have arrived idle), so an env's trajectory does not depend on
-// which envs share its wave.
+// The step schedule is PER LANE (each env's own jump positions and table row); only the trip count
+// is wave-uniform (lanes that have arrived idle) and a wave whose lanes need different coefficient
+// sets makes one pass per distinct set, so an env's trajectory does not depend on which envs share
+// its wave (bit for bit: every lane's arithmetic is the same whatever its neighbours do).
 // =============================================================================================
 struct LinK {
-    const float *lcoef;              // device: tick matrix (kLinMatFloats) + (n_sets-1) * kLinSetFloats floats
-    int n_sets;
-    int len_ticks[pvder::kLinMaxSets];   // step length of set s in ticks; set 0 = the tick behind a jump (exponential
-                                     // Euler, one matrix), sets 1.. = ETD3RK sets sorted by decreasing length
-    float est_refine;                // an ETD3RK step whose indicator max |y+ - b| over (i_a, Vdc) exceeds this is
-                                     // redone as two steps of half the length (once) ...
-    int setmask;                     // ... if both halves of the set are in the menu.  Bits per set s (fill_plan):
-                                     // bit s: length = whole sim time steps; bit 8+s: one tick short of that (usable
-                                     // while the env is one tick behind a boundary); neither: a half, used only for
-                                     // redoing a rejected step; bit 16+s: both halves of set s are in the menu
-    float est_guard;                 // a step accepted above this hands the env to the 23-state path
+    const float *lcoef;              // device: tick matrix (kLinMatFloats) + (n_sets-1) * kLinSetFloats floats, read as
+                                     // MFMA A operands straight from memory (pvder_etdlin.hpp)
+    const unsigned long long *sched; // device: row L-1 = the ETD3RK sets (one byte each, 0 = end) a segment of L sim
+                                     // time steps takes behind its tick
+    float est_guard;                 // a step whose indicator max |y+ - b| over (i_a, Vdc) exceeds this hands the env
+                                     // to the 23-state path
 };
 struct LinArgs {
     EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
@@ -1076,47 +1080,61 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
     const EtdArgs &A = G.A;
     const ModelK<float> &P = A.P;
     const StepK<float> &C = A.C;
-    const ResetK &R = A.R;
     const EtdK &Ec = A.Ec;
     float *__restrict__ fstate = A.fstate;
     int32_t *__restrict__ istate = A.istate;
     float *__restrict__ ev_vg = A.ev_vg;
     float *__restrict__ ev_si = A.ev_si;
     const uint8_t *__restrict__ action = A.action;
-    float *__restrict__ out = A.out;
-    float *__restrict__ stats = A.stats;
-    const int stats_fresh = A.stats_fresh;
     const int n_env = A.n_env;
     constexpr int NS = 6 * PH + 5, B = 6 * PH;
     constexpr int kBig = 0x3fffffff;
     const size_t N = (size_t)n_env;
     PVDER_TRACE_AT(0);
-    // coefficient block: staged once per launch (16-byte loads), re-read every step with ds_read_b128.
-    // The step lengths too: eight more wave-uniform values do not fit the scalar register file next to
-    // the model constants (unused entries hold INT_MAX, see fill_plan).
-    __shared__ __attribute__((aligned(16))) float Llds[kLinMatFloats + (kLinMaxSets - 1) * kLinSetFloats];
-    __shared__ __attribute__((aligned(16))) int Llen[kLinMaxSets];
-    // the state rows first: their loads are in flight while the block is staged
+    // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
+    // first ETD3RK set stay in registers for the whole launch; another set replaces the latter only when
+    // an env needs it (an env off the event grid).  Issued FIRST (they depend on nothing but the kernel
+    // arguments), the state rows right behind them: one memory latency.
+    const int lane = threadIdx.x & 63;
+    LinMatRegs At;
+    LinSetRegs Ac;
+    lin_load_mat(G.Lk.lcoef, lane, At);
+    lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
+    int cur = 1;
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
-    {
-        const int nv4 = (kLinMatFloats + (G.Lk.n_sets - 1) * kLinSetFloats) / 4;
-        const v4 *src = (const v4 *)G.Lk.lcoef;
-        for (int k = threadIdx.x; k < nv4; k += kBlock) ((v4 *)Llds)[k] = src[k];
-        if (threadIdx.x < kLinMaxSets) Llen[threadIdx.x] = G.Lk.len_ticks[threadIdx.x];
+    // ---- first segment of the env step.  One integer division per launch gives the event row in force
+    // at ksub, whether an event starts exactly there, and `until` = sim time steps to the next event-row
+    // change.  ksub is the first state word to arrive: the event inputs and the schedule row of the
+    // segment are requested while the other state rows are still in flight.
+    int row = 0, until = kBig;
+    bool evjump = false;                 // the current segment starts at an EVENT (not just a new action)
+    if (C.ev_count > 0) {
+        const int d = L.ksub - C.ev_s0;
+        if (d < 0) {
+            until = -d;
+        } else {
+            const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
+            row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
+            evjump = rd == 0 && qd < C.ev_count;
+            until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
+        }
     }
-    __syncthreads();
+    int spos = 0;                        // sim time steps of the env step behind this lane
+    int seg = until < C.n_sub ? until : C.n_sub;
+    float in_vg = ev_vg[(size_t)row * N + L.ec], in_si = ev_si[(size_t)row * N + L.ec];
+    unsigned long long sch = G.Lk.sched[seg - 1];
     PVDER_TRACE_AT(1);
     bool defer = PH == 3 && A.force_full != 0;
     if (L.run) {
-        v2 y[6] = {mk2(ys[0], ys[1]), mk2(ys[2], ys[3]), mk2(ys[4], ys[5]), mk2(ys[B], ys[B + 1]),
-                   mk2(ys[B + 2], ys[B + 3]), mk2(ys[B + 4], 0.f)};
+        v4f Y[3] = {{ys[0], ys[1], ys[2], ys[3]}, {ys[4], ys[5], ys[B], ys[B + 1]}, {ys[B + 2], ys[B + 3], ys[B + 4], 0.f}};
         if constexpr (PH == 3) {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
-            const float ei = unbalance2(y[0], mk2(ys[6], ys[7]), mk2(ys[12], ys[13]));
-            const float ex = unbalance2(y[1], mk2(ys[8], ys[9]), mk2(ys[14], ys[15]));
-            const float eu = unbalance2(y[2], mk2(ys[10], ys[11]), mk2(ys[16], ys[17]));
-            const v2 i2 = y[0] * y[0], x2 = y[1] * y[1];
+            const v2 ia = mk2(ys[0], ys[1]), xa = mk2(ys[2], ys[3]), ua = mk2(ys[4], ys[5]);
+            const float ei = unbalance2(ia, mk2(ys[6], ys[7]), mk2(ys[12], ys[13]));
+            const float ex = unbalance2(xa, mk2(ys[8], ys[9]), mk2(ys[14], ys[15]));
+            const float eu = unbalance2(ua, mk2(ys[10], ys[11]), mk2(ys[16], ys[17]));
+            const v2 i2 = ia * ia, x2 = xa * xa;
             defer |= ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
         }
         const PkConst K = make_pkconst(P);
@@ -1126,158 +1144,125 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
         const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
         float i2m = Ec.i2_to_m2;
         asm volatile("" : "+v"(i2m));
-        // ---- per-lane schedule, in ticks of 1/(60*micro) s.  One integer division per launch gives the
-        // event row in force at ksub, whether an event starts exactly there, and `until` = sim time steps
-        // from the start of the current segment to the next event-row change.
-        const int micro = C.micro;
-        const int end = C.n_sub * micro;
-        int row = 0, until = kBig;
-        bool evjump = false;                 // the current segment starts at an EVENT (not just a new action)
-        if (C.ev_count > 0) {
-            const int d = L.ksub - C.ev_s0;
-            if (d < 0) {
-                until = -d;
-            } else {
-                const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
-                row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
-                evjump = rd == 0 && qd < C.ev_count;
-                until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
-            }
-        }
-        int pos = 0, seg_end = 0, spos = 0, cap = kBig;
-        bool behind = false;
+        bool start = true;                   // this lane is at the start of a segment (its tick is due)
+        bool done = false;
         SubPk S;
         PVDER_TRACE_AT(2);
         for (int it = 0;; ++it) {
-            const bool active = pos < end;
-            if (!__builtin_amdgcn_readfirstlane(__any((int)(active && !defer)))) break;
+            if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
             if (it < 16) PVDER_TRACE_AT(3 + it);
-            typedef int i4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(3))) const i4 lds_ci4;
-            const lds_ci4 *lt = (const lds_ci4 *)Llen;
-            asm volatile("" : "+v"(lt));
-            const i4 l0 = lt[0], l1 = lt[1];
-            const int lens[kLinMaxSets] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-            v2 F[6];
+            v2 yp[6], F[6];
             float m2a, ir2a;
-            const bool newseg = active && pos == seg_end;
-            if (__builtin_amdgcn_readfirstlane(__any((int)newseg))) {
-                // ---- a segment starts (new action at pos 0, or a new event row): inputs, then the TICK
-                if (newseg) {
-                    if (pos > 0) {                       // an event row starts here
+            if (__builtin_amdgcn_readfirstlane(__any((int)(start && !done)))) {
+                // ---- a segment starts (new action at the start of the env step, or a new event row): the
+                // TICK behind the jump, exponential Euler  y+ = y + h phi1(hL) f(y).  The jump kicks the stiff
+                // loop; the exponential carries that transient exactly, and over one tick the rest of f
+                // hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  An EVENT may make
+                // |m| overshoot inside the tick: 3 % clearance there (see make_etd).
+                // (lanes in the middle of a segment recompute S from the inputs they hold: same values)
+                make_sub_pk(P, in_vg, in_si, S);
+                lin_pairs(Y, yp);
+                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
+                v4f acc[3] = {Y[0], Y[1], Y[2]};
+                lin_mfma1(At, F, acc);
+                const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
+                const float guard = evjump ? Ec.sat2_event : Ec.sat2_smooth;
+                const bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+                if (start && !done) {
+                    defer |= trip;
+                    Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
+                    start = false;
+                }
+            }
+            // ---- the segment's next ETD3RK step (schedule row: one set index per byte, 0 = segment finished)
+            const int sidx = (int)(sch & 0xffull);
+            bool todo = !done && sidx != 0;
+            // One pass per DISTINCT set among the wave's lanes: a single pass while the envs run in lockstep
+            for (;;) {
+                const unsigned long long tm = __ballot((int)todo);
+                if (tm == 0) break;
+                const int s_now = __builtin_amdgcn_readlane(sidx, (int)__builtin_ctzll(tm));
+                if (s_now != cur) {
+                    lin_load_set(G.Lk.lcoef + kLinMatFloats + (size_t)(s_now - 1) * kLinSetFloats, lane, Ac);
+                    cur = s_now;
+                }
+                float m2x, ir2x, m2b;
+                lin_pairs(Y, yp);
+                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
+                if (it == 1) PVDER_TRACE_DEP(24, F[0].x + F[2].y + F[3].x + F[5].x);
+                v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
+                {
+                    const int m3[3] = {LM21, LM31, LM41};
+                    lin_mfma<3>(Ac, m3, F, acc3);                     // a = y + M21 F1; b, y+ started
+                }
+                if (it == 1) PVDER_TRACE_DEP(25, acc3[0][0].x + acc3[1][1].x + acc3[2][2].x);
+                lin_pairs(acc3[0], yp);
+                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2x, ir2x);
+                if (it == 1) PVDER_TRACE_DEP(26, F[0].x + F[2].y + F[3].x + F[5].x);
+                v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
+                {
+                    const int m2[2] = {LM32, LM42};
+                    lin_mfma<2>(Ac, m2, F, acc2);                     // b complete
+                }
+                if (it == 1) PVDER_TRACE_DEP(27, acc2[0][0].x + acc2[1][1].x);
+                lin_pairs(acc2[0], yp);
+                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2b, ir2x);
+                if (it == 1) PVDER_TRACE_DEP(28, F[0].x + F[2].y + F[3].x + F[5].x);
+                v4f acc1[1][3] = {{acc2[1][0], acc2[1][1], acc2[1][2]}};
+                {
+                    const int m1[1] = {LM43};
+                    lin_mfma<1>(Ac, m1, F, acc1);                     // y+
+                }
+                if (it == 1) PVDER_TRACE_DEP(29, acc1[0][0].x + acc1[0][2].x);
+                // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
+                const float est = fmaxf(fmaxf(fabsf(acc1[0][0].x - acc2[0][0].x), fabsf(acc1[0][0].y - acc2[0][0].y)),
+                                        fabsf(acc1[0][1].z - acc2[0][1].z));
+                const v2 mn = fma2(bc2(P.KpG), mk2(acc1[0][1].x, acc1[0][1].y), mk2(acc1[0][0].z, acc1[0][0].w));
+                // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
+                const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+                const bool trip = fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
+                if (todo && sidx == s_now) {
+                    defer |= trip;
+                    Y[0] = acc1[0][0]; Y[1] = acc1[0][1]; Y[2] = acc1[0][2];
+                    sch >>= 8;
+                    todo = false;
+                }
+            }
+            // ---- segment finished?  Then the next one (if any) starts at an event row change
+            const bool fin = !done && !start && (sch & 0xffull) == 0;
+            if (__builtin_amdgcn_readfirstlane(__any((int)fin))) {
+                if (fin) {
+                    spos += seg;
+                    until -= seg;
+                    done = spos >= C.n_sub;
+                    if (!done) {                         // an event row starts here
                         row += 1;
                         until = row < C.ev_count ? C.ev_ds : kBig;
                         evjump = true;
+                        const int left = C.n_sub - spos;
+                        seg = until < left ? until : left;
+                        in_vg = ev_vg[(size_t)row * N + L.ec];
+                        in_si = ev_si[(size_t)row * N + L.ec];
+                        sch = G.Lk.sched[seg - 1];
+                        start = true;
                     }
-                    const int left = C.n_sub - spos;
-                    const int seg = until < left ? until : left;
-                    until -= seg;
-                    spos += seg;
-                    seg_end = pos + seg * micro;
-                    cap = kBig;
-                }
-                // (lanes that stay in their segment re-read the row they have: same values)
-                make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
-                // the tick behind the jump: exponential Euler, y+ = y + h phi1(hL) f(y).  The jump kicks the
-                // stiff loop; the exponential carries that transient exactly, and over one tick the rest of
-                // f hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  An EVENT may
-                // make |m| overshoot inside the tick: 3 % clearance there (see make_etd).
-                const lds_cv4 *tk = (const lds_cv4 *)Llds;
-                asm volatile("" : "+v"(tk));
-                bal_f<PH>(P, K, S, y, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
-                v2 acc1[1][6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) acc1[0][q] = y[q];
-                const int m1[1] = {0};
-                lin_matvec<1>(tk, m1, F, acc1);
-                const v2 mn = fma2(bc2(P.KpG), acc1[0][2], acc1[0][1]);
-                const float guard = evjump ? Ec.sat2_event : Ec.sat2_smooth;
-                const bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
-                if (newseg) {
-                    defer |= trip;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) y[q] = acc1[0][q];
-                    pos += lens[0];
-                    evjump = false;
-                    behind = true;                        // one tick past a sim-time-step boundary
-                }
-            }
-            // ---- ETD3RK in f-form with the largest step that fits the segment (and the cap a rejected
-            // step left behind)
-            const bool stepping = pos < seg_end;          // (a segment of one tick is finished already)
-            const int rem = seg_end - pos;
-            const int lim = rem < cap ? rem : cap;
-            int sidx = 1, len = 0;
-            const int sm = G.Lk.setmask;
-#pragma unroll
-            for (int s = kLinMaxSets - 1; s >= 1; --s) {        // largest eligible length (sets sorted by decreasing length)
-                const bool whole = (sm >> s) & 1, short1 = (sm >> (8 + s)) & 1;
-                const bool ok = whole || (short1 && behind) || (!whole && !short1 && cap != kBig);
-                if (lens[s] <= lim && ok) { sidx = s; len = lens[s]; }
-            }
-            const lds_cv4 *set = (const lds_cv4 *)(Llds + kLinMatFloats) + (sidx - 1) * (kLinSetFloats / 4);
-            asm volatile("" : "+v"(set));
-            float m2x, ir2x, m2b;
-            bal_f<PH>(P, K, S, y, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
-            v2 acc3[3][6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { acc3[0][q] = y[q]; acc3[1][q] = y[q]; acc3[2][q] = y[q]; }
-            {
-                const int m3[3] = {LM21, LM31, LM41};
-                lin_matvec<3>(set, m3, F, acc3);                      // a = y + M21 F1; b, y+ started
-            }
-            bal_f<PH>(P, K, S, acc3[0], L.qref, L.vdcref, kpo, kio, F, m2x, ir2x);
-            v2 acc2[2][6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { acc2[0][q] = acc3[1][q]; acc2[1][q] = acc3[2][q]; }
-            {
-                const int m2[2] = {LM32, LM42};
-                lin_matvec<2>(set, m2, F, acc2);                      // b complete
-            }
-            bal_f<PH>(P, K, S, acc2[0], L.qref, L.vdcref, kpo, kio, F, m2b, ir2x);
-            v2 acc1[1][6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) acc1[0][q] = acc2[1][q];
-            {
-                const int m1[1] = {LM43};
-                lin_matvec<1>(set, m1, F, acc1);                      // y+
-            }
-            // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
-            const v2 di = acc1[0][0] - acc2[0][0];
-            const float est = fmaxf(fmaxf(fabsf(di.x), fabsf(di.y)), fabsf(acc1[0][3].x - acc2[0][3].x));
-            const v2 mn = fma2(bc2(P.KpG), acc1[0][2], acc1[0][1]);
-            // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
-            const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
-            const bool trip = fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
-            // a step whose indicator is too large is redone as two of half the length -- once
-            const bool retry = cap == kBig && est > G.Lk.est_refine && ((sm >> (16 + sidx)) & 1) != 0;
-            if (stepping) {
-                if (len == 0) {
-                    defer = true;                         // (a menu that cannot tile this segment: 23-state path)
-                } else if (retry) {
-                    cap = (len + 1) >> 1;
-                } else {
-                    defer |= trip;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) y[q] = acc1[0][q];
-                    pos += len;
-                    if ((sm >> (8 + sidx)) & 1) behind = false;      // back on a sim-time-step boundary
                 }
             }
         }
         if (!defer) {
             const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);
+            const v2 z3[3] = {mk2(Y[0].x, Y[0].y), mk2(Y[0].z, Y[0].w), mk2(Y[1].x, Y[1].y)};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                ys[2 * k] = y[k].x; ys[2 * k + 1] = y[k].y;
+                ys[2 * k] = z3[k].x; ys[2 * k + 1] = z3[k].y;
                 if constexpr (PH == 3) {
-                    const v2 hz = bc2(-0.5f) * y[k], jz = swp(y[k]) * jh3;
+                    const v2 hz = bc2(-0.5f) * z3[k], jz = swp(z3[k]) * jh3;
                     const v2 zb = hz - jz, zc = hz + jz;
                     ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
                     ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
                 }
             }
-            ys[B] = y[3].x; ys[B + 1] = y[3].y; ys[B + 2] = y[4].x; ys[B + 3] = y[4].y; ys[B + 4] = y[5].x;
+            ys[B] = Y[1].z; ys[B + 1] = Y[1].w; ys[B + 2] = Y[2].x; ys[B + 3] = Y[2].y; ys[B + 4] = Y[2].z;
             L.ksub += C.n_sub;
             L.steps += 1;
         }
@@ -1686,29 +1671,14 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
     if (integrator == PVDER_INT_ETDLIN) {
-        if (!lin || !lin->sets || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
-        if (lin->len_ticks[0] < 1 || !(lin->est_guard > 0.f) || !(lin->est_refine > 0.f)) return PVDER_EINVAL;
-        for (int s = 1; s < lin->n_sets; ++s)       // sorted by decreasing length
-            if (lin->len_ticks[s] < 1 || (s > 1 && lin->len_ticks[s] >= lin->len_ticks[s - 1])) return PVDER_EINVAL;
+        if (!lin || !lin->sets || !lin->sched || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
+        if (lin->len_ticks[0] < 1 || !(lin->est_guard > 0.f)) return PVDER_EINVAL;
+        for (int s = 1; s < lin->n_sets; ++s)
+            if (lin->len_ticks[s] < 1) return PVDER_EINVAL;
         LinK &K = p.lin.Lk;
         K.lcoef = lin->sets;
-        K.n_sets = lin->n_sets;
-        for (int s = 0; s < pvder::kLinMaxSets; ++s) K.len_ticks[s] = s < lin->n_sets ? lin->len_ticks[s] : 0x7fffffff;
+        K.sched = (const unsigned long long *)lin->sched;
         K.est_guard = lin->est_guard;
-        K.est_refine = lin->est_refine;
-        K.setmask = 0;
-        const int tick0 = lin->len_ticks[0];
-        for (int s = 1; s < lin->n_sets; ++s) {
-            const int len = lin->len_ticks[s];
-            if (len % cfg->micro == 0) K.setmask |= 1 << s;                       // whole sim time steps
-            else if ((len + tick0) % cfg->micro == 0) K.setmask |= 1 << (8 + s);  // ... minus the tick
-            bool hi = false, lo = false;
-            for (int q = 1; q < lin->n_sets; ++q) {
-                hi |= lin->len_ticks[q] == (len + 1) / 2;
-                lo |= lin->len_ticks[q] == len / 2;
-            }
-            if (len > 1 && hi && lo) K.setmask |= 1 << (16 + s);                  // can be redone as two halves
-        }
     }
     return 0;
 }

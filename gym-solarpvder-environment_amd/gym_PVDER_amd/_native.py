@@ -59,7 +59,7 @@ class AutoReset(C.Structure):
 class LinCoef(C.Structure):
     """``struct pvder_lin_coef`` (include/pvder_hip.h)."""
     _fields_ = [("sets", C.c_void_p), ("n_sets", C.c_int32), ("len_ticks", C.c_int32 * LIN_MAX_SETS),
-                ("est_refine", C.c_float), ("est_guard", C.c_float)]
+                ("sched", C.c_void_p), ("est_guard", C.c_float)]
 
 
 def hipcc_path() -> str:

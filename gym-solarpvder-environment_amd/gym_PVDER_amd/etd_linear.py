@@ -231,10 +231,10 @@ def etd3rk_f_matrices(L: np.ndarray, h: float) -> List[np.ndarray]:
 
 
 def pack_matrix(M: np.ndarray) -> np.ndarray:
-    """[NB, NB] -> flat [NB * ROWS_PAD] fp32, column-major with the rows padded to 12: the kernel
-    multiplies column k (12 floats = 3 ds_read_b128, row pairs (2r, 2r+1) adjacent) by f_k."""
-    out = np.zeros((NB, ROWS_PAD), dtype=np.float32)
-    out[:, :NB] = M.T.astype(np.float32)
+    """[NB, NB] -> flat [12 * 12] fp32, row-major, rows and columns padded to 12: the kernel reads row
+    4g + r as the MFMA A operands of row group g (three 16-byte loads by lane r)."""
+    out = np.zeros((ROWS_PAD, ROWS_PAD), dtype=np.float32)
+    out[:NB, :NB] = M.astype(np.float32)
     return out.reshape(-1)
 
 
@@ -243,7 +243,7 @@ def pack_sets(L: np.ndarray, hs: Sequence[float]) -> np.ndarray:
     return np.concatenate([pack_matrix(M) for h in hs for M in etd3rk_f_matrices(L, float(h))])
 
 
-MAT_FLOATS = NB * ROWS_PAD
+MAT_FLOATS = ROWS_PAD * ROWS_PAD
 SET_FLOATS = N_STAGE_MATS * MAT_FLOATS
 
 
@@ -268,26 +268,29 @@ def etd3rk_step(c, mats: Sequence[np.ndarray], y, inputs, dtype=np.float64):
 # ---------------------------------------------------------------------------------------------------
 # step-size menu of a launch
 # ---------------------------------------------------------------------------------------------------
-EST_REFINE = 1e-2     # |y+ - b| over (i_a, Vdc) above which an ETD3RK step is redone as two half steps.  The indicator
-#                       runs ~70x above the true error of the step (DESIGN.md "etdlin": 1e-2 <-> 1.4e-4 for the
-#                       largest insolation events of PVDER-v0 rollouts, median 2e-4 <-> 3e-6); halving divides it by ~8.
-#                       At one wave per SIMD a launch lasts as long as its slowest wave, so the threshold sits where
-#                       only the steps that need it trip it (event steps with both event types on), not lower.
-EST_GUARD = 5e-2      # an env that must ACCEPT a step above this (hopelessly far from the operating point) takes the
-#                       23-state path
+EST_GUARD = 5e-2      # |y+ - b| over (i_a, Vdc) of an ETD3RK step above which an env is handed to the 23-state path:
+#                       hopelessly far from the operating point.  The indicator runs ~70x above the true error of
+#                       the step (fp64 prototype, DESIGN.md "etdlin"); with the env step taken as tick + TWO equal
+#                       ETD3RK steps PVDER-v0 rollouts (both event types on) stay below 2e-3
+
+
+def tick_length(micro: int) -> int:
+    """Ticks of the exponential-Euler step behind an input jump: 2 when a sim time step is an even number
+    of ticks (what is left of a segment then splits into two EQUAL ETD3RK steps: one coefficient set,
+    resident in registers, used twice), else 1."""
+    return 2 if micro >= 4 and micro % 2 == 0 else 1
 
 
 def choose_sets(n_sub: int, micro: int, ev_s0: int, ev_ds: int, ev_count: int, max_ksub: int,
                 max_sets: int = 8) -> List[int]:
-    """Step lengths (ticks of 1/(60*micro) s) of the coefficient sets of a launch: [tick, others sorted
-    by decreasing length].  An env takes one tick (exponential Euler) behind every input jump and then
-    the largest ETD3RK step that fits what is left of the segment, so the menu holds
+    """Step lengths (ticks of 1/(60*micro) s) of the coefficient sets of a launch: [tick, the set PVDER-v0
+    env steps use, others].  An env takes the tick (exponential Euler) behind every input jump and then
+    the largest eligible ETD3RK step of the menu (rule: include/pvder_hip.h, pvder_lin_coef), which holds
 
-    * ``L*micro - 1`` for the segment lengths L (sim time steps between two jumps) that envs running in
-      lockstep with the event grid meet -- most frequent first; PVDER-v0: L = n_sub only, events sit
-      on env-step boundaries -- which makes the usual env step TWO integrator steps -- and its two
-      halves, for steps the error indicator rejects;
-    * ``micro - 1`` and ``micro``: together they tile any segment (an env reset off the grid, an event
+    * HALF of ``L*micro - tick`` for the segment lengths L (sim time steps between two jumps) that envs
+      running in lockstep with the event grid meet, most frequent first.  PVDER-v0: L = n_sub only
+      (events sit on env-step boundaries), so an env step is tick + two equal ETD3RK steps;
+    * ``micro - tick`` and ``micro``: together they tile any segment (an env reset off the grid, an event
       spec that is not a multiple of the env step);
     * power-of-two multiples of ``micro`` while there is room, so that such segments take O(log L) steps.
     """
@@ -300,20 +303,60 @@ def choose_sets(n_sub: int, micro: int, ev_s0: int, ev_ds: int, ev_count: int, m
         for a, b in zip(cuts, cuts[1:]):
             cnt[b - a] += 1
         k += n_sub
-    lens = {micro - 1, micro} if micro > 1 else {1}
+    t0 = tick_length(micro)
+    base = sorted({micro - t0, micro} - {0}, reverse=True) or [1]
+    lens: List[int] = []                         # set 1 = the most frequent one: the kernel keeps it in registers
     for L, _ in cnt.most_common():
-        t = L * micro - 1
-        want = {t, (t + 1) // 2, t // 2} - {0}
-        if len(lens | want) > max_sets - 1:
-            if len(lens | {t}) <= max_sets - 1 and t >= 1:
-                lens.add(t)
+        if len(lens) + len([b for b in base if b not in lens]) >= max_sets - 1:
             break
-        lens |= want
+        rest = L * micro - t0
+        if rest >= 2 and rest % 2 == 0 and rest // 2 % micro != 0 and (rest // 2 + t0) % micro != 0:
+            t = rest // 2                        # a genuine half (neither whole steps nor whole minus the tick)
+        else:
+            t = rest                             # (odd remainder / tiny segment: one step over all of it)
+        if t >= 1 and t not in lens:
+            lens.append(t)
+    lens += [b for b in base if b not in lens]
     p = 2
     while len(lens) < max_sets - 1 and p < n_sub:
-        lens.add(p * micro)
+        if p * micro not in lens:
+            lens.append(p * micro)
         p *= 2
-    return [1] + sorted(lens, reverse=True)
+    return [t0] + lens
+
+
+SCHED_BYTES = 8       # bytes per schedule row: up to 7 ETD3RK steps + the terminating 0
+
+
+def build_schedule(n_sub: int, micro: int, len_ticks: Sequence[int]) -> np.ndarray:
+    """uint8 [n_sub, 8]: row L-1 = the set numbers (1-based positions in ``len_ticks``, 0-terminated) of
+    the ETD3RK steps that cover a segment of L sim time steps behind its tick.  Rule: a HALF (a length
+    that is neither whole sim time steps nor that minus the tick) is taken when exactly two or one of
+    it are left; otherwise the largest length that fits among the whole ones and -- while the env is
+    still one tick past a boundary -- the whole-minus-tick ones."""
+    t0 = len_ticks[0]
+    whole = lambda t: t % micro == 0
+    short1 = lambda t: not whole(t) and (t + t0) % micro == 0
+    table = np.zeros((n_sub, SCHED_BYTES), dtype=np.uint8)
+    for L in range(1, n_sub + 1):
+        rem, behind, steps = L * micro - t0, True, []
+        while rem > 0:
+            fit = [s for s in range(1, len(len_ticks))
+                   if not whole(len_ticks[s]) and not short1(len_ticks[s]) and rem in (len_ticks[s], 2 * len_ticks[s])]
+            if not fit:
+                fit = [s for s in range(1, len(len_ticks))
+                       if (whole(len_ticks[s]) or (short1(len_ticks[s]) and behind)) and len_ticks[s] <= rem]
+                fit.sort(key=lambda s: -len_ticks[s])
+            if not fit:
+                raise ValueError("step menu %s cannot tile a segment of %d sim time steps" % (list(len_ticks), L))
+            s = fit[0]
+            rem -= len_ticks[s]
+            behind = behind and not short1(len_ticks[s])
+            steps.append(s)
+        if len(steps) > SCHED_BYTES - 1:
+            raise ValueError("segment of %d sim time steps needs %d steps (> %d)" % (L, len(steps), SCHED_BYTES - 1))
+        table[L - 1, :len(steps)] = steps
+    return table
 
 
 def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[int]) -> np.ndarray:

@@ -226,7 +226,7 @@ class PVDERVec(EnvSpecMixin):
 
     # -- everything a plan folds in: assigning any of these drops the plan (rebuilt at the next step)
     _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded",
-                            "est_guard", "est_refine", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
+                            "est_guard", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
                             "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "integrator"))
 
     def __setattr__(self, name, value):
@@ -402,24 +402,26 @@ class PVDERVec(EnvSpecMixin):
         schedule changes."""
         lens = etd_linear.choose_sets(cfg.n_sub, cfg.micro, cfg.ev_s0, cfg.ev_ds, cfg.ev_count, cfg.max_ksub,
                                       _native.LIN_MAX_SETS)
-        key = (self.der_id, cfg.micro, tuple(lens))
+        key = (self.der_id, cfg.micro, cfg.n_sub, tuple(lens))
         if getattr(self, "_lin_key", None) != key:
-            host = PVDERVec._lin_cache.get(key)
+            host = PVDERVec._lin_cache.get(key[:2] + key[3:])
             if host is None:
                 host = etd_linear.build_coefficients(self.par, self.der_id, cfg.micro, lens)
-                PVDERVec._lin_cache[key] = host
+                PVDERVec._lin_cache[key[:2] + key[3:]] = host
             assert host.size == etd_linear.MAT_FLOATS + (len(lens) - 1) * self._lib.pvder_lin_set_floats()
             self._lin_dev = torch.from_numpy(host).to(self.device)
+            sched = etd_linear.build_schedule(cfg.n_sub, cfg.micro, lens)
+            self._lin_sched = torch.from_numpy(sched).to(self.device)
             self._lin_key = key
         lc = _native.LinCoef()
         lc.sets = self._lin_dev.data_ptr()
+        lc.sched = self._lin_sched.data_ptr()
         lc.n_sets = len(lens)
         for k, t in enumerate(lens):
             lc.len_ticks[k] = t
-        lc.est_refine, lc.est_guard = self.est_refine, self.est_guard
+        lc.est_guard = self.est_guard
         return lc
 
-    est_refine = etd_linear.EST_REFINE
     est_guard = etd_linear.EST_GUARD
 
     def _make_plan(self):

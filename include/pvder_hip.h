@@ -200,34 +200,34 @@ int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvde
  * the Jacobian-driven LSODA integration the reference runs (PVDER_env.py:384-386, jacFlag).  The
  * scheme is evaluated in f-form, U_i = y + sum_j M_ij f(U_j): six dense 11x11 matrices per step
  * size ("coefficient set", PVDER_LIN_SET_FLOATS floats: M21, M31, M32, M41, M42, M43, each
- * PVDER_LIN_MAT_FLOATS = 11 columns x 12 floats, column-major with the 11 rows padded to 12),
+ * PVDER_LIN_MAT_FLOATS = 12 x 12 floats, row-major with the 11 rows / columns padded to 12 -- the
+ * kernels read them as MFMA A operands, 16 bytes at a time),
  * computed by the caller in fp64 -- the Python host does it in gym_PVDER_amd/etd_linear.py
  * (phi-functions of hL by an augmented-matrix exponential) -- and uploaded once to a device buffer.
  *   sets         : [tick matrix (PVDER_LIN_MAT_FLOATS)] [set 1] ... [set n_sets-1].  The tick matrix is
  *                  h phi1(hL) for h = len_ticks[0] ticks, one tick = 1/(60 * cfg->micro) s: the first
  *                  step behind an input jump (new action / new event row) is an exponential-Euler
- *                  step  y+ = y + h phi1(hL) f(y)  of that length (normally 1 tick);
- *   set s >= 1   : ETD3RK over len_ticks[s] ticks, sorted by decreasing length: after the tick an env
- *                  takes the LARGEST one that fits the rest of its segment (the stretch up to the next
- *                  event row change or the end of the env step).  The caller must provide lengths that
- *                  tile every segment (micro - 1 and micro ticks always do);
- *   est_refine   : an ETD3RK step whose embedded error indicator  max |y+ - b|  over (i_a, Vdc) exceeds
- *                  it is redone as two steps of half its length (once), if ceil(len/2) and floor(len/2)
- *                  are in the menu.  A length that is neither a whole number of 1/60 s nor one tick
- *                  short of it (such a half) is used for redoing a rejected step only, and a
- *                  one-tick-short length only while the env is one tick past a 1/60 s boundary, so
- *                  no step strands a remainder the menu cannot tile;
- *   est_guard    : an env that ACCEPTS a step above this -- far from the operating point L was taken
- *                  at -- is advanced by the 23-state ETDRK4 path instead (`coef`, as for
+ *                  step  y+ = y + h phi1(hL) f(y)  of that length (1 or 2 ticks);
+ *   set s >= 1   : ETD3RK over len_ticks[s] ticks;
+ *   sched        : device, cfg->n_sub rows of 8 bytes: row L-1 lists, one set number per byte and
+ *                  terminated by 0, the ETD3RK steps an env takes behind the tick to cover a SEGMENT
+ *                  of L sim time steps (the stretch up to the next event row change or the end of the
+ *                  env step); the tick and the listed lengths must add up to L * cfg->micro ticks.
+ *                  The Python host lists, for the segment lengths PVDER-v0 meets, two steps of half
+ *                  of what the tick leaves (an env step = tick + two equal ETD3RK steps with ONE
+ *                  coefficient set) and tiles any other length with whole multiples of 1/60 s;
+ *   est_guard    : an env whose embedded error indicator  max |y+ - b|  over (i_a, Vdc) exceeds it in
+ *                  any ETD3RK step -- hopelessly far from the operating point L was taken at -- is
+ *                  advanced by the 23-state ETDRK4 path instead (`coef`, as for
  *                  pvder_step_etdrk4_f32), like the envs that come near a limit or are not balanced. */
-#define PVDER_LIN_MAT_FLOATS 132
-#define PVDER_LIN_SET_FLOATS 792
+#define PVDER_LIN_MAT_FLOATS 144
+#define PVDER_LIN_SET_FLOATS 864
 #define PVDER_LIN_MAX_SETS 8
 typedef struct pvder_lin_coef {
     const float *sets;       /* device, PVDER_LIN_MAT_FLOATS + (n_sets - 1) * PVDER_LIN_SET_FLOATS floats */
     int32_t n_sets;          /* 2 .. PVDER_LIN_MAX_SETS */
     int32_t len_ticks[PVDER_LIN_MAX_SETS];
-    float est_refine;
+    const uint8_t *sched;    /* device, 8 * cfg->n_sub bytes */
     float est_guard;
 } pvder_lin_coef;
 int pvder_lin_set_floats(void);

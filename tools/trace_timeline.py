@@ -78,7 +78,8 @@ def main():
     R = np.stack(rows)                     # [launch, block, slot]
     print("N=%d blocks=%d   event-timed step (both launches) median %.1f us" % (N, nblk, float(np.median(evs))))
     names = {0: "entry", 1: "lds staged", 2: "state loaded", 20: "integration done", 22: "outputs+reward done", 23: "stores issued", 21: "epilogue issued"}
-    for s in [0, 1, 2] + list(range(3, 18)) + [20, 22, 23, 21]:
+    names.update({24: "it1: F1", 25: "it1: M21/31/41 F1", 26: "it1: F2", 27: "it1: M32/42 F2", 28: "it1: F3", 29: "it1: M43 F3"})
+    for s in [0, 1, 2] + list(range(3, 18)) + [24, 25, 26, 27, 28, 29, 20, 22, 23, 21]:
         x = R[:, :, s]
         print("slot %2d %-18s min %6.2f  med %6.2f  p90 %6.2f  max %6.2f us" % (
             s, names.get(s, "sub-step %d" % (s - 3)), np.median(x.min(1)), np.median(np.median(x, 1)),
