@@ -3,9 +3,10 @@
 
 Default integrator: etdlin -- fp32 ETD3RK (Cox-Matthews exponential Runge-Kutta) on the model linearised
 at its nominal operating point: the full 11x11 Jacobian sits in the matrix exponential, so an env step
-is TWO integrator steps (1/1920 s behind the action / event jump, then the remaining 479/1920 of the
-env step); `--integrator etdrk4` is round 1's 16-step scheme, the literal classic-RK4 kernel is timed
-in the same run ("classic_rk4").  All meet the 1e-4 rel-L2 parity bar (tests/, -m gpu).
+is an exponential-Euler tick of 2/1920 s behind the action / event jump + TWO equal ETD3RK steps over
+the rest, with the dense matrix-vector products on the matrix cores (fp32 MFMA); `--integrator etdrk4`
+is round 1's 16-step scheme, the literal classic-RK4 kernel is timed in the same run ("classic_rk4").
+All meet the 1e-4 rel-L2 parity bar (tests/, -m gpu).
 
 Workload (BASELINE.json configs[2], the configuration the north_star target is quoted on; with
 --gpus N it is the per-GPU shard of configs[3] = weak scaling): 65 536 parallel PVDER-v0 envs per
@@ -46,8 +47,11 @@ VALU_PEAK_F32 = 157.3e12          # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (vect
 VALU_PEAK_F64 = 78.6e12           # FLOP/s, MI355X_MICROARCH.md "Peak FP64 (vector)"
 BYTES_PER_ENV_STEP = {"f32": 269, "f64": 533}      # three-phase, carried words + obs + reward + done
 # flop / instructions per integrator step, counted from the gfx950 ISA of the inner loops (DESIGN.md "Kernels")
-FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907, "etdlin": 1820}
-INSTR_PER_STEP = {"etdrk4": 396, "etdlin": 936}
+# (etdlin: an ETD3RK step = 3 evaluations of f (~70 flop) + 6 dense 11x11 matrix-vector products on the
+#  matrix cores (242 flop each); the tick = 1 evaluation + 1 product)
+FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907, "etdlin": 3 * 70 + 6 * 242}
+FLOP_PER_TICK = 70 + 242
+INSTR_PER_STEP = {"etdrk4": 396}
 DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1}
 KERNEL_NAME = {"etdlin": "step_etdlin_kernel", "etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel",
                "rk45": "step_rk45_kernel<double,3>"}
@@ -460,7 +464,10 @@ def run_rank(args):
         # integrator steps per env step: a sim time step that starts at an input jump (the first of each
         # env step + one event per second) takes 2 steps (graded) or `micro` uniform ones, the others micro_coarse
         if args.integrator == "etdlin":
-            steps_per_env_step = 2.0 * (1.0 + (0 if 60 % args.n_sub == 0 else (args.n_sub - 1) / 60.0))   # per segment: one tick + the rest
+            # per segment between input jumps: the tick + two equal ETD3RK steps (events on env-step boundaries
+            # when n_sub divides 60: one segment per env step)
+            segs = 1.0 + (0 if 60 % args.n_sub == 0 else (args.n_sub - 1) / 60.0)
+            steps_per_env_step = 2.0 * segs
         elif args.integrator == "etdrk4":
             n_fine = 1.0 + (args.n_sub - 1) / 60.0
             steps_per_env_step = n_fine * (2 if env.graded else args.micro) + (args.n_sub - n_fine) * env.micro_coarse \
@@ -468,6 +475,8 @@ def run_rank(args):
         else:
             steps_per_env_step = args.micro * args.n_sub
         flops = fps * steps_per_env_step * N / avg_kern_s if (fps and avg_kern_s) else None
+        if flops and args.integrator == "etdlin":
+            flops += FLOP_PER_TICK * segs * N / avg_kern_s
         traffic, traffic_src = pmc_traffic(KERNEL_NAME[args.integrator], N)
         valu_peak = VALU_PEAK_F64 if prec == "f64" else VALU_PEAK_F32
         out = {
@@ -480,8 +489,9 @@ def run_rank(args):
                                    ": %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
                                    % (N, args.n_sub, {"etdlin": "fp32 ETD3RK on the model linearised at its operating point (exponential RK, full "
-                                                                "11x11 Jacobian in the exponential), per segment between input jumps: first step "
-                                                                "1/(60*%d) s + one over the remainder (2 steps per env step)" % args.micro,
+                                                                "11x11 Jacobian in the exponential, matrix-vector products on the matrix cores), "
+                                                                "per segment between input jumps: exponential-Euler tick of 2/(60*%d) s + two "
+                                                                "equal ETD3RK steps" % args.micro,
                                                       "etdrk4": ("fp32 ETDRK4 (exponential RK, stiff order 4, 5 stages), sim time step behind an input jump: "
                                                                  + ("first step 1/(60*%d) s + one over the remainder" if env.graded else "%d uniform steps")
                                                                  + ", every other one: %d step(s)") % (args.micro, env.micro_coarse or args.micro),
@@ -501,8 +511,9 @@ def run_rank(args):
                          "kernel_avg_source": src, "kernel_samples": len(kern_ms),
                          "region_ms_per_step": finite(region_ms),
                          "algorithmic_bytes_per_env_step": bytes_step, "kernel_src_sha": kernel_source_hash()},
-            # the binding roof of this path is the vector ALU, not HBM
-            "valu_roofline": {"bound": "valu_" + prec, "achieved": finite(flops / 1e12), "peak": valu_peak / 1e12,
+            # the binding roof of this path is arithmetic latency, not HBM; fp32
+            # vector and fp32 matrix pipes have the same 157.3 TFLOP/s peak (etdlin uses both)
+            "valu_roofline": {"bound": ("valu+mfma_" if args.integrator == "etdlin" else "valu_") + prec, "achieved": finite(flops / 1e12), "peak": valu_peak / 1e12,
                               "unit": "TFLOP/s", "frac": finite(flops / valu_peak),
                               "flop_per_integrator_step": fps,
                               "integrator_steps_per_env_step": steps_per_env_step,

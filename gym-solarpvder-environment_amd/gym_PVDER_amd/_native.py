@@ -95,9 +95,12 @@ _lib = None
 def lib() -> C.CDLL:
     """Load libpvder_hip.so (after torch, so that torch's libamdhip64 is the one HIP runtime of
     the process) and set the prototypes.  Raises if the library or a symbol is missing."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    # A/B runs of variant builds (tools/ab_*.sh) point PVDER_LIB_PATH at their own library instead of
+    # copying it over the shipped one; the same C ABI, the same checks below
+    LIB_PATH = os.environ.get("PVDER_LIB_PATH", LIB_PATH)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "native library %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "

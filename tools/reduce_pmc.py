@@ -37,7 +37,7 @@ def main():
     shutil.copy(wf, os.path.join(prof, tag + "_pmc_write_size_counter_collection.csv"))
     stats = glob.glob(os.path.join(sdir, "**", "*kernel_stats.csv"), recursive=True)
     assert stats, "no kernel_stats.csv under " + sdir
-    shutil.copy(stats[0], os.path.join(prof, tag + "_bench_etdrk4_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(prof, tag + "_bench_kernel_stats.csv"))
     avg_ns = calls = None
     for row in csv.DictReader(open(stats[0])):
         if KERNEL in row["Name"]:
@@ -62,7 +62,7 @@ def main():
         "note": "expected from the kernel's own accesses: reads 25 fp32 rows + 3 int32 rows + action + event rows "
                 "= ~8.2 MB, writes 25+3+13 rows = 10.75 MB",
     }
-    with open(os.path.join(prof, tag + "_pmc_etdrk4_bal_traffic.json"), "w") as f:
+    with open(os.path.join(prof, tag + "_pmc_step_kernel_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
