@@ -64,7 +64,7 @@ constexpr int kDeferred = -1; // transient istate status (single-phase ETDRK4 on
 
 template <typename T>
 struct StepK {
-    int n_sub, micro, micro2, graded, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it;
+    int n_sub, micro, micro2, graded, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it, extra;
     T dq, dv, inv_tmax, p_t, q_t, rtol, atol;
 };
 
@@ -152,8 +152,11 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 }
 
 template <typename T>
-__device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T vrms, T Ppcc, T Qpcc) {
-    // PVDER_env.py:231-301 -- one 'required' term per goal (:78-93 via :448-452)
+__device__ __forceinline__ T ladder(T err, T lo, T hi) { return err <= lo ? (T)1 : (err >= hi ? (T)-5 : (T)-1); }
+
+template <typename T>
+__device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T vrms, T Ppcc, T Qpcc, T Vdc, T vdcref) {
+    // PVDER_env.py:231-301 -- the goal's 'required' term (:78-93 via :448-452) ...
     T err, lo, hi, cont;
     if (C.goal == PVDER_GOAL_VOLTAGE) {            // voltage_error :276-287
         const T d = vrms - P.vrms_ref;
@@ -168,8 +171,13 @@ __device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T 
         if (qt == (T)0) qt = (T)1e-6;              // :266-267 (discrete branch only)
         err = fabs(Qpcc - qt) / fabs(qt); lo = (T)0.01; hi = (T)0.05;
     }
-    if (!C.discrete) return cont;
-    return err <= lo ? (T)1 : (err >= hi ? (T)-5 : (T)-1);
+    T r = C.discrete ? ladder(err, lo, hi) : cont;
+    // ... plus the optional Vdc_error term of my_spec (:251-262; Vdctarget = Vdc_ref, :243), summed (:301)
+    if ((C.extra & PVDER_REWARD_VDC_ERROR) && C.goal == PVDER_GOAL_POWER) {
+        const T d = vdcref - Vdc;
+        r += C.discrete ? ladder(fabs(d) / vdcref, (T)0.02, (T)0.05) : -(d * d);
+    }
+    return r;
 }
 
 // ---- per-lane bookkeeping shared by every step kernel
@@ -264,7 +272,7 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
     }
     T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
     pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc);
+    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc, y[6 * PH], L.vdcref);
 #ifdef PVDER_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 32 + 22] = wall_clock64() + (reward > (T)1e30 ? 1 : 0);
 #endif
@@ -1484,6 +1492,7 @@ StepK<T> fold_cfg(const pvder_step_cfg *c) {
     C.goal = c->goal; C.discrete = c->discrete; C.ev_s0 = c->ev_s0; C.ev_ds = c->ev_ds;
     C.ev_count = c->ev_count;
     C.max_it = c->reserved > 0 ? c->reserved : 20000000;   // RK45: attempts per sim time step
+    C.extra = c->extra_rewards;
     C.dq = (T)c->del_qref; C.dv = (T)c->del_vdcref; C.inv_tmax = (T)c->inv_max_sim_time;
     C.p_t = (T)c->p_target; C.q_t = (T)c->q_target; C.rtol = (T)c->rtol; C.atol = (T)c->atol;
     return C;
@@ -1844,6 +1853,95 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
         const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env,
                                    (char *)out + (size_t)k * out_step_stride * esz, hstep, stats, 1, stream);
         if (rc) return rc;
+    }
+    return 0;
+}
+
+// ---- the per-step collective of the sharded env, enqueued from C ------------------------------------
+// One all-gather of the [13, N_local] output block per env step (RCCL over xGMI): the step kernel runs
+// on the caller's stream, the gather on this object's own stream, two output blocks alternate so that
+// the gather of step t overlaps the kernel of step t+1.  Everything a step needs -- wait for the gather
+// that last read the block, launch, record, cross-stream wait, ncclAllGather, record -- is issued from
+// ONE host call per rollout instead of six Python-level calls per step.  RCCL is not linked: the
+// caller passes the address of ncclAllGather from the librccl it already uses.
+typedef int (*nccl_all_gather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+struct pvder_gather {
+    nccl_all_gather_fn all_gather;
+    void *comm;
+    hipStream_t stream;
+    hipEvent_t ready[2], done[2];
+    bool pending[2];
+};
+
+int pvder_gather_create(pvder_gather **out, void *nccl_all_gather, void *comm) {
+    if (!out || !nccl_all_gather || !comm) return PVDER_EINVAL;
+    *out = nullptr;
+    pvder_gather *g = new (std::nothrow) pvder_gather;
+    if (!g) return -(int)hipErrorOutOfMemory;
+    g->all_gather = (nccl_all_gather_fn)nccl_all_gather;
+    g->comm = comm;
+    g->pending[0] = g->pending[1] = false;
+    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipEventCreateWithFlags(&g->ready[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done[b], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { delete g; return hip_rc(e); }
+    *out = g;
+    return 0;
+}
+
+void pvder_gather_destroy(pvder_gather *g) {
+    if (!g) return;
+    (void)hipStreamSynchronize(g->stream);
+    for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(g->ready[b]); (void)hipEventDestroy(g->done[b]); }
+    (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+// make `stream` wait for the gathers still in flight (their results are then visible to work enqueued on it)
+int pvder_gather_drain(pvder_gather *g, void *stream) {
+    if (!g) return PVDER_EINVAL;
+    for (int b = 0; b < 2; ++b)
+        if (g->pending[b]) {
+            const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, g->done[b], 0);
+            if (e != hipSuccess) return hip_rc(e);
+            g->pending[b] = false;
+        }
+    return 0;
+}
+
+// n_steps transitions, each followed by the all-gather of its output block: step k writes out[k & 1]
+// ([13, n_env] floats) and gathers it into recv[k & 1] ([world * 13, n_env]).  sync_each != 0: the next
+// step waits for the gather (no overlap).  first_block: parity of the first step (continue a rollout).
+int pvder_plan_rollout_gather(const pvder_plan *plan, pvder_gather *g, void *fstate, int32_t *istate, float *ev_vg,
+                              float *ev_si, const uint8_t *actions, int n_steps, float *out0, float *out1, float *recv0,
+                              float *recv1, float *stats, void *stream, int first_block, int sync_each) {
+    if (!plan || !g || n_steps < 0 || !actions || !out0 || !out1 || !recv0 || !recv1) return PVDER_EINVAL;
+    if (plan->integrator == PVDER_INT_RK45) return PVDER_EINVAL;     // (fp32 blocks only)
+    hipStream_t st = (hipStream_t)stream;
+    float *outs[2] = {out0, out1}, *recvs[2] = {recv0, recv1};
+    const size_t count = (size_t)PVDER_OROWS * plan->n_env;
+    for (int k = 0; k < n_steps; ++k) {
+        const int b = (first_block + k) & 1;
+        hipError_t e = hipSuccess;
+        if (g->pending[b]) e = hipStreamWaitEvent(st, g->done[b], 0);        // gather t-2 has read this block
+        if (e != hipSuccess) return hip_rc(e);
+        const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env, outs[b],
+                                   nullptr, stats, 1, stream);
+        if (rc) return rc;
+        e = hipEventRecord(g->ready[b], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->ready[b], 0);
+        if (e != hipSuccess) return hip_rc(e);
+        const int nrc = g->all_gather(outs[b], recvs[b], count, 7 /* ncclFloat32 */, g->comm, g->stream);
+        if (nrc != 0) return -20000 - nrc;
+        e = hipEventRecord(g->done[b], g->stream);
+        if (e != hipSuccess) return hip_rc(e);
+        g->pending[b] = true;
+        if (sync_each) {
+            e = hipStreamWaitEvent(st, g->done[b], 0);
+            if (e != hipSuccess) return hip_rc(e);
+        }
     }
     return 0;
 }

@@ -27,7 +27,8 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_reset_masked_f64", "pvder_step_etdrk4_f32", "pvder_step_rk4_f32", "pvder_step_rk45_f64",
            "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients", "pvder_lin_set_floats", "pvder_lin_max_sets",
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
-           "pvder_plan_rollout"]
+           "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
+           "pvder_plan_rollout_gather"]
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
 LIN_MAX_SETS = 8
@@ -40,7 +41,8 @@ class StepCfg(C.Structure):
                 ("ev_s0", C.c_int32), ("ev_ds", C.c_int32), ("ev_count", C.c_int32),
                 ("reserved", C.c_int32), ("del_qref", C.c_double), ("del_vdcref", C.c_double),
                 ("inv_max_sim_time", C.c_double), ("p_target", C.c_double), ("q_target", C.c_double),
-                ("rtol", C.c_double), ("atol", C.c_double), ("micro_coarse", C.c_int32), ("graded", C.c_int32)]
+                ("rtol", C.c_double), ("atol", C.c_double), ("micro_coarse", C.c_int32), ("graded", C.c_int32),
+                ("extra_rewards", C.c_int32), ("pad_", C.c_int32)]
 
 
 class EventSpec(C.Structure):
@@ -139,6 +141,14 @@ def lib() -> C.CDLL:
     L.pvder_plan_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pvder_plan_rollout.restype = i32
     L.pvder_plan_rollout.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.pvder_gather_create.restype = i32
+    L.pvder_gather_create.argtypes = [C.POINTER(vp), vp, vp]
+    L.pvder_gather_destroy.restype = None
+    L.pvder_gather_destroy.argtypes = [vp]
+    L.pvder_gather_drain.restype = i32
+    L.pvder_gather_drain.argtypes = [vp, vp]
+    L.pvder_plan_rollout_gather.restype = i32
+    L.pvder_plan_rollout_gather.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32]
     _lib = L
     return L
 

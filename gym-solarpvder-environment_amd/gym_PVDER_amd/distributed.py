@@ -133,8 +133,65 @@ class RcclAllGather:
         done.record(self.stream)
         return done
 
+    def native(self, env) -> "NativeStepGather":
+        """The same collective driven from C together with the step launch (no Python per step)."""
+        return NativeStepGather(self, env)
+
     def close(self):
         if getattr(self, "_comm", None):
             self.stream.synchronize()
             self._nccl.ncclCommDestroy(self._comm)
             self._comm = None
+
+
+class NativeStepGather:
+    """K env steps, each followed by the all-gather of its output block, from ONE host call
+    (include/pvder_hip.h ``pvder_plan_rollout_gather``): the step kernel on torch's current stream, the
+    gather on the C object's own stream, two output blocks alternating so that the gather of step t
+    overlaps the kernel of step t+1.  Measured at world size 1 (bench.py, forced): the Python-level
+    sequence (wait_event, step, record, wait, ncclAllGather via ctypes, record) costs ~29 us of host time
+    per step against an 11 us kernel."""
+
+    def __init__(self, rccl: RcclAllGather, env):
+        from . import _native
+        self._lib, self.env, self.world = _native.lib(), env, rccl.world
+        fn = C.cast(rccl._nccl.ncclAllGather, C.c_void_p)
+        self._h = C.c_void_p()
+        with torch.cuda.device(env.device):
+            _native.check(self._lib.pvder_gather_create(C.byref(self._h), fn, rccl._comm), "pvder_gather_create")
+        n = env.num_envs
+        self.out = [env.out, torch.empty_like(env.out)]
+        self.recv = [torch.empty((self.world * 13, n), dtype=torch.float32, device=env.device) for _ in range(2)]
+        self._k = 0
+
+    def rollout(self, actions: torch.Tensor, sync_each: bool = False):
+        """``actions``: [K, N] uint8 device tensor.  After ``drain()`` the collated block of the last
+        step is ``self.recv[(steps_so_far - 1) & 1]``."""
+        from . import _native
+        env = self.env
+        assert actions.dtype == torch.uint8 and actions.is_contiguous() and actions.shape[1] == env.num_envs
+        plan = env._plan or env._make_plan()
+        K = int(actions.shape[0])
+        with env._device_ctx():
+            rc = self._lib.pvder_plan_rollout_gather(plan, self._h, env.fstate.data_ptr(), env.istate.data_ptr(),
+                                                     env.ev_vg.data_ptr(), env.ev_si.data_ptr(), actions.data_ptr(), K,
+                                                     self.out[0].data_ptr(), self.out[1].data_ptr(),
+                                                     self.recv[0].data_ptr(), self.recv[1].data_ptr(),
+                                                     env.stats.data_ptr(), env._stream(), self._k & 1, 1 if sync_each else 0)
+        _native.check(rc, "pvder_plan_rollout_gather")
+        self._k += K
+        if K:
+            env.out = self.out[(self._k - 1) & 1]
+
+    def drain(self):
+        from . import _native
+        with self.env._device_ctx():
+            _native.check(self._lib.pvder_gather_drain(self._h, self.env._stream()), "pvder_gather_drain")
+
+    def last(self) -> torch.Tensor:
+        return self.recv[(self._k - 1) & 1]
+
+    def close(self):
+        if self._h:
+            self._lib.pvder_gather_destroy(self._h)
+            self._h = None

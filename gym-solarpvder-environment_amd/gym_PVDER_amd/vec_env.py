@@ -182,6 +182,8 @@ class PVDERVec(EnvSpecMixin):
         self._set_n(n_sim_time_steps_per_env_step)
         self.max_sim_time_user = max_sim_time
         self._set_max_sim_time(max_sim_time)
+        self.env_goal_spec = copy.deepcopy(type(self).env_goal_spec)      # per instance: the reference's class-level
+        #                                  dict is shared by (and mutated across) every instance, SURVEY.md section 5
         self._set_goals(list(goals_list) if goals_list is not None else None)
         self._set_discrete(DISCRETE_REWARD)
         self.integrator = integrator
@@ -227,7 +229,15 @@ class PVDERVec(EnvSpecMixin):
     # -- everything a plan folds in: assigning any of these drops the plan (rebuilt at the next step)
     _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded",
                             "est_guard", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
-                            "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "integrator"))
+                            "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "env_goal_spec", "integrator"))
+
+    def set_reward_spec(self, reward_types):
+        """``env_goal_spec[goal]['reward']['my_spec'] = reward_types`` for the active goal (the reference's
+        ``update_env_goal`` is "under construction", PVDER_env.py:454-456; ``reward_calc`` iterates this
+        list, :249): the goal's required term, optionally plus 'Vdc_error' (power_regulation)."""
+        self.env_goal_spec[self._goals_list[0]]['reward']['my_spec'] = list(reward_types)
+        self._drop_plan()
+        self._cfg()                       # validate now
 
     def __setattr__(self, name, value):
         object.__setattr__(self, name, value)
@@ -371,6 +381,19 @@ class PVDERVec(EnvSpecMixin):
         c.q_target = self.env_reward_spec['reference_values']['Q_ref'] / der_model.SBASE   # :241
         c.rtol, c.atol = self.rtol, self.atol
         c.reserved = self._debug_knob
+        # reward types beyond the goal's required one: env_goal_spec[goal]['reward']['my_spec'] (:249; the
+        # reference only ever fills it with the 'required' list, :448-452 -- its update path is "under
+        # construction", :454-456 -- but reward_calc honours whatever it holds)
+        goal = self._goals_list[0]
+        spec = self.env_goal_spec[goal]['reward']
+        mine = spec.get('my_spec', spec['required'])
+        unknown = set(mine) - set(self.env_reward_spec['reward_list']['valid'])
+        if unknown or spec['required'][0] not in mine or set(mine) - set(spec['required']) - {'Vdc_error'}:
+            raise ValueError("reward my_spec %s: must hold the goal's required term %s, optionally plus 'Vdc_error'"
+                             % (mine, spec['required']))
+        if 'Vdc_error' in mine and goal != 'power_regulation':
+            raise ValueError("'Vdc_error' needs Vdctarget, which reward_calc defines for power_regulation only (:243-245)")
+        c.extra_rewards = 1 if 'Vdc_error' in mine else 0
         return c
 
     def _spec(self) -> _native.EventSpec:

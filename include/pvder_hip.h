@@ -108,7 +108,12 @@ typedef struct pvder_step_cfg {
                              steps: h = 1/(60*micro) -- the size of the FIRST step behind a jump is
                              what sets the error -- then the remainder (1 - 1/micro)/60.
                              PVDER defaults: micro 32, micro_coarse 1, graded 1 */
+    int32_t extra_rewards; /* reward types of env_goal_spec[goal]['reward']['my_spec'] beyond the goal's
+                             required one (:249): PVDER_REWARD_VDC_ERROR adds the Vdc_error term
+                             (:251-262; power_regulation only, as its target is defined at :243-245) */
+    int32_t pad_;
 } pvder_step_cfg;
+#define PVDER_REWARD_VDC_ERROR 1
 
 /* ---- event generator spec for reset (PVDER_env.py:60-61, :400-411) */
 typedef struct pvder_event_spec {
@@ -257,6 +262,23 @@ int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                        const uint8_t *actions, int n_steps, void *out, size_t out_step_stride, double *hstep,
                        float *stats, void *stream);
+
+/* ---- the per-step collective of the sharded env (multi-GPU) -------------------------
+ * The reference has no distributed code; the build shards independent envs over ranks and collates
+ * the [13, n_env] output block of every step with ONE all-gather (RCCL over xGMI).  These entry points
+ * enqueue step kernel + gather from C -- one host call per rollout instead of six Python-level calls
+ * per step: the kernel on the caller's stream, the gather on the object's own stream, two output
+ * blocks alternating (step k uses out[(first_block + k) & 1] / recv[...]) so that the gather of step t
+ * overlaps the kernel of step t+1.  RCCL is not linked: `nccl_all_gather` is the address of
+ * ncclAllGather in the librccl the caller uses, `comm` its ncclComm_t.  recv blocks are
+ * [world * 13, n_env] floats.  pvder_gather_drain makes `stream` wait for the gathers in flight. */
+typedef struct pvder_gather pvder_gather;
+int pvder_gather_create(pvder_gather **g, void *nccl_all_gather, void *comm);
+void pvder_gather_destroy(pvder_gather *g);
+int pvder_gather_drain(pvder_gather *g, void *stream);
+int pvder_plan_rollout_gather(const pvder_plan *plan, pvder_gather *g, void *fstate, int32_t *istate, float *ev_vg,
+                              float *ev_si, const uint8_t *actions, int n_steps, float *out0, float *out1, float *recv0,
+                              float *recv1, float *stats, void *stream, int first_block, int sync_each);
 
 #ifdef __cplusplus
 }

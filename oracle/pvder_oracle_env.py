@@ -51,6 +51,43 @@ GOAL_REWARDS = {                    # 'required' lists, PVDER_env.py:78-93 via :
 }
 
 
+def reward_terms(goal: str, discrete: bool, Vrms: float, Vrms_ref: float, S_PCC: complex, Vdc: float, Vdc_ref: float,
+                 my_spec: Optional[List[str]] = None):
+    """``reward_calc`` (PVDER_env.py:231-301) on explicit model quantities: one entry per reward type
+    of ``env_goal_spec[goal]['reward']['my_spec']`` (default: the goal's 'required' list, :448-452),
+    summed (:301).  ``Vdc_error`` (:251-262) is only defined for power_regulation (its target,
+    ``Vdctarget = PV_model.Vdc_ref``, is set at :243-245 for that goal alone)."""
+    rewards: List = []
+    for rt in (my_spec if my_spec is not None else GOAL_REWARDS[goal]):   # :249
+        if rt == "Vdc_error":                                           # :251-262
+            if goal != "power_regulation":
+                raise ValueError("Vdc_error needs Vdctarget, which reward_calc defines for power_regulation only")
+            if discrete:
+                rewards.append(discrete3(abs(Vdc - Vdc_ref) / Vdc_ref, 0.02, 0.05))
+            else:
+                rewards.append(-(Vdc_ref - Vdc) ** 2)
+        elif rt == "voltage_error":                                     # :276-287
+            if discrete:
+                rewards.append(discrete3(abs(Vrms - Vrms_ref) / abs(Vrms_ref), 0.01, 0.05))
+            else:
+                rewards.append(-(Vrms - Vrms_ref) ** 2)
+        elif rt == "Q_error":                                           # :263-275
+            Qt = Q_REF_TARGET / pm.SBASE                                # :241
+            if discrete:
+                if Qt == 0.0:
+                    Qt = 1e-6
+                rewards.append(discrete3(abs(S_PCC.imag - Qt) / abs(Qt), 0.01, 0.05))
+            else:
+                rewards.append(-(S_PCC.imag - Qt) ** 2)
+        elif rt == "power_error":                                       # :290-299
+            Pt = P_REF / pm.SBASE                                       # :245
+            if discrete:
+                rewards.append(discrete3(abs(S_PCC.real - Pt) / Pt, 0.01, 0.03))
+            else:
+                rewards.append(-(S_PCC.real - Pt) ** 2)
+    return sum(rewards)                                                 # :301
+
+
 def discrete3(e: float, lo: float, hi: float) -> int:
     """+1 / -1 / -5 ladder of PVDER_env.py:255-260, :268-273, :280-285, :292-297."""
     if e <= lo:
@@ -186,30 +223,8 @@ class OraclePVDER:
 
     def reward_calc(self):
         o = self.outputs()
-        m = self.model
-        goal = self.goals_list[0]                                       # :234
-        rewards: List = []
-        for rt in GOAL_REWARDS[goal]:                                   # :249
-            if rt == "voltage_error":                                   # :276-287
-                if self.DISCRETE_REWARD:
-                    rewards.append(discrete3(abs(o.Vrms - m.Vrms_ref) / abs(m.Vrms_ref), 0.01, 0.05))
-                else:
-                    rewards.append(-(o.Vrms - m.Vrms_ref) ** 2)
-            elif rt == "Q_error":                                       # :263-275
-                Qt = Q_REF_TARGET / pm.SBASE                            # :241
-                if self.DISCRETE_REWARD:
-                    if Qt == 0.0:
-                        Qt = 1e-6
-                    rewards.append(discrete3(abs(o.S_PCC.imag - Qt) / abs(Qt), 0.01, 0.05))
-                else:
-                    rewards.append(-(o.S_PCC.imag - Qt) ** 2)
-            elif rt == "power_error":                                   # :290-299
-                Pt = P_REF / pm.SBASE                                   # :245
-                if self.DISCRETE_REWARD:
-                    rewards.append(discrete3(abs(o.S_PCC.real - Pt) / Pt, 0.01, 0.03))
-                else:
-                    rewards.append(-(o.S_PCC.real - Pt) ** 2)
-        return sum(rewards)                                             # :301
+        return reward_terms(self.goals_list[0], self.DISCRETE_REWARD, o.Vrms, self.model.Vrms_ref, o.S_PCC, o.Vdc,
+                            self.Vdc_ref, getattr(self, "reward_spec", None))
 
     # -- observation (PVDER_env.py:531-542) ------------------------------------------------------
     @property

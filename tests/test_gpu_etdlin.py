@@ -244,3 +244,39 @@ def test_single_phase_etdlin_vs_bridge(gpu_device):
     got, want = np.stack(got), np.stack(want)
     err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
     assert err.max() < FP32_TOL / 2, err.max()
+
+
+def test_native_step_gather_world1(gpu_device):
+    """pvder_plan_rollout_gather (step launch + ncclAllGather enqueued from C, two alternating output
+    blocks, gather on its own stream) at world size 1: every collated block equals the step's own
+    output block, and the env ends where K plain steps end."""
+    import os
+    import torch.distributed as dist
+    from gym_PVDER_amd.distributed import RcclAllGather
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    N, K = 4096, 9
+    kw = dict(seed=12, events_spec=both_events_spec(), auto_reset=True, max_sim_time=1.5)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(2)
+    acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    a = make_vec(N, gpu_device, **kw); a.reset()
+    b = make_vec(N, gpu_device, **kw); b.reset()
+    rc = RcclAllGather(gpu_device)
+    nat = rc.native(b)
+    for k in range(K):                              # one step per call: every collated block can be checked
+        a.step(acts[k], return_tensors=False)
+        nat.rollout(acts[k:k + 1])
+        nat.drain()
+        torch.cuda.synchronize()
+        assert torch.equal(nat.last(), a.out), k
+        assert torch.equal(b.out, a.out)
+    nat.rollout(acts[:6])                           # several steps per call, gathers overlapped
+    nat.drain()
+    for k in range(6):
+        a.step(acts[k], return_tensors=False)
+    torch.cuda.synchronize()
+    assert torch.equal(nat.last(), a.out) and torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate)
+    nat.close()
+    rc.close()

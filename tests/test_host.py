@@ -56,7 +56,9 @@ def test_ctypes_structs_match_header_layout(tmp_path):
                    'offsetof(pvder_step_cfg, atol), sizeof(pvder_event_spec), offsetof(pvder_event_spec, v_min),'
                    'offsetof(pvder_event_spec, s_max), (int)PVDER_PAR_COUNT, sizeof(pvder_autoreset),'
                    'offsetof(pvder_autoreset, seed), offsetof(pvder_autoreset, spec), offsetof(pvder_autoreset, y0));'
-                   'printf("%zu %zu\\n", offsetof(pvder_step_cfg, micro_coarse), offsetof(pvder_step_cfg, graded));return 0;}')
+                   'printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(pvder_step_cfg, micro_coarse), offsetof(pvder_step_cfg, graded),'
+                   'offsetof(pvder_step_cfg, extra_rewards), sizeof(pvder_lin_coef), offsetof(pvder_lin_coef, sched),'
+                   'offsetof(pvder_lin_coef, est_guard));return 0;}')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
@@ -64,6 +66,8 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     assert vals[:6] == [ctypes.sizeof(S), S.del_qref.offset, S.atol.offset, ctypes.sizeof(E), E.v_min.offset, E.s_max.offset]
     assert vals[7:11] == [ctypes.sizeof(A), A.seed.offset, A.spec.offset, A.y0.offset]
     assert vals[11:13] == [S.micro_coarse.offset, S.graded.offset]
+    Lc = _native.LinCoef
+    assert vals[13:17] == [S.extra_rewards.offset, ctypes.sizeof(Lc), Lc.sched.offset, Lc.est_guard.offset]
     from gym_PVDER_amd import der_model
     assert vals[6] == len(der_model.PAR)
 
