@@ -346,3 +346,39 @@ def test_checkpoint_resume_is_bit_exact(gpu_device, tmp_path):
     assert env2.step_stats() == env.step_stats()
     with pytest.raises(ValueError):
         PVDERVec(299, **kw).load_state_dict(env.state_dict())
+
+
+def test_calc_returns_vs_oracle(gpu_device):
+    """SURVEY.md 8(f) rank 2 against the oracle: the returns of the reference's four fixed policies
+    (PVDER_env.py:458-497) from the batched rollout == the fp64 bridge (converged RK45) stepping the same
+    event tables (counter generator keyed by (seed, env id, episode)) and the same action sequences,
+    with the reference's reward rules (oracle/bridge_env.py)."""
+    from gym_PVDER_amd import der_model
+    from gym_PVDER_amd.evaluate import ACTION_SPECS, calc_returns
+    from helpers import counter_tables
+    from oracle.bridge_env import BridgeVecEnv
+    seed, episodes, T = 11, 2, 2.0          # (the converged bridge integrates ~50 000 RK45 steps per env step)
+    K = int(T * 60 / 15)
+    rng = np.random.default_rng(3)
+    rand = rng.integers(0, 5, size=(K + 1, episodes))
+    vg, si = counter_tables(episodes, seed, episode=1, env_id_base=0)
+    for goal, discrete in (("voltage_regulation", False), ("Q_regulation", False), ("power_regulation", True)):
+        got = calc_returns(episodes=episodes, device=gpu_device, goals=[goal], seed=seed, max_sim_time=T,
+                           DISCRETE_REWARD=discrete, random_actions=torch.as_tensor(rand))
+        for name, fixed in ACTION_SPECS.items():
+            ref = BridgeVecEnv(episodes, n=15, max_sim_time=T, discrete=discrete, goal=goal, method="rk45",
+                               rtol=1e-8, atol=1e-11)
+            ref.reset(vg, si)
+            total = np.zeros(episodes)
+            for k in range(K):
+                a = np.full(episodes, fixed) if fixed is not None else rand[k]
+                _, r, d = ref.step(a)
+                total += r
+            assert bool(d.all())
+            want, have = float(total.mean()), got[goal][name]['return']
+            if discrete:
+                assert abs(have - want) <= 4.0 / episodes + 1e-9, (goal, name, have, want)     # at most one threshold flip
+            else:
+                assert abs(have - want) <= 1e-3 * abs(want) + 1e-9, (goal, name, have, want)
+            assert abs(got[goal][name]['ref'][0] - ref.vdcref.mean() * der_model.VBASE) < 1e-2
+            assert abs(got[goal][name]['ref'][1] - ref.qref.mean() * der_model.SBASE) < 1e-1
