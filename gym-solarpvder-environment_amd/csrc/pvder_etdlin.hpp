@@ -96,6 +96,11 @@ __device__ __forceinline__ void lin_load_mat(const float *__restrict__ m, int la
             A[g][0] = a.x; A[g][1] = a.y; A[g][2] = a.z; A[g][3] = a.w;
             A[g][4] = b.x; A[g][5] = b.y; A[g][6] = b.z; A[g][7] = b.w;
             A[g][8] = c.x; A[g][9] = c.y; A[g][10] = c.z; A[g][11] = c.w;
+            // pin the operands to the accumulation-register half of the file (the MFMA reads its A operand
+            // from there just as well): left to itself hipcc keeps them in the 256 architectural VGPRs and
+            // starves the VALU code of the step loop of registers
+#pragma unroll
+            for (int k = 0; k < kLinN; ++k) asm volatile("" : "+a"(A[g][k]));
         }
     }
 }

@@ -156,6 +156,7 @@ __device__ __forceinline__ T ladder(T err, T lo, T hi) { return err <= lo ? (T)1
 
 template <typename T>
 __device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T vrms, T Ppcc, T Qpcc, T Vdc, T vdcref) {
+#pragma clang fp contract(off)       // (the same bits in every kernel: see pvder::outputs)
     // PVDER_env.py:231-301 -- the goal's 'required' term (:78-93 via :448-452) ...
     T err, lo, hi, cont;
     if (C.goal == PVDER_GOAL_VOLTAGE) {            // voltage_error :276-287
@@ -1391,8 +1392,11 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
         L.steps += 1;
     }
     const bool ran = L.run;
-    // no in-kernel auto-reset here: this kernel sits at the 256-VGPR + AGPR limit; the launcher
-    // enqueues reset_kernel<..., true> (reset where status != 0) right behind it instead
+    // no in-kernel auto-reset here: this kernel sits at the 256-VGPR + AGPR limit -- hipcc has miscompiled it
+    // twice when its code was rearranged (auto-reset inlined into the epilogue, round 1; the sim time step
+    // factored into a helper taking the right-hand side as a lambda, round 2: NaN states; both caught by the
+    // parity tests) -- so its loop stays written out and the launcher enqueues
+    // reset_kernel<..., true> (reset where status != 0) right behind it instead
     epilogue<T, PH, false>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
     if (ran) hstep[L.e] = (L.status != 0) ? (T)0 : hn;       // a finished env restarts the controller
 }

@@ -62,6 +62,7 @@ template <> struct Math<double> {
 
 template <typename T, int PH>
 __device__ __forceinline__ void make_sub(const ModelK<T> &P, T vgm, T sinsol, SubK<T, PH> &S) {
+#pragma clang fp contract(off)       // (see outputs(): the same bits in every kernel)
     const T ar = P.GR * vgm, ai = P.GI * vgm;
     S.AR[0] = ar;
     S.AI[0] = ai;
@@ -78,13 +79,16 @@ __device__ __forceinline__ void make_sub(const ModelK<T> &P, T vgm, T sinsol, Su
 // PV array power (pu): max(0, Vdc*(pv1 - pvB*exp(pvK*Vdc)))
 template <typename T>
 __device__ __forceinline__ T ppv_of(const ModelK<T> &P, T pv1, T Vdc) {
+#pragma clang fp contract(off)       // (reported as an observation: see outputs())
     const T e = Math<T>::exp_pv(P.pvK * Vdc);
     const T p = Vdc * (pv1 - P.pvB * e);
     return p > (T)0 ? p : (T)0;
 }
 
 // dy/dt.  th2t = 2*wbase*t in turns (only matters when the currents are unbalanced).
-template <typename T, int PH>
+// NPAR = number of identical phases the PH phases written out stand for: rhs<T, 1, 3> is the BALANCED
+// three-phase model on its 11-state reduction (phase a + the shared states; phases b, c = phase a rotated)
+template <typename T, int PH, int NPAR = 1>
 __device__ __forceinline__ void rhs(const ModelK<T> &P, const SubK<T, PH> &S, const T *__restrict__ y,
                                     T th2t, T qref, T vdcref, T *__restrict__ dy) {
     constexpr int B = 6 * PH;
@@ -102,8 +106,8 @@ __device__ __forceinline__ void rhs(const ModelK<T> &P, const SubK<T, PH> &S, co
         Pt += mR[p] * iR + mI[p] * iI;          // Re(m conj i)
         Qp += vI[p] * iR - vR[p] * iI;          // Im(v conj i)
     }
-    const T ReS = (T)0.5 * hV * Pt;             // Re S = 1/2 sum Re(vt conj i), vt = m Vdc/2
-    const T Q = (T)0.5 * Qp;                    // Im S_PCC
+    const T ReS = (T)(0.5 * NPAR) * hV * Pt;    // Re S = 1/2 sum Re(vt conj i), vt = m Vdc/2
+    const T Q = (T)(0.5 * NPAR) * Qp;           // Im S_PCC
     // current references
     const T iarR = xDC + P.KpDC * (vdcref - Vdc);
     const T qerr = qref - Q;
@@ -185,6 +189,10 @@ template <typename T, int PH>
 __device__ __forceinline__ void outputs(const ModelK<T> &P, const SubK<T, PH> &S, const T *__restrict__ y,
                                         T &iaR, T &iaI, T &vaR, T &vaI, T &Ppcc, T &Qpcc, T &ppv,
                                         T &vrms) {
+    // No fma contraction here: which product of  a*b + c*d  the compiler fuses depends on the code around
+    // the call, and every kernel that reports an observation of the same state (per-step launch, fused
+    // rollout, 23-state tail, reset) must report the same bits.
+#pragma clang fp contract(off)
     constexpr int B = 6 * PH;
     T Pp = (T)0, Qp = (T)0, v2 = (T)0;
 #pragma unroll

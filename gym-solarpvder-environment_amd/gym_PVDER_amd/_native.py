@@ -78,8 +78,10 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())          # build aside, then rename: never a half-written library
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs (the VALU code reads them without
+    # v_accvgpr_read copies); the 231 A operands of the etdlin kernels are pinned to the AGPR half instead
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC, "-o", tmp] + srcs
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-I" + INCLUDE, "-I" + CSRC, "-o", tmp] + srcs
     if verbose:
         print(" ".join(cmd))
     try:

@@ -280,3 +280,4 @@ def test_native_step_gather_world1(gpu_device):
     assert torch.equal(nat.last(), a.out) and torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate)
     nat.close()
     rc.close()
+    dist.destroy_process_group()

@@ -30,7 +30,7 @@ def main():
     lib = os.path.join(out_dir, "libpvder_hip_trace.so")
     srcs = [os.path.join(_native.CSRC, f) for f in sorted(os.listdir(_native.CSRC)) if f.endswith(".hip")]
     subprocess.check_call([_native.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DPVDER_TRACE", "-I" + _native.INCLUDE, "-I" + _native.CSRC, "-o", lib] + srcs)
+                           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DPVDER_TRACE", "-I" + _native.INCLUDE, "-I" + _native.CSRC, "-o", lib] + srcs)
     _native.LIB_PATH = lib
     L = _native.lib()
     L.pvder_debug_trace.restype = C.c_int
