@@ -332,7 +332,23 @@ def run_rank(args):
                 print("bench.py: direct RCCL all-gather unavailable (%r), using torch.distributed" % (exc,), file=sys.stderr)
             ok = torch.tensor([1 if direct is not None else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks take the same path
+            if int(ok.item()) == 1:
+                # one trial step + gather through the C path, checked against the rank's own block, before
+                # the run depends on it (a failure here still falls back to c10d on every rank)
+                try:
+                    native.rollout(actions[:1])
+                    native.drain()
+                    torch.cuda.synchronize(dev)
+                    mine = native.last()[rank * 13:(rank + 1) * 13]
+                    good = bool(torch.equal(mine, env.out))
+                except Exception as exc:
+                    good = False
+                    print("bench.py: C-side step+gather failed its trial (%r), using torch.distributed" % (exc,), file=sys.stderr)
+                ok = torch.tensor([1 if good else 0], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
+                if native is not None:
+                    env.out = native.out[0]
                 direct = native = None
                 collective = "torch.distributed.all_gather_into_tensor (RCCL), async, staged copy"
         if direct is None:

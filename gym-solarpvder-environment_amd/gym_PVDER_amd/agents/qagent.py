@@ -43,7 +43,9 @@ class BatchedQAgent:
 
     def get_discrete_state(self, obs: torch.Tensor) -> torch.Tensor:
         """[N, 11] observations -> flat table row index [N] (qagent.py:43-45)."""
-        d = ((obs.to(torch.float32) - self.low) / self.win).to(torch.int64).clamp_(0, self.bins - 1)
+        # in float64 like the reference (its observations and window sizes are float64 arrays): Q_PCC = 0 sits
+        # exactly on a bin edge of the 6-bin grid, where fp32 and fp64 arithmetic round to different bins
+        d = ((obs.to(torch.float64) - self.low) / self.win).to(torch.int64).clamp_(0, self.bins - 1)
         return (d * self._strides).sum(dim=1)
 
     def agent_action(self, obs: torch.Tensor) -> torch.Tensor:
@@ -53,6 +55,17 @@ class BatchedQAgent:
     def update_epsilon(self):                                       # agent_utilities.py:79-84
         if self.epsilon > self.explore_spec['MIN_EPSILON']:
             self.epsilon = max(self.explore_spec['MIN_EPSILON'], self.epsilon * self.explore_spec['EPSILON_DECAY'])
+
+    def update(self, s: torch.Tensor, a: torch.Tensor, r: torch.Tensor, s2: torch.Tensor, done: torch.Tensor,
+               alive: torch.Tensor):
+        """One Q-learning update per running env (qagent.py:83-103): table rows ``s`` / ``s2`` (flat
+        indices), actions ``a``, rewards ``r`` (fp32), ``done`` of this transition, ``alive`` = the env
+        was still running before it (finished envs return stale tuples and must not learn from them)."""
+        lr, gamma = self.train_spec['LEARNING_RATE'], self.train_spec['DISCOUNT']
+        cur = self.q_table[s, a]
+        new_q = (1.0 - lr) * cur + lr * (r + gamma * self.q_table[s2].max(dim=1).values)          # :88-95
+        new_q = torch.where(done, torch.zeros_like(new_q), new_q)                                   # :100-103
+        self.q_table.index_put_((s[alive], a[alive]), new_q[alive])
 
     def train(self, episodes: Optional[int] = None) -> Dict[str, List[float]]:
         """``episodes`` lockstep episodes of all N envs (the env must not auto-reset)."""
@@ -75,11 +88,7 @@ class BatchedQAgent:
                 s2 = self.get_discrete_state(obs)
                 r32 = r.to(torch.float32)
                 ep_reward += torch.where(alive, r.to(torch.float64), torch.zeros_like(ep_reward))
-                cur = self.q_table[s, a]
-                new_q = (1.0 - lr) * cur + lr * (r32 + gamma * self.q_table[s2].max(dim=1).values)   # :88-95
-                new_q = torch.where(done, torch.zeros_like(new_q), new_q)                              # :100-103
-                upd = alive                                      # finished envs return stale tuples
-                self.q_table.index_put_((s[upd], a[upd]), new_q[upd])
+                self.update(s, a, r32, s2, done, alive)
                 alive = alive & ~done
                 s = s2
                 if not bool(alive.any()):
