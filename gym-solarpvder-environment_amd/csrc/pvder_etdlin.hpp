@@ -74,62 +74,64 @@ __device__ __forceinline__ void bal_f(const ModelK<float> &P, const PkConst &K, 
 // with a shared left operand: [12 x 11] x [11 x 64 lanes].  v_mfma_f32_4x4x1_16b_f32 computes, for each of
 // its 16 blocks of 4 lanes, the outer product  D[r][j] += A[r] * B[j]  (r = row = accumulator register,
 // j = lane within the block).  With B = f_k exactly as it sits in its VGPR (one env per lane) and
-// A = M[4g + r][k] in lane r of block 0, BROADCAST to all 16 blocks by the instruction itself
-// (cbsz = 4, abid = 0), the four accumulator registers of row group g receive rows 4g..4g+3 of  M f
-// for the lane's own env -- the layout the rest of the kernel uses, no shuffles.  One MFMA does the
+// A = M[4g + r][k] BROADCAST to all 16 blocks by the instruction itself (cbsz = 4: every block takes the
+// A operand of block `abid`), the four accumulator registers of row group g receive rows 4g..4g+3 of
+// M f  for the lane's own env -- the layout the rest of the kernel uses, no shuffles.  One MFMA does the
 // work of two v_pk_fma_f32 + their operand read, on the otherwise idle matrix pipe, and each element
 // is ONE fused multiply-add in the same k order a VALU chain would use (tools/mfma_probe.hip:
 // bit-identical to fmaf; broadcast semantics checked there too).  fp32 in, fp32 out: no precision is
-// traded.  The A operands of a coefficient set (6 matrices x 3 row groups x 11 columns = 198
-// registers, only lanes 0..3 of which carry data) are read once -- three 16-byte loads per matrix row,
-// by four lanes -- and stay in the register file (512 VGPRs + AGPRs at one wave per SIMD).
-typedef float LinSetRegs[kLinMats][3][kLinRows];
-typedef float LinMatRegs[3][kLinRows];
+// traded.
+// Operand packing: `abid` selects WHICH block's four lanes are broadcast, so ONE register holds the A
+// operands of sixteen products -- lane 4k + r of the register of row group g carries M[4g + r][k], and the
+// product with column k names abid = k.  A matrix is 3 registers, a coefficient set (6 matrices) 18, the
+// tick matrix 3: 21 registers for everything the step loop multiplies with (the first version kept one
+// register per (matrix, row group, column), data in lanes 0..3 only: 231 registers, the whole AGPR file).
+typedef float LinMatRegs[3];
+typedef float LinSetRegs[kLinMats][3];
 
-// lanes 0..3: row 4g + lane of the matrix (row-major, 12 floats per row); other lanes: not read by the MFMA
+// lane 4k + r <- M[4g + r][k]  (row-major, 12 floats per row; blocks 11..15 are never selected)
 __device__ __forceinline__ void lin_load_mat(const float *__restrict__ m, int lane, LinMatRegs &A) {
-    if (lane < 4) {
+    const int k = lane >> 2, r = lane & 3;
+    const float *p = m + r * kLinRows + (k < kLinRows ? k : 0);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const v4f *p = (const v4f *)(m + (4 * g + lane) * kLinRows);
-            const v4f a = p[0], b = p[1], c = p[2];
-            A[g][0] = a.x; A[g][1] = a.y; A[g][2] = a.z; A[g][3] = a.w;
-            A[g][4] = b.x; A[g][5] = b.y; A[g][6] = b.z; A[g][7] = b.w;
-            A[g][8] = c.x; A[g][9] = c.y; A[g][10] = c.z; A[g][11] = c.w;
-            // pin the operands to the accumulation-register half of the file (the MFMA reads its A operand
-            // from there just as well): left to itself hipcc keeps them in the 256 architectural VGPRs and
-            // starves the VALU code of the step loop of registers
-#pragma unroll
-            for (int k = 0; k < kLinN; ++k) asm volatile("" : "+a"(A[g][k]));
-        }
-    }
+    for (int g = 0; g < 3; ++g) A[g] = p[4 * g * kLinRows];
 }
 __device__ __forceinline__ void lin_load_set(const float *__restrict__ set, int lane, LinSetRegs &A) {
 #pragma unroll
     for (int m = 0; m < kLinMats; ++m) lin_load_mat(set + m * kLinMatFloats, lane, A[m]);
 }
 
-// acc[j] += M_mat[j] f  for NM matrices of the set that share the input vector f (six pairs)
-template <int NM>
-__device__ __forceinline__ void lin_mfma(const LinSetRegs &A, const int (&mat)[NM], const v2 *__restrict__ f,
-                                         v4f (&acc)[NM][3]) {
-#pragma unroll
-    for (int k = 0; k < kLinN; ++k) {
-        const float fk = (k & 1) ? f[k >> 1].y : f[k >> 1].x;
+// acc[j] += M_mat[j] f  for NM matrices of the set that share the input vector f (six pairs); column K and
+// the ones behind it (abid is an immediate of the instruction: compile-time recursion over the columns)
+template <int NM, int K>
+__device__ __forceinline__ void lin_mfma_cols(const LinSetRegs &A, const int (&mat)[NM], const v2 *__restrict__ f,
+                                              v4f (&acc)[NM][3]) {
+    if constexpr (K < kLinN) {
+        const float fk = (K & 1) ? f[K >> 1].y : f[K >> 1].x;
 #pragma unroll
         for (int j = 0; j < NM; ++j)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                acc[j][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[mat[j]][g][k], fk, acc[j][g], 4, 0, 0);
+                acc[j][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[mat[j]][g], fk, acc[j][g], 4, K, 0);
+        lin_mfma_cols<NM, K + 1>(A, mat, f, acc);
+    }
+}
+template <int NM>
+__device__ __forceinline__ void lin_mfma(const LinSetRegs &A, const int (&mat)[NM], const v2 *__restrict__ f,
+                                         v4f (&acc)[NM][3]) {
+    lin_mfma_cols<NM, 0>(A, mat, f, acc);
+}
+template <int K>
+__device__ __forceinline__ void lin_mfma1_cols(const LinMatRegs &A, const v2 *__restrict__ f, v4f (&acc)[3]) {
+    if constexpr (K < kLinN) {
+        const float fk = (K & 1) ? f[K >> 1].y : f[K >> 1].x;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g], fk, acc[g], 4, K, 0);
+        lin_mfma1_cols<K + 1>(A, f, acc);
     }
 }
 __device__ __forceinline__ void lin_mfma1(const LinMatRegs &A, const v2 *__restrict__ f, v4f (&acc)[3]) {
-#pragma unroll
-    for (int k = 0; k < kLinN; ++k) {
-        const float fk = (k & 1) ? f[k >> 1].y : f[k >> 1].x;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g][k], fk, acc[g], 4, 0, 0);
-    }
+    lin_mfma1_cols<0>(A, f, acc);
 }
 // state in accumulator layout (rows 0-3, 4-7, 8-11) -> the six pairs bal_f reads
 __device__ __forceinline__ void lin_pairs(const v4f (&Y)[3], v2 *__restrict__ y) {

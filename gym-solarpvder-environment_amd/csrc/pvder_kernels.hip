@@ -650,7 +650,8 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
 // a scratch allocation -- AMDGPU callees save callee-saved VGPRs even when they never return -- and
 // with scratch enabled the workgroups start ~2 us later).
 typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
-__device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
+__device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, const uint8_t *act = nullptr,
+                                                 long long out_off = 0) {
     const int run_status = 0;
     const ModelK<float> &P = A.P;
     const StepK<float> &C = A.C;
@@ -661,8 +662,8 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer) {
     int32_t *__restrict__ istate = A.istate;
     float *__restrict__ ev_vg = A.ev_vg;
     float *__restrict__ ev_si = A.ev_si;
-    const uint8_t *__restrict__ action = A.action;
-    float *__restrict__ out = A.out;
+    const uint8_t *__restrict__ action = act ? act : A.action;       // (rollouts: the step's own action row / output block)
+    float *__restrict__ out = A.out + out_off;
     float *__restrict__ stats = A.stats;
     const int n_env = A.n_env;
     constexpr int NS = 23, NP = pvder::NP;
@@ -1082,23 +1083,273 @@ struct LinArgs {
     EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
     LinK Lk;
 };
+// open-loop rollouts (pvder_plan_rollout): the arguments that move from step to step
+struct RollK {
+    const uint8_t *actions;          // [n_steps][n_env]
+    int n_steps;
+    long long out_stride;            // floats between the output blocks of consecutive steps (0: one block)
+    int *progress;                   // [n_wg]: steps of the rollout the workgroup has behind it
+    int resume;                      // fused kernel: 0 = start at step 0, 1 = start at progress[wg]
+    int max_finish;                  // finish kernel: at most this many steps per workgroup
+};
+
+// first segment of an env step that starts at sim time step ksub: ONE integer division gives the event
+// row in force, whether an event starts exactly there, and `until` = sim time steps to the next
+// event-row change; the segment's inputs and schedule row are requested right away
+struct LinSeg {
+    int row, until, seg;
+    bool evjump;                         // the segment starts at an EVENT (not just a new action)
+    float in_vg, in_si;
+    unsigned long long sch;
+};
+__device__ __forceinline__ LinSeg lin_first_segment(const StepK<float> &C, const LinK &Lk, int ksub, const float *ev_vg,
+                                                    const float *ev_si, size_t N, int ec) {
+    constexpr int kBig = 0x3fffffff;
+    LinSeg s;
+    s.row = 0; s.until = kBig; s.evjump = false;
+    if (C.ev_count > 0) {
+        const int d = ksub - C.ev_s0;
+        if (d < 0) {
+            s.until = -d;
+        } else {
+            const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
+            s.row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
+            s.evjump = rd == 0 && qd < C.ev_count;
+            s.until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
+        }
+    }
+    s.seg = s.until < C.n_sub ? s.until : C.n_sub;
+    s.in_vg = ev_vg[(size_t)s.row * N + ec];
+    s.in_si = ev_si[(size_t)s.row * N + ec];
+    s.sch = Lk.sched[s.seg - 1];
+    return s;
+}
+
+// balance check of a three-phase state (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
+__device__ __forceinline__ bool lin_unbalanced(const float *ys) {
+    using namespace pvder;
+    const v2 ia = mk2(ys[0], ys[1]), xa = mk2(ys[2], ys[3]), ua = mk2(ys[4], ys[5]);
+    const float ei = unbalance2(ia, mk2(ys[6], ys[7]), mk2(ys[12], ys[13]));
+    const float ex = unbalance2(xa, mk2(ys[8], ys[9]), mk2(ys[14], ys[15]));
+    const float eu = unbalance2(ua, mk2(ys[10], ys[11]), mk2(ys[16], ys[17]));
+    const v2 i2 = ia * ia, x2 = xa * xa;
+    return ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
+}
+
+// 23-state rows <-> the accumulator layout of the 11-state reduction (rows 0-3, 4-7, 8-11)
+template <int PH>
+__device__ __forceinline__ void lin_from_rows(const float *ys, pvder::v4f (&Y)[3]) {
+    constexpr int B = 6 * PH;
+    Y[0] = {ys[0], ys[1], ys[2], ys[3]};
+    Y[1] = {ys[4], ys[5], ys[B], ys[B + 1]};
+    Y[2] = {ys[B + 2], ys[B + 3], ys[B + 4], 0.f};
+}
+template <int PH>
+__device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys) {   // phases b, c = phase a rotated by -/+ 120 degrees
+    using namespace pvder;
+    constexpr int B = 6 * PH;
+    const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);
+    const v2 z3[3] = {mk2(Y[0].x, Y[0].y), mk2(Y[0].z, Y[0].w), mk2(Y[1].x, Y[1].y)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ys[2 * k] = z3[k].x; ys[2 * k + 1] = z3[k].y;
+        if constexpr (PH == 3) {
+            const v2 hz = bc2(-0.5f) * z3[k], jz = swp(z3[k]) * jh3;
+            const v2 zb = hz - jz, zc = hz + jz;
+            ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
+            ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
+        }
+    }
+    ys[B] = Y[1].z; ys[B + 1] = Y[1].w; ys[B + 2] = Y[2].x; ys[B + 3] = Y[2].y; ys[B + 4] = Y[2].z;
+}
+
+// One env step of the lanes with `run` set, state Y in registers: per-lane schedule, wave-uniform trip
+// count.  Returns the lanes that must be handed to the 23-state path (their Y is then meaningless).
+template <int PH>
+__device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
+                                              int &cur, pvder::v4f (&Y)[3], float qref, float vdcref, int ec, LinSeg sg,
+                                              bool run, bool defer, int trace_step) {
+    using namespace pvder;
+    constexpr int kBig = 0x3fffffff;
+    const ModelK<float> &P = G.A.P;
+    const StepK<float> &C = G.A.C;
+    const EtdK &Ec = G.A.Ec;
+    const size_t N = (size_t)G.A.n_env;
+    const PkConst K = make_pkconst(P);
+    // outer-loop gains pinned to SGPRs (see step_etdrk4_bal_kernel: the dispatch-packet trap)
+    float g_kpdc = P.KpDC, g_kpq = -P.KpQ, g_kidc = P.KiDC, g_kiq = -P.KiQ;
+    asm volatile("" : "+s"(g_kpdc), "+s"(g_kpq), "+s"(g_kidc), "+s"(g_kiq));
+    const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
+    float i2m = Ec.i2_to_m2;
+    asm volatile("" : "+v"(i2m));
+    int spos = 0;                        // sim time steps of the env step behind this lane
+    bool start = true;                   // this lane is at the start of a segment (its tick is due)
+    bool done = !run;
+    SubPk S;
+    for (int it = 0;; ++it) {
+        if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
+        if (trace_step == 0 && it < 16) PVDER_TRACE_AT(3 + it);
+        v2 yp[6], F[6];
+        float m2a, ir2a;
+        if (__builtin_amdgcn_readfirstlane(__any((int)(start && !done)))) {
+            // ---- a segment starts (new action at the start of the env step, or a new event row): the
+            // TICK behind the jump, exponential Euler  y+ = y + h phi1(hL) f(y).  The jump kicks the stiff
+            // loop; the exponential carries that transient exactly, and over one tick the rest of f
+            // hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  An EVENT may make
+            // |m| overshoot inside the tick: 3 % clearance there (see make_etd).
+            // (lanes in the middle of a segment recompute S from the inputs they hold: same values)
+            make_sub_pk(P, sg.in_vg, sg.in_si, S);
+            lin_pairs(Y, yp);
+            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
+            v4f acc[3] = {Y[0], Y[1], Y[2]};
+            lin_mfma1(At, F, acc);
+            const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
+            const float guard = sg.evjump ? Ec.sat2_event : Ec.sat2_smooth;
+            const bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+            if (start && !done) {
+                defer |= trip;
+                Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
+                start = false;
+            }
+        }
+        // ---- the segment's next ETD3RK step (schedule row: one set index per byte, 0 = segment finished)
+        const int sidx = (int)(sg.sch & 0xffull);
+        bool todo = !done && sidx != 0;
+        // One pass per DISTINCT set among the wave's lanes: a single pass while the envs run in lockstep
+        for (;;) {
+            const unsigned long long tm = __ballot((int)todo);
+            if (tm == 0) break;
+            const int s_now = __builtin_amdgcn_readlane(sidx, (int)__builtin_ctzll(tm));
+            if (s_now != cur) {
+                lin_load_set(G.Lk.lcoef + kLinMatFloats + (size_t)(s_now - 1) * kLinSetFloats, lane, Ac);
+                cur = s_now;
+            }
+            float m2x, ir2x, m2b;
+            lin_pairs(Y, yp);
+            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
+            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(24, F[0].x + F[2].y + F[3].x + F[5].x);
+            v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
+            {
+                const int m3[3] = {LM21, LM31, LM41};
+                lin_mfma<3>(Ac, m3, F, acc3);                     // a = y + M21 F1; b, y+ started
+            }
+            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(25, acc3[0][0].x + acc3[1][1].x + acc3[2][2].x);
+            lin_pairs(acc3[0], yp);
+            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2x, ir2x);
+            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(26, F[0].x + F[2].y + F[3].x + F[5].x);
+            v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
+            {
+                const int m2[2] = {LM32, LM42};
+                lin_mfma<2>(Ac, m2, F, acc2);                     // b complete
+            }
+            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(27, acc2[0][0].x + acc2[1][1].x);
+            lin_pairs(acc2[0], yp);
+            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2b, ir2x);
+            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(28, F[0].x + F[2].y + F[3].x + F[5].x);
+            v4f acc1[1][3] = {{acc2[1][0], acc2[1][1], acc2[1][2]}};
+            {
+                const int m1[1] = {LM43};
+                lin_mfma<1>(Ac, m1, F, acc1);                     // y+
+            }
+            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(29, acc1[0][0].x + acc1[0][2].x);
+            // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
+            const float est = fmaxf(fmaxf(fabsf(acc1[0][0].x - acc2[0][0].x), fabsf(acc1[0][0].y - acc2[0][0].y)),
+                                    fabsf(acc1[0][1].z - acc2[0][1].z));
+            const v2 mn = fma2(bc2(P.KpG), mk2(acc1[0][1].x, acc1[0][1].y), mk2(acc1[0][0].z, acc1[0][0].w));
+            // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
+            const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+            const bool trip = fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
+            if (todo && sidx == s_now) {
+                defer |= trip;
+                Y[0] = acc1[0][0]; Y[1] = acc1[0][1]; Y[2] = acc1[0][2];
+                sg.sch >>= 8;
+                todo = false;
+            }
+        }
+        // ---- segment finished?  Then the next one (if any) starts at an event row change
+        const bool fin = !done && !start && (sg.sch & 0xffull) == 0;
+        if (__builtin_amdgcn_readfirstlane(__any((int)fin))) {
+            if (fin) {
+                spos += sg.seg;
+                sg.until -= sg.seg;
+                done = spos >= C.n_sub;
+                if (!done) {                         // an event row starts here
+                    sg.row += 1;
+                    sg.until = sg.row < C.ev_count ? C.ev_ds : kBig;
+                    sg.evjump = true;
+                    const int left = C.n_sub - spos;
+                    sg.seg = sg.until < left ? sg.until : left;
+                    sg.in_vg = G.A.ev_vg[(size_t)sg.row * N + ec];
+                    sg.in_si = G.A.ev_si[(size_t)sg.row * N + ec];
+                    sg.sch = G.Lk.sched[sg.seg - 1];
+                    start = true;
+                }
+            }
+        }
+    }
+    return defer;
+}
+
+// One env transition of the workgroup's envs through memory -- the body of step_etdlin_kernel, also
+// run step after step by the rollout's finish kernel.  act / out_off select the action row and the
+// output block of the step (rollouts); the kernel arguments are re-read through laundered copies of
+// the kernarg pointer where keeping them live across the step loop would not fit the scalar
+// register file (hipcc then spills SGPRs and gives the kernel a private segment).
+template <int PH>
+__device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
+                                              int &cur, const uint8_t *__restrict__ act, long long out_off, int stats_fresh) {
+    using namespace pvder;
+    const EtdArgs &A = G.A;
+    constexpr int NS = 6 * PH + 5;
+    const size_t N = (size_t)A.n_env;
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(A.C, A.fstate, A.istate, act, A.n_env, L, ys);
+    // ksub is the first state word to arrive: the event inputs and the schedule row of the first segment
+    // are requested while the other state rows are still in flight
+    const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
+    PVDER_TRACE_AT(1);
+    bool defer = PH == 3 && A.force_full != 0;
+    if constexpr (PH == 3) defer |= L.run && lin_unbalanced(ys);
+    {
+        // every lane enters (a lane that does not run is `done` from the start): the coefficient registers are
+        // packed ACROSS the lanes of the wave -- a set reloaded inside the loop must be loaded by all 64
+        v4f Y[3];
+        lin_from_rows<PH>(ys, Y);
+        PVDER_TRACE_AT(2);
+        defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, 0);
+        if (L.run && !defer) {
+            lin_to_rows<PH>(Y, ys);
+            L.ksub += A.C.n_sub;
+            L.steps += 1;
+        }
+    }
+    PVDER_TRACE_AT(20);
+    KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const EtdArgs &E = *(const EtdArgs *)ka;
+    if (defer) {
+        if constexpr (PH == 1) E.istate[PVDER_I_STATUS * (size_t)E.n_env + L.e] = kDeferred;   // marker for the follow-up launch
+        L.run = false;
+        L.live = false;
+    }
+    epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out + out_off, E.stats, E.n_env,
+                        stats_fresh);
+    PVDER_TRACE_AT(21);
+    if constexpr (PH == 3) {
+        // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state
+        // path right here -- no second launch
+        if (__syncthreads_or((int)defer)) {
+            KernargPtr kb = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kb));
+            etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
+        }
+    }
+}
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
     using namespace pvder;
-    const EtdArgs &A = G.A;
-    const ModelK<float> &P = A.P;
-    const StepK<float> &C = A.C;
-    const EtdK &Ec = A.Ec;
-    float *__restrict__ fstate = A.fstate;
-    int32_t *__restrict__ istate = A.istate;
-    float *__restrict__ ev_vg = A.ev_vg;
-    float *__restrict__ ev_si = A.ev_si;
-    const uint8_t *__restrict__ action = A.action;
-    const int n_env = A.n_env;
-    constexpr int NS = 6 * PH + 5, B = 6 * PH;
-    constexpr int kBig = 0x3fffffff;
-    const size_t N = (size_t)n_env;
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
     // first ETD3RK set stay in registers for the whole launch; another set replaces the latter only when
@@ -1110,193 +1361,195 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
     lin_load_mat(G.Lk.lcoef, lane, At);
     lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
     int cur = 1;
-    Lane<float> L;
-    float ys[NS];
-    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys);
-    // ---- first segment of the env step.  One integer division per launch gives the event row in force
-    // at ksub, whether an event starts exactly there, and `until` = sim time steps to the next event-row
-    // change.  ksub is the first state word to arrive: the event inputs and the schedule row of the
-    // segment are requested while the other state rows are still in flight.
-    int row = 0, until = kBig;
-    bool evjump = false;                 // the current segment starts at an EVENT (not just a new action)
-    if (C.ev_count > 0) {
-        const int d = L.ksub - C.ev_s0;
-        if (d < 0) {
-            until = -d;
-        } else {
-            const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
-            row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
-            evjump = rd == 0 && qd < C.ev_count;
-            until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
-        }
-    }
-    int spos = 0;                        // sim time steps of the env step behind this lane
-    int seg = until < C.n_sub ? until : C.n_sub;
-    float in_vg = ev_vg[(size_t)row * N + L.ec], in_si = ev_si[(size_t)row * N + L.ec];
-    unsigned long long sch = G.Lk.sched[seg - 1];
-    PVDER_TRACE_AT(1);
-    bool defer = PH == 3 && A.force_full != 0;
-    if (L.run) {
-        v4f Y[3] = {{ys[0], ys[1], ys[2], ys[3]}, {ys[4], ys[5], ys[B], ys[B + 1]}, {ys[B + 2], ys[B + 3], ys[B + 4], 0.f}};
-        if constexpr (PH == 3) {   // balance check (tolerances: 2e-5 relative on i and x, 2e-9 absolute on u ~ 1e-6)
-            const v2 ia = mk2(ys[0], ys[1]), xa = mk2(ys[2], ys[3]), ua = mk2(ys[4], ys[5]);
-            const float ei = unbalance2(ia, mk2(ys[6], ys[7]), mk2(ys[12], ys[13]));
-            const float ex = unbalance2(xa, mk2(ys[8], ys[9]), mk2(ys[14], ys[15]));
-            const float eu = unbalance2(ua, mk2(ys[10], ys[11]), mk2(ys[16], ys[17]));
-            const v2 i2 = ia * ia, x2 = xa * xa;
-            defer |= ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
-        }
-        const PkConst K = make_pkconst(P);
-        // outer-loop gains pinned to SGPRs (see step_etdrk4_bal_kernel: the dispatch-packet trap)
-        float g_kpdc = P.KpDC, g_kpq = -P.KpQ, g_kidc = P.KiDC, g_kiq = -P.KiQ;
-        asm volatile("" : "+s"(g_kpdc), "+s"(g_kpq), "+s"(g_kidc), "+s"(g_kiq));
-        const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
-        float i2m = Ec.i2_to_m2;
-        asm volatile("" : "+v"(i2m));
-        bool start = true;                   // this lane is at the start of a segment (its tick is due)
-        bool done = false;
-        SubPk S;
-        PVDER_TRACE_AT(2);
-        for (int it = 0;; ++it) {
-            if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
-            if (it < 16) PVDER_TRACE_AT(3 + it);
-            v2 yp[6], F[6];
-            float m2a, ir2a;
-            if (__builtin_amdgcn_readfirstlane(__any((int)(start && !done)))) {
-                // ---- a segment starts (new action at the start of the env step, or a new event row): the
-                // TICK behind the jump, exponential Euler  y+ = y + h phi1(hL) f(y).  The jump kicks the stiff
-                // loop; the exponential carries that transient exactly, and over one tick the rest of f
-                // hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  An EVENT may make
-                // |m| overshoot inside the tick: 3 % clearance there (see make_etd).
-                // (lanes in the middle of a segment recompute S from the inputs they hold: same values)
-                make_sub_pk(P, in_vg, in_si, S);
-                lin_pairs(Y, yp);
-                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
-                v4f acc[3] = {Y[0], Y[1], Y[2]};
-                lin_mfma1(At, F, acc);
-                const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
-                const float guard = evjump ? Ec.sat2_event : Ec.sat2_smooth;
-                const bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
-                if (start && !done) {
-                    defer |= trip;
-                    Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
-                    start = false;
-                }
-            }
-            // ---- the segment's next ETD3RK step (schedule row: one set index per byte, 0 = segment finished)
-            const int sidx = (int)(sch & 0xffull);
-            bool todo = !done && sidx != 0;
-            // One pass per DISTINCT set among the wave's lanes: a single pass while the envs run in lockstep
-            for (;;) {
-                const unsigned long long tm = __ballot((int)todo);
-                if (tm == 0) break;
-                const int s_now = __builtin_amdgcn_readlane(sidx, (int)__builtin_ctzll(tm));
-                if (s_now != cur) {
-                    lin_load_set(G.Lk.lcoef + kLinMatFloats + (size_t)(s_now - 1) * kLinSetFloats, lane, Ac);
-                    cur = s_now;
-                }
-                float m2x, ir2x, m2b;
-                lin_pairs(Y, yp);
-                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
-                if (it == 1) PVDER_TRACE_DEP(24, F[0].x + F[2].y + F[3].x + F[5].x);
-                v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
-                {
-                    const int m3[3] = {LM21, LM31, LM41};
-                    lin_mfma<3>(Ac, m3, F, acc3);                     // a = y + M21 F1; b, y+ started
-                }
-                if (it == 1) PVDER_TRACE_DEP(25, acc3[0][0].x + acc3[1][1].x + acc3[2][2].x);
-                lin_pairs(acc3[0], yp);
-                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2x, ir2x);
-                if (it == 1) PVDER_TRACE_DEP(26, F[0].x + F[2].y + F[3].x + F[5].x);
-                v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
-                {
-                    const int m2[2] = {LM32, LM42};
-                    lin_mfma<2>(Ac, m2, F, acc2);                     // b complete
-                }
-                if (it == 1) PVDER_TRACE_DEP(27, acc2[0][0].x + acc2[1][1].x);
-                lin_pairs(acc2[0], yp);
-                bal_f<PH>(P, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2b, ir2x);
-                if (it == 1) PVDER_TRACE_DEP(28, F[0].x + F[2].y + F[3].x + F[5].x);
-                v4f acc1[1][3] = {{acc2[1][0], acc2[1][1], acc2[1][2]}};
-                {
-                    const int m1[1] = {LM43};
-                    lin_mfma<1>(Ac, m1, F, acc1);                     // y+
-                }
-                if (it == 1) PVDER_TRACE_DEP(29, acc1[0][0].x + acc1[0][2].x);
-                // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
-                const float est = fmaxf(fmaxf(fabsf(acc1[0][0].x - acc2[0][0].x), fabsf(acc1[0][0].y - acc2[0][0].y)),
-                                        fabsf(acc1[0][1].z - acc2[0][1].z));
-                const v2 mn = fma2(bc2(P.KpG), mk2(acc1[0][1].x, acc1[0][1].y), mk2(acc1[0][0].z, acc1[0][0].w));
-                // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
-                const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
-                const bool trip = fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
-                if (todo && sidx == s_now) {
-                    defer |= trip;
-                    Y[0] = acc1[0][0]; Y[1] = acc1[0][1]; Y[2] = acc1[0][2];
-                    sch >>= 8;
-                    todo = false;
-                }
-            }
-            // ---- segment finished?  Then the next one (if any) starts at an event row change
-            const bool fin = !done && !start && (sch & 0xffull) == 0;
-            if (__builtin_amdgcn_readfirstlane(__any((int)fin))) {
-                if (fin) {
-                    spos += seg;
-                    until -= seg;
-                    done = spos >= C.n_sub;
-                    if (!done) {                         // an event row starts here
-                        row += 1;
-                        until = row < C.ev_count ? C.ev_ds : kBig;
-                        evjump = true;
-                        const int left = C.n_sub - spos;
-                        seg = until < left ? until : left;
-                        in_vg = ev_vg[(size_t)row * N + L.ec];
-                        in_si = ev_si[(size_t)row * N + L.ec];
-                        sch = G.Lk.sched[seg - 1];
-                        start = true;
-                    }
-                }
-            }
-        }
-        if (!defer) {
-            const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);
-            const v2 z3[3] = {mk2(Y[0].x, Y[0].y), mk2(Y[0].z, Y[0].w), mk2(Y[1].x, Y[1].y)};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ys[2 * k] = z3[k].x; ys[2 * k + 1] = z3[k].y;
-                if constexpr (PH == 3) {
-                    const v2 hz = bc2(-0.5f) * z3[k], jz = swp(z3[k]) * jh3;
-                    const v2 zb = hz - jz, zc = hz + jz;
-                    ys[6 + 2 * k] = zb.x; ys[6 + 2 * k + 1] = zb.y;
-                    ys[12 + 2 * k] = zc.x; ys[12 + 2 * k + 1] = zc.y;
-                }
-            }
-            ys[B] = Y[1].z; ys[B + 1] = Y[1].w; ys[B + 2] = Y[2].x; ys[B + 3] = Y[2].y; ys[B + 4] = Y[2].z;
-            L.ksub += C.n_sub;
-            L.steps += 1;
-        }
-    }
-    PVDER_TRACE_AT(20);
-    // The epilogue re-reads its arguments through a laundered copy of the kernarg pointer: kept live
-    // across the step loop they do not fit the scalar register file next to the loop's own constants
-    // (hipcc then spills SGPRs and gives the kernel a private segment).
-    KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    lin_step_body<PH>(G, lane, At, Ac, cur, G.A.action, 0, G.A.stats_fresh);
+}
+
+// =============================================================================================
+// Open-loop rollouts (pvder_plan_rollout with a scratch buffer, etdlin, three-phase): n_steps env steps in
+// ONE launch, the 11-state reduction in registers from the first step to the last.  A per-step launch
+// spends 3 us waiting for its state rows and 2 us writing them back (41 rows) around 4.6 us of
+// integration; the fused loop reads the state once, writes it once, and per step only computes and stores
+// the 13 output rows -- with the SAME code the per-step launch runs (lin_integrate; rotation into the
+// 23-row form; outputs / reward_of), so the results are bit-identical to n_steps single launches.
+// What the loop does NOT carry is everything rare: a workgroup leaves the loop -- its state as of the
+// start of that step written back -- at the first step in which one of its envs is off balance or near a
+// limit (23-state path), would finish its episode (done / auto-reset logic, known BEFORE the step: time
+// and step counters), is not running, or comes out non-finite.  step_etdlin_finish_kernel then takes
+// the workgroup through the remaining steps one at a time, through memory, with the per-step body.
+// =============================================================================================
+struct RollArgs {
+    LinArgs G;                       // at kernarg offset 0 (the 23-state tail of the finish kernel re-reads G.A from there)
+    RollK Rk;
+};
+typedef __attribute__((address_space(4))) const RollArgs *RollKernargPtr;
+// the kernel arguments through a laundered copy of the kernarg pointer: hipcc must re-read what it needs
+// (scalar loads, cache hits) instead of keeping hundreds of loop-invariant values -- parameters copied
+// into VGPRs, packed constants -- live across the step loop, where every register is taken
+__device__ __forceinline__ const RollArgs &roll_args() {
+    RollKernargPtr ka = (RollKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));
-    const EtdArgs &E = *(const EtdArgs *)ka;
-    if (defer) {
-        if constexpr (PH == 1) E.istate[PVDER_I_STATUS * (size_t)E.n_env + L.e] = kDeferred;   // marker for the follow-up launch
-        L.run = false;
-        L.live = false;
+    return *(const RollArgs *)ka;
+}
+
+template <int PH>
+__global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollArgs Q) {
+    using namespace pvder;
+    constexpr int NS = 6 * PH + 5;
+    const int lane = threadIdx.x & 63;
+    LinMatRegs At;
+    LinSetRegs Ac;
+    lin_load_mat(Q.G.Lk.lcoef, lane, At);
+    lin_load_set(Q.G.Lk.lcoef + kLinMatFloats, lane, Ac);
+    int cur = 1;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    v4f Y[3];
+    float qref, vdcref;
+    int ksub, steps;
+    bool bail;
+    {
+        const EtdArgs &A = Q.G.A;
+        const size_t N = (size_t)A.n_env;
+        const int ec = e < A.n_env ? e : A.n_env - 1;
+        float ys[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) ys[q] = ld(&A.fstate[(size_t)q * N + ec]);
+        qref = ld(&A.fstate[(size_t)NS * N + ec]);
+        vdcref = ld(&A.fstate[(size_t)(NS + 1) * N + ec]);
+        ksub = ld(&A.istate[PVDER_I_KSUB * N + ec]);
+        steps = ld(&A.istate[PVDER_I_STEPS * N + ec]);
+        const int status = ld(&A.istate[PVDER_I_STATUS * N + ec]);
+        bail = (PH == 3 && A.force_full != 0) || status != 0;
+        if constexpr (PH == 3) bail |= lin_unbalanced(ys);
+        lin_from_rows<PH>(ys, Y);
     }
-    epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out, E.stats, E.n_env, E.stats_fresh);
-    PVDER_TRACE_AT(21);
-    if constexpr (PH == 3) {
-        if (__syncthreads_or((int)defer)) {
-            KernargPtr kb = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kb));
-            etdrk4_full_tail(*(const EtdArgs *)kb, defer);
+    __shared__ float park[13][kBlock];          // the state at the start of the current step, should the workgroup leave
+    float last_reward = 0.f, bad = 0.f;
+    const int k_first = Q.Rk.resume ? Q.Rk.progress[blockIdx.x] : 0;
+    int k = k_first;
+    if (!__syncthreads_or((int)bail)) {
+        for (;; ++k) {
+            const RollArgs &Q1 = roll_args();
+            if (k >= Q1.Rk.n_steps) break;
+            const EtdArgs &A = Q1.G.A;
+            const size_t N = (size_t)A.n_env;
+            const int ec = e < A.n_env ? e : A.n_env - 1;
+            park[0][threadIdx.x] = Y[0].x; park[1][threadIdx.x] = Y[0].y; park[2][threadIdx.x] = Y[0].z;
+            park[3][threadIdx.x] = Y[0].w; park[4][threadIdx.x] = Y[1].x; park[5][threadIdx.x] = Y[1].y;
+            park[6][threadIdx.x] = Y[1].z; park[7][threadIdx.x] = Y[1].w; park[8][threadIdx.x] = Y[2].x;
+            park[9][threadIdx.x] = Y[2].y; park[10][threadIdx.x] = Y[2].z;
+            park[11][threadIdx.x] = qref; park[12][threadIdx.x] = vdcref;
+            // the step that would END the episode is not taken here (done / auto-reset live in the per-step body)
+            bool leave = ksub + A.C.n_sub >= A.C.max_ksub || (A.C.max_steps > 0 && steps + 1 >= A.C.max_steps);
+            // action_calc (PVDER_env.py:198-229)
+            const int a = ld(&Q1.Rk.actions[(size_t)k * N + ec]);
+            bad = 0.f;
+            if (a == 1) qref += A.C.dq;
+            else if (a == 2) qref -= A.C.dq;
+            else if (a == 3) vdcref += A.C.dv;
+            else if (a == 4) vdcref -= A.C.dv;
+            else if (a != 0) bad = 1.f;
+            if (!__builtin_amdgcn_readfirstlane(__any((int)leave))) {
+                const LinSeg sg = lin_first_segment(A.C, Q1.G.Lk, ksub, A.ev_vg, A.ev_si, N, ec);
+                leave = lin_integrate<PH>(Q1.G, lane, At, Ac, cur, Y, qref, vdcref, ec, sg, true, false, k);
+            }
+            float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
+                        fabsf(Y[1].z) + fabsf(Y[1].w) + fabsf(Y[2].x) + fabsf(Y[2].y) + fabsf(Y[2].z);
+            leave |= !(chk < 1e30f);
+            if (__syncthreads_or((int)leave)) {
+                Y[0] = {park[0][threadIdx.x], park[1][threadIdx.x], park[2][threadIdx.x], park[3][threadIdx.x]};
+                Y[1] = {park[4][threadIdx.x], park[5][threadIdx.x], park[6][threadIdx.x], park[7][threadIdx.x]};
+                Y[2] = {park[8][threadIdx.x], park[9][threadIdx.x], park[10][threadIdx.x], 0.f};
+                qref = park[11][threadIdx.x]; vdcref = park[12][threadIdx.x];
+                break;
+            }
+            // observation and reward at (y(tStop), tStop), exactly as the per-step epilogue computes them
+            const RollArgs &Q2 = roll_args();
+            const EtdArgs &B = Q2.G.A;
+            ksub += B.C.n_sub;
+            steps += 1;
+            float ys[NS];
+            lin_to_rows<PH>(Y, ys);
+            SubK<float, PH> S;
+            {
+                const int row = event_row(ksub, B.C.ev_s0, B.C.ev_ds, B.C.ev_count);
+                make_sub<float, PH>(B.P, B.ev_vg[(size_t)row * N + ec], B.ev_si[(size_t)row * N + ec], S);
+            }
+            float iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
+            outputs<float, PH>(B.P, S, ys, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
+            last_reward = reward_of<float>(B.C, B.P, vrms, Ppcc, Qpcc, ys[6 * PH], vdcref);
+            if (e < B.n_env) {
+                float *o = B.out + k * Q2.Rk.out_stride;
+                write_obs<float>(o, N, e, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ys[6 * PH], ppv, vdcref, qref,
+                                 (float)ksub * (float)(1.0 / 60.0) * B.C.inv_tmax);
+                st(&o[PVDER_O_REWARD * N + e], last_reward);
+                st(&o[PVDER_O_DONE * N + e], 0.f);
+            }
         }
     }
+    // state -> memory (as of the last completed step), statistics of the last step if it was completed here
+    const RollArgs &Q3 = roll_args();
+    const EtdArgs &A = Q3.G.A;
+    const size_t N = (size_t)A.n_env;
+    const bool live = e < A.n_env;
+    if (live && k > k_first) {
+        float ys[NS];
+        lin_to_rows<PH>(Y, ys);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) st(&A.fstate[(size_t)q * N + e], ys[q]);
+        st(&A.fstate[(size_t)NS * N + e], qref);
+        st(&A.fstate[(size_t)(NS + 1) * N + e], vdcref);
+        st(&A.istate[PVDER_I_KSUB * N + e], (int32_t)ksub);
+        st(&A.istate[PVDER_I_STEPS * N + e], (int32_t)steps);
+    }
+    if (k == Q3.Rk.n_steps && k > k_first && A.stats) {
+        __shared__ float wsum[2][kBlock / 64];
+        const float r = wave_sum_to_lane63(live ? last_reward : 0.f);
+        const float ba = wave_sum_to_lane63(live ? bad : 0.f);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) { wsum[0][w] = r; wsum[1][w] = ba; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float t = 0.f;
+            if (threadIdx.x == 0 || threadIdx.x == 3)
+#pragma unroll
+                for (int q = 0; q < kBlock / 64; ++q) t += wsum[threadIdx.x == 0 ? 0 : 1][q];
+            A.stats[4 * (size_t)blockIdx.x + threadIdx.x] = t;         // (#done = #non-finite = 0 in a step taken here)
+        }
+    }
+    if (threadIdx.x == 0) Q3.Rk.progress[blockIdx.x] = k;
+}
+
+// the steps the fused kernel left to a workgroup, one at a time through memory (usually: the step that
+// ends an episode, once per episode)
+template <int PH>
+__global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollArgs Q) {
+    using namespace pvder;
+    const LinArgs &G = Q.G;
+    const RollK &Rk = Q.Rk;
+    const int k0 = Rk.progress[blockIdx.x];
+    if (k0 >= Rk.n_steps) return;
+    const int k1 = Rk.n_steps - k0 > Rk.max_finish ? k0 + Rk.max_finish : Rk.n_steps;
+    const int lane = threadIdx.x & 63;
+    for (int k = k0; k < k1; ++k) {
+        if (k > 0 && Rk.out_stride != 0 && !G.A.R.enabled) {      // stale tuples follow the output block (carry_stale_kernel)
+            const int e = blockIdx.x * kBlock + threadIdx.x;
+            const size_t N = (size_t)G.A.n_env;
+            if (e < G.A.n_env && G.A.istate[PVDER_I_STATUS * N + e] != 0) {
+                float *o = G.A.out + k * Rk.out_stride;
+#pragma unroll
+                for (int q = 0; q < PVDER_OROWS; ++q) o[(size_t)q * N + e] = (o - Rk.out_stride)[(size_t)q * N + e];
+            }
+        }
+        LinMatRegs At;
+        LinSetRegs Ac;
+        lin_load_mat(G.Lk.lcoef, lane, At);
+        lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
+        int cur = 1;
+        lin_step_body<PH>(G, lane, At, Ac, cur, Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1);
+        __threadfence();                 // the next step of this workgroup reads what this one wrote
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Rk.progress[blockIdx.x] = k1;
 }
 
 // =============================================================================================
@@ -1634,6 +1887,21 @@ int reset_impl(const double *par, const pvder_step_cfg *cfg, const pvder_autores
     return hip_rc(hipGetLastError());
 }
 
+// A finished env returns the stale tuple (PVDER_env.py:145-152) and the step kernels leave its rows of the
+// output block alone.  When a step writes ANOTHER block than the previous one (rollouts with per-step
+// blocks, the two alternating blocks of the step + all-gather path) the tuple is carried over first.
+// Only enqueued without auto-reset (with it no env is ever finished on entry).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void carry_stale_kernel(const int32_t *__restrict__ istate, const T *__restrict__ prev,
+                                                             T *__restrict__ out, int n_env) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_env) return;
+    const size_t N = (size_t)n_env;
+    if (istate[PVDER_I_STATUS * N + e] == 0) return;
+#pragma unroll
+    for (int q = 0; q < PVDER_OROWS; ++q) out[(size_t)q * N + e] = prev[(size_t)q * N + e];
+}
+
 // ---- plans: everything a step launch needs that does not change from step to step, folded once
 // (parameter folding, phi-function scalars, reset arguments).  The per-call entry points below build
 // one on the stack; pvder_plan_create() keeps one on the heap for callers that step many times.
@@ -1697,11 +1965,17 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
 }
 
 int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action,
-                void *out, double *hstep, float *stats, int zero_stats, void *stream) {
+                void *out, double *hstep, float *stats, int zero_stats, void *stream, const void *out_prev = nullptr) {
     if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
     const int n_env = p.n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
+    if (out_prev && out_prev != out && !p.R.enabled) {       // stale tuples of finished envs follow the output block
+        if (p.integrator == PVDER_INT_RK45)
+            hipLaunchKernelGGL(carry_stale_kernel<double>, grid, block, 0, st, istate, (const double *)out_prev, (double *)out, n_env);
+        else
+            hipLaunchKernelGGL(carry_stale_kernel<float>, grid, block, 0, st, istate, (const float *)out_prev, (float *)out, n_env);
+    }
     const int fresh = zero_stats != 0 ? 1 : 0;       // first launch of the step: overwrite the statistics slots
     switch (p.integrator) {
     case PVDER_INT_ETDLIN:
@@ -1854,11 +2128,42 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
     if (!plan || n_steps < 0 || !actions || !out) return PVDER_EINVAL;
     const size_t esz = plan->integrator == PVDER_INT_RK45 ? sizeof(double) : sizeof(float);
     for (int k = 0; k < n_steps; ++k) {
-        const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env,
-                                   (char *)out + (size_t)k * out_step_stride * esz, hstep, stats, 1, stream);
+        char *blk = (char *)out + (size_t)k * out_step_stride * esz;
+        const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env, blk, hstep, stats, 1,
+                                   stream, k > 0 ? blk - out_step_stride * esz : nullptr);
         if (rc) return rc;
     }
     return 0;
+}
+
+// Open-loop rollout with the env steps FUSED into one launch (etdlin, three-phase): same results as
+// pvder_plan_rollout, bit for bit.  Four launches whatever n_steps: the fused kernel (state in registers
+// from step to step) until a workgroup meets a step it does not carry -- the one that ends an episode,
+// an env off balance / near a limit --, the finish kernel takes those workgroups through that ONE step
+// (per-step body, through memory), the fused kernel resumes, the finish kernel takes whatever is left.
+int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                             const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
+                             int32_t *progress, void *stream) {
+    if (!plan || n_steps < 0 || !actions || !out || !progress || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
+    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3) return PVDER_EINVAL;
+    if (n_steps == 0) return 0;
+    const int n_env = plan->n_env;
+    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    RollArgs Q;
+    Q.G = plan->lin;
+    EtdArgs &A = Q.G.A;
+    RollK &Rk = Q.Rk;
+    A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
+    A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
+    Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
+    Rk.resume = 0; Rk.max_finish = 1;
+    hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
+    hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    Rk.resume = 1; Rk.max_finish = n_steps;
+    hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
+    hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    return hip_rc(hipGetLastError());
 }
 
 // ---- the per-step collective of the sharded env, enqueued from C ------------------------------------
@@ -1932,7 +2237,7 @@ int pvder_plan_rollout_gather(const pvder_plan *plan, pvder_gather *g, void *fst
         if (g->pending[b]) e = hipStreamWaitEvent(st, g->done[b], 0);        // gather t-2 has read this block
         if (e != hipSuccess) return hip_rc(e);
         const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env, outs[b],
-                                   nullptr, stats, 1, stream);
+                                   nullptr, stats, 1, stream, outs[b ^ 1]);
         if (rc) return rc;
         e = hipEventRecord(g->ready[b], st);
         if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->ready[b], 0);

@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -28,7 +28,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients", "pvder_lin_set_floats", "pvder_lin_max_sets",
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
-           "pvder_plan_rollout_gather"]
+           "pvder_plan_rollout_gather", "pvder_plan_rollout_fused"]
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
 LIN_MAX_SETS = 8
@@ -143,6 +143,8 @@ def lib() -> C.CDLL:
     L.pvder_plan_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pvder_plan_rollout.restype = i32
     L.pvder_plan_rollout.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.pvder_plan_rollout_fused.restype = i32
+    L.pvder_plan_rollout_fused.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.pvder_gather_create.restype = i32
     L.pvder_gather_create.argtypes = [C.POINTER(vp), vp, vp]
     L.pvder_gather_destroy.restype = None

@@ -294,11 +294,14 @@ class PVDERVec(EnvSpecMixin):
         """Point the env at another [13, N] output block (same dtype/device): the next launches write
         their observation / reward / done rows there.  For callers that hand the block of step t to a
         consumer (e.g. an all-gather in flight) while step t+1 computes.  Rows of envs that do not run
-        (finished, auto_reset off) are not rewritten, so alternate blocks only with auto_reset on."""
+        (finished, auto_reset off: the stale tuple, PVDER_env.py:145-152) are not rewritten by a launch, so
+        without auto_reset the current block is copied into the new one first."""
         if buf.shape != self.out.shape or buf.dtype != self.out.dtype or buf.device != self.out.device \
                 or not buf.is_contiguous():
             raise ValueError("use_out: need a contiguous %s tensor of shape %s on %s"
                              % (self.out.dtype, tuple(self.out.shape), self.out.device))
+        if not self.auto_reset and buf.data_ptr() != self.out.data_ptr():
+            buf.copy_(self.out)
         self.out = buf
 
     # -- events ---------------------------------------------------------------------------------
@@ -545,12 +548,15 @@ class PVDERVec(EnvSpecMixin):
                 return None
             return self.obs, self.out[11], self.out[12] != 0, {}
 
-    def rollout(self, actions: torch.Tensor, out: Optional[torch.Tensor] = None):
+    def rollout(self, actions: torch.Tensor, out: Optional[torch.Tensor] = None, fused: Optional[bool] = None):
         """``K`` transitions from ONE host call: ``actions`` is a [K, N] uint8 device tensor (row k =
         the actions of step k -- an open-loop action sequence: recorded actions, fixed policies of
         ``calc_returns``, the synthetic random-action rollouts of bench.py).  The same fused launch as
         ``step``, enqueued K times by the C side (pvder_plan_rollout): per-step results land in
-        ``out[k]`` ([K, 13, N]) when given, otherwise every step overwrites ``self.out``."""
+        ``out[k]`` ([K, 13, N]) when given, otherwise every step overwrites ``self.out``.
+        ``fused=True`` (etdlin, three-phase model): the K env steps run inside ONE launch with the state
+        in registers from step to step (pvder_plan_rollout_fused) -- the same results bit for bit;
+        ``None`` picks it when it applies and K >= 4."""
         if self._needs_reset:
             raise RuntimeError("call reset() before rollout()")
         if actions.dim() != 2 or actions.shape[1] != self.num_envs:
@@ -571,15 +577,34 @@ class PVDERVec(EnvSpecMixin):
                 if out is not None:
                     out[k].copy_(self.out)
             return
+        can_fuse = self.integrator == "etdlin" and self.ns == 23 and not self._timing
+        if fused and not can_fuse:
+            raise ValueError("fused rollouts: integrator='etdlin', three-phase model, no per-launch timing")
+        if fused is None:
+            fused = can_fuse and K >= 4
         plan = self._plan or self._make_plan()
         with self._device_ctx():
-            rc = self._lib.pvder_plan_rollout(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self.ev_vg.data_ptr(),
-                                              self.ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
-                                              self.hstep.data_ptr() if self.hstep is not None else None,
-                                              self.stats.data_ptr(), self._stream())
-            _native.check(rc, "pvder_plan_rollout")
+            if out is not None and K > 0 and not self.auto_reset:
+                out[0].copy_(self.out)               # stale tuples of finished envs: block k takes them from block k-1
+            if fused:
+                if self._progress is None:
+                    self._progress = torch.zeros((self.num_envs + self._lib.pvder_block_size() - 1)
+                                                 // self._lib.pvder_block_size(), dtype=torch.int32, device=self.device)
+                rc = self._lib.pvder_plan_rollout_fused(plan, self.fstate.data_ptr(), self.istate.data_ptr(),
+                                                        self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), K,
+                                                        dst.data_ptr(), stride, self.stats.data_ptr(),
+                                                        self._progress.data_ptr(), self._stream())
+                _native.check(rc, "pvder_plan_rollout_fused")
+            else:
+                rc = self._lib.pvder_plan_rollout(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self.ev_vg.data_ptr(),
+                                                  self.ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
+                                                  self.hstep.data_ptr() if self.hstep is not None else None,
+                                                  self.stats.data_ptr(), self._stream())
+                _native.check(rc, "pvder_plan_rollout")
             if out is not None and K > 0:
                 self.out.copy_(out[K - 1])
+
+    _progress = None                 # scratch of the fused rollouts (one int32 per workgroup)
 
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 6
+#define PVDER_ABI_VERSION 7
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -251,7 +251,9 @@ int pvder_step_etdlin_f32(const double *par, const pvder_step_cfg *cfg, const pv
  * hstep is only read for PVDER_INT_RK45 (fstate/out are then double).
  * pvder_plan_rollout: n_steps transitions from ONE host call -- the same per-step launch, enqueued
  * n_steps times, with action row k = actions + k*n_env and output block k = out + k*out_step_stride
- * elements (0: every step overwrites the same block). */
+ * elements (0: every step overwrites the same block).  A finished env (status != 0 on entry, no
+ * auto-reset) returns the stale tuple: the step kernels leave its rows alone, and block k > 0 receives
+ * them from block k-1; block 0 must hold them on entry (copy the block of the preceding step there). */
 enum pvder_integrator { PVDER_INT_ETDLIN = 0, PVDER_INT_ETDRK4 = 1, PVDER_INT_RK4 = 2, PVDER_INT_RK45 = 3 };
 typedef struct pvder_plan pvder_plan;
 int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, const pvder_step_cfg *cfg,
@@ -262,14 +264,28 @@ int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                        const uint8_t *actions, int n_steps, void *out, size_t out_step_stride, double *hstep,
                        float *stats, void *stream);
+/* pvder_plan_rollout_fused: the same open-loop rollout (calc_returns' fixed policies, PVDER_env.py:458-497;
+ * recorded or synthetic action sequences) with the env steps FUSED into one launch -- PVDER_INT_ETDLIN,
+ * three-phase model only (PVDER_EINVAL otherwise).  The 11-state reduction of a balanced env stays in
+ * registers from the first step to the last: the state rows are read once and written once, and per step
+ * only the 13 output rows are stored.  Results are bit-identical to pvder_plan_rollout: the steps a
+ * workgroup cannot carry in registers (the one that ends an episode -- done / same-step auto-reset --, an
+ * env that is unbalanced, near a limit, not running or non-finite) are taken by the per-step body, through
+ * memory, by a follow-up launch; four launches per call whatever n_steps.
+ *   progress : device scratch, int32[ceil(n_env / pvder_block_size())] (contents need not be initialised).
+ *   stats    : as pvder_plan_step; on return the slots hold the statistics of the LAST step. */
+int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                             const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
+                             int32_t *progress, void *stream);
 
 /* ---- the per-step collective of the sharded env (multi-GPU) -------------------------
  * The reference has no distributed code; the build shards independent envs over ranks and collates
  * the [13, n_env] output block of every step with ONE all-gather (RCCL over xGMI).  These entry points
  * enqueue step kernel + gather from C -- one host call per rollout instead of six Python-level calls
  * per step: the kernel on the caller's stream, the gather on the object's own stream, two output
- * blocks alternating (step k uses out[(first_block + k) & 1] / recv[...]) so that the gather of step t
- * overlaps the kernel of step t+1.  RCCL is not linked: `nccl_all_gather` is the address of
+ * blocks alternating (step k uses out[(first_block + k) & 1] / recv[...]; the stale tuples of finished
+ * envs are carried from one block to the other) so that the gather of step t overlaps the kernel of
+ * step t+1.  RCCL is not linked: `nccl_all_gather` is the address of
  * ncclAllGather in the librccl the caller uses, `comm` its ncclComm_t.  recv blocks are
  * [world * 13, n_env] floats.  pvder_gather_drain makes `stream` wait for the gathers in flight. */
 typedef struct pvder_gather pvder_gather;

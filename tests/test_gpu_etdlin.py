@@ -215,14 +215,84 @@ def test_rollout_equals_single_steps(gpu_device):
         a.step(acts[k], return_tensors=False)
         singles.append(a.out.clone())
     blocks = torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device)
-    b.rollout(acts, out=blocks)
+    b.rollout(acts, out=blocks, fused=False)
     assert torch.equal(blocks, torch.stack(singles))
     assert torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate) and torch.equal(a.out, b.out)
     assert int(b.istate[2].max()) >= 2              # an auto-reset happened inside the rollout
-    b.rollout(acts[:3])                             # without per-step blocks: only the last one remains
+    b.rollout(acts[:3], fused=False)                # without per-step blocks: only the last one remains
     for k in range(3):
         a.step(acts[k], return_tensors=False)
     assert torch.equal(a.out, b.out)
+
+
+def _same_env_state(a, b):
+    return (torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate) and torch.equal(a.out, b.out)
+            and torch.equal(a.ev_vg, b.ev_vg) and torch.equal(a.ev_si, b.ev_si))
+
+
+@pytest.mark.parametrize("N,K,max_sim_time", [(1024, 12, 2.0), (1000, 23, 2.0), (4096, 40, 40.0), (300, 5, 1.0)])
+def test_fused_rollout_equals_single_steps(gpu_device, N, K, max_sim_time):
+    """pvder_plan_rollout_fused (the K env steps inside ONE launch, state in registers from step to step;
+    episode ends / auto-resets handed to the per-step body) == K step() calls, bit for bit: per-step output
+    blocks, final states, counters, event tables, statistics -- with zero, one and several episode ends inside
+    the rollout, a batch that is not a multiple of the workgroup size, and an invalid action."""
+    kw = dict(n_sim_time_steps_per_env_step=15, seed=11, events_spec=both_events_spec(), auto_reset=True,
+              max_sim_time=max_sim_time)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(8)
+    acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    acts[K // 2, 7] = 9                              # invalid action: no-op, counted
+    a = make_vec(N, gpu_device, **kw); a.reset()
+    b = make_vec(N, gpu_device, **kw); b.reset()
+    singles = []
+    for k in range(K):
+        a.step(acts[k], return_tensors=False)
+        singles.append(a.out.clone())
+    blocks = torch.full((K, 13, N), float("nan"), dtype=torch.float32, device=gpu_device)
+    b.rollout(acts, out=blocks, fused=True)
+    assert torch.equal(blocks, torch.stack(singles))
+    assert _same_env_state(a, b)
+    assert a.step_stats() == b.step_stats()
+    # a second rollout continues from where the first one stopped; without per-step blocks only the last remains
+    b.rollout(acts[:min(7, K)], fused=True)
+    for k in range(min(7, K)):
+        a.step(acts[k], return_tensors=False)
+    assert _same_env_state(a, b)
+    assert a.step_stats() == b.step_stats()
+    bad_step = K // 2
+    c = make_vec(N, gpu_device, **kw); c.reset()
+    c.rollout(acts[:bad_step + 1], fused=True)       # the invalid action in the LAST step: it shows in the statistics
+    assert c.step_stats()["n_bad_action"] == 1
+
+
+def test_fused_rollout_with_desynchronised_and_deferred_envs(gpu_device):
+    """Envs off the common schedule (masked reset mid-episode), envs the fast path must defer (unbalanced,
+    near the duty-cycle limit) and finished envs without auto-reset (stale tuple): the fused rollout hands
+    their workgroups to the per-step body and still equals K single steps bit for bit."""
+    N, K = 2048, 10
+    kw = dict(n_sim_time_steps_per_env_step=15, seed=5, events_spec=both_events_spec(), auto_reset=False, max_sim_time=3.0)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(21)
+    acts = torch.randint(0, 5, (3 * K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    envs = [make_vec(N, gpu_device, **kw) for _ in range(2)]
+    for env in envs:
+        env.reset()
+        for k in range(3):
+            env.step(acts[k], return_tensors=False)
+        mask = torch.zeros(N, dtype=torch.uint8, device=gpu_device)
+        mask[256:512:2] = 1                          # every second env of one workgroup restarts: off the event grid
+        env.reset(mask)
+        env.fstate[6:12, 1024:1030] *= 1.01          # phase b of six envs: unbalanced -> 23-state path
+        env.fstate[24, 1536:1540] = 1.1 * 0.93       # Vdc_ref -7 %: |m| at its limit -> deferred for good
+    a, b = envs
+    singles = []
+    for k in range(3, 3 + K):
+        a.step(acts[k], return_tensors=False)
+        singles.append(a.out.clone())
+    blocks = torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device)
+    b.rollout(acts[3:3 + K], out=blocks, fused=True)
+    assert torch.equal(blocks, torch.stack(singles))
+    assert _same_env_state(a, b)
+    assert bool((a.istate[3] != 0).any())            # some envs finished inside the rollout (max_sim_time) and stayed so
+    assert a.step_stats() == b.step_stats()
 
 
 def test_single_phase_etdlin_vs_bridge(gpu_device):
