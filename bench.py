@@ -77,6 +77,9 @@ def parse(argv=None):
                     help="bracket every K-th step kernel with HIP events (clamped so that even a short run gets samples); 0 = none")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
                     help="length of the sustained leg that follows the --steps window (0 = skip)")
+    ap.add_argument("--fused-seconds", type=float, default=0.5,
+                    help="length of the separately labelled fused-rollout leg (0 = skip)")
+    ap.add_argument("--fused-steps", type=int, default=160, help="env steps per fused launch in that leg")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: all-gather issued directly into RCCL (default) or through torch.distributed")
     ap.add_argument("--sync-gather", type=int, default=0,
@@ -400,11 +403,11 @@ def run_rank(args):
                 nxt = stop if every <= 0 else min(stop, i + every - 1 - (env._timing_k % every if env._timing else 0))
                 j0, j1 = i % pool, i % pool + (nxt - i)
                 if nxt > i and j1 <= pool:
-                    env.rollout(actions[j0:j1])
+                    env.rollout(actions[j0:j1], fused=False)       # (the headline: ONE launch per env step)
                     env._timing_k += nxt - i
                     i = nxt
                 elif nxt > i:
-                    env.rollout(actions[j0:pool])
+                    env.rollout(actions[j0:pool], fused=False)
                     env._timing_k += pool - j0
                     i += pool - j0
                     continue
@@ -471,6 +474,37 @@ def run_rank(args):
                      "ms_per_step": 1e3 * el_s / n_sus, "host_enqueue_ms_per_step": 1e3 * host_s / n_sus,
                      "kernel_avg_ms": finite(sum(k_s) / len(k_s)) if k_s else None, "kernel_samples": len(k_s),
                      "region_ms_per_step": region_s}
+    # separately labelled leg: the same workload as open-loop rollouts with the env steps FUSED into one launch
+    # (pvder_plan_rollout_fused: state in registers from step to step, bit-identical results; one call = one
+    # 160-step episode) -- what calc_returns-style evaluation sweeps and recorded-action replays run at
+    fused_leg = None
+    if dist is None and args.integrator == "etdlin" and args.fused_seconds > 0 and env.ns == 23:
+        Kf = max(1, min(args.fused_steps, pool))
+        blocks = torch.empty((Kf, 13, N), dtype=env.out.dtype, device=dev) if Kf * 13 * N * 4 <= (4 << 30) else None
+        env.rollout(actions[:Kf], out=blocks, fused=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        env.rollout(actions[:Kf], out=blocks, fused=True)
+        torch.cuda.synchronize(dev)
+        reps = int(max(2, min(2000, args.fused_seconds / max(time.perf_counter() - t0, 1e-6))))
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r0.record()
+        for r in range(reps):
+            j0 = (r * Kf) % max(1, pool - Kf + 1)
+            env.rollout(actions[j0:j0 + Kf], out=blocks, fused=True)
+        r1.record()
+        torch.cuda.synchronize(dev)
+        el_f = time.perf_counter() - t0
+        per = el_f / (reps * Kf)
+        fused_leg = {"value": N * reps * Kf / el_f, "unit": "env-steps/s", "steps_per_launch": Kf, "launches": reps,
+                     "seconds": el_f, "ms_per_step": 1e3 * per, "region_ms_per_step": r0.elapsed_time(r1) / (reps * Kf),
+                     "per_step_output_blocks": blocks is not None,
+                     "hbm_frac_on_269B_per_env_step": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK,
+                     "kernel": "step_etdlin_rollout_kernel<3> (+ step_etdlin_finish_kernel<3> for the step that ends an episode)",
+                     "note": "same envs, events and random actions as the headline; results bit-identical to one launch per "
+                             "step (tests/test_gpu_etdlin.py::test_fused_rollout_equals_single_steps); NOT the headline"}
     compute_only = None
     if dist is not None:        # the same steps without the collective: what the gather costs
         el_c, host_c, k_c, region_c = timed(total, args.steps, every, gather=False)
@@ -571,6 +605,7 @@ def run_rank(args):
                               "ns_per_instr_per_wave": (avg_kern_s * 1e9 / (steps_per_env_step * INSTR_PER_STEP[args.integrator])
                                                         if args.integrator in INSTR_PER_STEP else None)} if flops else None,
             "sustained": sustained,
+            "fused_rollout": fused_leg,
             "ranks_seen": ranks_seen,
             "last_step_stats": st,
         }

@@ -121,17 +121,38 @@ __device__ __forceinline__ void lin_mfma(const LinSetRegs &A, const int (&mat)[N
                                          v4f (&acc)[NM][3]) {
     lin_mfma_cols<NM, 0>(A, mat, f, acc);
 }
-template <int K>
+// acc += M f for ONE matrix: three row groups give three dependent chains of eleven MFMAs, and a dependent
+// 4x4x1 issues every ~16 clocks where an independent one issues every 8 -- so the columns are summed as two
+// half-chains (0..5 into acc, 6..10 from zero), six chains in flight, joined by three packed adds.
+template <int K, int KEND>
 __device__ __forceinline__ void lin_mfma1_cols(const LinMatRegs &A, const v2 *__restrict__ f, v4f (&acc)[3]) {
-    if constexpr (K < kLinN) {
+    if constexpr (K < KEND) {
         const float fk = (K & 1) ? f[K >> 1].y : f[K >> 1].x;
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g], fk, acc[g], 4, K, 0);
-        lin_mfma1_cols<K + 1>(A, f, acc);
+        lin_mfma1_cols<K + 1, KEND>(A, f, acc);
+    }
+}
+template <int K>
+__device__ __forceinline__ void lin_mfma1_pair(const LinMatRegs &A, const v2 *__restrict__ f, v4f (&lo)[3], v4f (&hi)[3]) {
+    constexpr int H = 6;
+    if constexpr (K < H) {
+        const float fl = (K & 1) ? f[K >> 1].y : f[K >> 1].x;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) lo[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g], fl, lo[g], 4, K, 0);
+        if constexpr (K + H < kLinN) {
+            const float fh = ((K + H) & 1) ? f[(K + H) >> 1].y : f[(K + H) >> 1].x;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) hi[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[g], fh, hi[g], 4, K + H, 0);
+        }
+        lin_mfma1_pair<K + 1>(A, f, lo, hi);
     }
 }
 __device__ __forceinline__ void lin_mfma1(const LinMatRegs &A, const v2 *__restrict__ f, v4f (&acc)[3]) {
-    lin_mfma1_cols<0>(A, f, acc);
+    v4f hi[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    lin_mfma1_pair<0>(A, f, acc, hi);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] += hi[g];
 }
 // state in accumulator layout (rows 0-3, 4-7, 8-11) -> the six pairs bal_f reads
 __device__ __forceinline__ void lin_pairs(const v4f (&Y)[3], v2 *__restrict__ y) {

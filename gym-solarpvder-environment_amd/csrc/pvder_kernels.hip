@@ -52,6 +52,19 @@ __device__ unsigned long long g_trace[4096 * 32];
 #define PVDER_TRACE_DEP(slot, val) do { } while (0)
 #endif
 
+// A/B switches of the kernarg laundering (tools/ab_variant.sh): -DPVDER_NO_LAUNDER_EPI / _ROLL let hipcc
+// keep the kernel arguments live instead of re-reading them
+#ifdef PVDER_NO_LAUNDER_EPI
+#define PVDER_LAUNDER_EPI(p) do { } while (0)
+#else
+#define PVDER_LAUNDER_EPI(p) asm volatile("" : "+s"(p))
+#endif
+#ifdef PVDER_NO_LAUNDER_ROLL
+#define PVDER_LAUNDER_ROLL(p) do { } while (0)
+#else
+#define PVDER_LAUNDER_ROLL(p) asm volatile("" : "+s"(p))
+#endif
+
 using pvder::ModelK;
 using pvder::SubK;
 using pvder::v2;
@@ -1163,6 +1176,52 @@ __device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys)
     ys[B] = Y[1].z; ys[B + 1] = Y[1].w; ys[B + 2] = Y[2].x; ys[B + 3] = Y[2].y; ys[B + 4] = Y[2].z;
 }
 
+// One ETD3RK step of every lane from Y with the coefficient set in Ac: Yn = y+, returns whether the lane
+// must be handed to the 23-state path (|m| / |iref| guards at the start, the middle -- stage a --, the end
+// of the step; embedded error indicator)
+template <int PH>
+__device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
+                                           const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float i2m,
+                                           pvder::v4f (&Yn)[3], bool traced) {
+    using namespace pvder;
+    const ModelK<float> &P = G.A.P;
+    const EtdK &Ec = G.A.Ec;
+    const PkConst K = make_pkconst(P);
+    v2 yp[6], F[6];
+    float m2a, ir2a, m2x, ir2x, m2b;
+    lin_pairs(Y, yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
+    if (traced) PVDER_TRACE_DEP(24, F[0].x + F[2].y + F[3].x + F[5].x);
+    v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
+    {
+        const int m3[3] = {LM21, LM31, LM41};
+        lin_mfma<3>(Ac, m3, F, acc3);                     // a = y + M21 F1; b, y+ started
+    }
+    if (traced) PVDER_TRACE_DEP(25, acc3[0][0].x + acc3[1][1].x + acc3[2][2].x);
+    lin_pairs(acc3[0], yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2x, ir2x);
+    if (traced) PVDER_TRACE_DEP(26, F[0].x + F[2].y + F[3].x + F[5].x);
+    v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
+    {
+        const int m2[2] = {LM32, LM42};
+        lin_mfma<2>(Ac, m2, F, acc2);                     // b complete
+    }
+    if (traced) PVDER_TRACE_DEP(27, acc2[0][0].x + acc2[1][1].x);
+    lin_pairs(acc2[0], yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2b, ir2x);
+    if (traced) PVDER_TRACE_DEP(28, F[0].x + F[2].y + F[3].x + F[5].x);
+    Yn[0] = acc2[1][0]; Yn[1] = acc2[1][1]; Yn[2] = acc2[1][2];
+    lin_mfma1(Ac[LM43], F, Yn);                           // y+
+    if (traced) PVDER_TRACE_DEP(29, Yn[0].x + Yn[2].x);
+    // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
+    const float est = fmaxf(fmaxf(fabsf(Yn[0].x - acc2[0][0].x), fabsf(Yn[0].y - acc2[0][0].y)),
+                            fabsf(Yn[1].z - acc2[0][1].z));
+    const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
+    // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
+    const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+    return fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
+}
+
 // One env step of the lanes with `run` set, state Y in registers: per-lane schedule, wave-uniform trip
 // count.  Returns the lanes that must be handed to the 23-state path (their Y is then meaningless).
 template <int PH>
@@ -1186,6 +1245,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
     bool start = true;                   // this lane is at the start of a segment (its tick is due)
     bool done = !run;
     SubPk S;
+    cur = __builtin_amdgcn_readfirstlane(cur);           // (wave-uniform by construction: tell hipcc)
     for (int it = 0;; ++it) {
         if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
         if (trace_step == 0 && it < 16) PVDER_TRACE_AT(3 + it);
@@ -1215,55 +1275,35 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
         // ---- the segment's next ETD3RK step (schedule row: one set index per byte, 0 = segment finished)
         const int sidx = (int)(sg.sch & 0xffull);
         bool todo = !done && sidx != 0;
-        // One pass per DISTINCT set among the wave's lanes: a single pass while the envs run in lockstep
-        for (;;) {
-            const unsigned long long tm = __ballot((int)todo);
-            if (tm == 0) break;
-            const int s_now = __builtin_amdgcn_readlane(sidx, (int)__builtin_ctzll(tm));
-            if (s_now != cur) {
-                lin_load_set(G.Lk.lcoef + kLinMatFloats + (size_t)(s_now - 1) * kLinSetFloats, lane, Ac);
-                cur = s_now;
-            }
-            float m2x, ir2x, m2b;
-            lin_pairs(Y, yp);
-            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
-            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(24, F[0].x + F[2].y + F[3].x + F[5].x);
-            v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
-            {
-                const int m3[3] = {LM21, LM31, LM41};
-                lin_mfma<3>(Ac, m3, F, acc3);                     // a = y + M21 F1; b, y+ started
-            }
-            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(25, acc3[0][0].x + acc3[1][1].x + acc3[2][2].x);
-            lin_pairs(acc3[0], yp);
-            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2x, ir2x);
-            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(26, F[0].x + F[2].y + F[3].x + F[5].x);
-            v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
-            {
-                const int m2[2] = {LM32, LM42};
-                lin_mfma<2>(Ac, m2, F, acc2);                     // b complete
-            }
-            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(27, acc2[0][0].x + acc2[1][1].x);
-            lin_pairs(acc2[0], yp);
-            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2b, ir2x);
-            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(28, F[0].x + F[2].y + F[3].x + F[5].x);
-            v4f acc1[1][3] = {{acc2[1][0], acc2[1][1], acc2[1][2]}};
-            {
-                const int m1[1] = {LM43};
-                lin_mfma<1>(Ac, m1, F, acc1);                     // y+
-            }
-            if (trace_step == 0 && it == 1) PVDER_TRACE_DEP(29, acc1[0][0].x + acc1[0][2].x);
-            // embedded indicator: 3rd-order y+ against the 2nd-order stage value b
-            const float est = fmaxf(fmaxf(fabsf(acc1[0][0].x - acc2[0][0].x), fabsf(acc1[0][0].y - acc2[0][0].y)),
-                                    fabsf(acc1[0][1].z - acc2[0][1].z));
-            const v2 mn = fma2(bc2(P.KpG), mk2(acc1[0][1].x, acc1[0][1].y), mk2(acc1[0][0].z, acc1[0][0].w));
-            // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
-            const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
-            const bool trip = fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
-            if (todo && sidx == s_now) {
+        // One pass per DISTINCT set among the wave's lanes.  Lockstep (every lane that has a step to take
+        // names the resident set -- always, while the envs of the wave share their schedule): ONE pass with
+        // the registers as they are; the general loop reloads sets and is entered only by a wave whose envs
+        // have drifted apart.  Same arithmetic either way: a lane's result does not depend on its neighbours.
+        if (__builtin_amdgcn_readfirstlane(__any((int)(todo && sidx != cur))) == 0) {
+            v4f Yn[3];
+            const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, i2m, Yn, trace_step == 0 && it == 1);
+            if (todo) {
                 defer |= trip;
-                Y[0] = acc1[0][0]; Y[1] = acc1[0][1]; Y[2] = acc1[0][2];
+                Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
                 sg.sch >>= 8;
-                todo = false;
+            }
+        } else {
+            for (;;) {
+                const unsigned long long tm = __ballot((int)todo);
+                if (tm == 0) break;
+                const int s_now = __builtin_amdgcn_readlane(sidx, (int)__builtin_ctzll(tm));
+                if (s_now != cur) {
+                    lin_load_set(G.Lk.lcoef + kLinMatFloats + (size_t)(s_now - 1) * kLinSetFloats, lane, Ac);
+                    cur = s_now;
+                }
+                v4f Yn[3];
+                const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, i2m, Yn, false);
+                if (todo && sidx == s_now) {
+                    defer |= trip;
+                    Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
+                    sg.sch >>= 8;
+                    todo = false;
+                }
             }
         }
         // ---- segment finished?  Then the next one (if any) starts at an event row change
@@ -1326,7 +1366,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     }
     PVDER_TRACE_AT(20);
     KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
+    PVDER_LAUNDER_EPI(ka);
     const EtdArgs &E = *(const EtdArgs *)ka;
     if (defer) {
         if constexpr (PH == 1) E.istate[PVDER_I_STATUS * (size_t)E.n_env + L.e] = kDeferred;   // marker for the follow-up launch
@@ -1387,7 +1427,7 @@ typedef __attribute__((address_space(4))) const RollArgs *RollKernargPtr;
 // into VGPRs, packed constants -- live across the step loop, where every register is taken
 __device__ __forceinline__ const RollArgs &roll_args() {
     RollKernargPtr ka = (RollKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
+    PVDER_LAUNDER_ROLL(ka);
     return *(const RollArgs *)ka;
 }
 
@@ -1395,6 +1435,7 @@ template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollArgs Q) {
     using namespace pvder;
     constexpr int NS = 6 * PH + 5;
+    if (Q.Rk.resume && Q.Rk.progress[blockIdx.x] >= Q.Rk.n_steps) return;      // (workgroup-uniform) nothing left
     const int lane = threadIdx.x & 63;
     LinMatRegs At;
     LinSetRegs Ac;
@@ -1426,13 +1467,32 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
     float last_reward = 0.f, bad = 0.f;
     const int k_first = Q.Rk.resume ? Q.Rk.progress[blockIdx.x] : 0;
     int k = k_first;
-    if (!__syncthreads_or((int)bail)) {
+    if (!__syncthreads_or((int)bail) && k < Q.Rk.n_steps) {
+        // what a step reads from memory -- its action, the event inputs and the schedule row of its first
+        // segment -- is requested ONE STEP AHEAD (the addresses only depend on the step counter): a lone wave
+        // per SIMD would otherwise sit out two memory round trips per env step
+        int a_now;
+        LinSeg sg;
+        {
+            const EtdArgs &A = Q.G.A;
+            const size_t N = (size_t)A.n_env;
+            const int ec = e < A.n_env ? e : A.n_env - 1;
+            a_now = ld(&Q.Rk.actions[(size_t)k * N + ec]);
+            sg = lin_first_segment(A.C, Q.G.Lk, ksub, A.ev_vg, A.ev_si, N, ec);
+        }
         for (;; ++k) {
             const RollArgs &Q1 = roll_args();
             if (k >= Q1.Rk.n_steps) break;
             const EtdArgs &A = Q1.G.A;
             const size_t N = (size_t)A.n_env;
             const int ec = e < A.n_env ? e : A.n_env - 1;
+            const bool traced = k == k_first + 3;       // (trace builds: timeline of the fourth step)
+            if (traced) PVDER_TRACE_AT(0);
+            const int k_next = k + 1 < Q1.Rk.n_steps ? k + 1 : k;
+            const int a_next = ld(&Q1.Rk.actions[(size_t)k_next * N + ec]);
+            // (the row in force at the end of this step is the one the next step starts with: its inputs
+            // also serve the observation at tStop)
+            const LinSeg sg_next = lin_first_segment(A.C, Q1.G.Lk, ksub + A.C.n_sub, A.ev_vg, A.ev_si, N, ec);
             park[0][threadIdx.x] = Y[0].x; park[1][threadIdx.x] = Y[0].y; park[2][threadIdx.x] = Y[0].z;
             park[3][threadIdx.x] = Y[0].w; park[4][threadIdx.x] = Y[1].x; park[5][threadIdx.x] = Y[1].y;
             park[6][threadIdx.x] = Y[1].z; park[7][threadIdx.x] = Y[1].w; park[8][threadIdx.x] = Y[2].x;
@@ -1441,17 +1501,17 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
             // the step that would END the episode is not taken here (done / auto-reset live in the per-step body)
             bool leave = ksub + A.C.n_sub >= A.C.max_ksub || (A.C.max_steps > 0 && steps + 1 >= A.C.max_steps);
             // action_calc (PVDER_env.py:198-229)
-            const int a = ld(&Q1.Rk.actions[(size_t)k * N + ec]);
+            if (traced) PVDER_TRACE_AT(1);
+            const int a = a_now;
             bad = 0.f;
             if (a == 1) qref += A.C.dq;
             else if (a == 2) qref -= A.C.dq;
             else if (a == 3) vdcref += A.C.dv;
             else if (a == 4) vdcref -= A.C.dv;
             else if (a != 0) bad = 1.f;
-            if (!__builtin_amdgcn_readfirstlane(__any((int)leave))) {
-                const LinSeg sg = lin_first_segment(A.C, Q1.G.Lk, ksub, A.ev_vg, A.ev_si, N, ec);
-                leave = lin_integrate<PH>(Q1.G, lane, At, Ac, cur, Y, qref, vdcref, ec, sg, true, false, k);
-            }
+            if (!__builtin_amdgcn_readfirstlane(__any((int)leave)))
+                leave = lin_integrate<PH>(Q1.G, lane, At, Ac, cur, Y, qref, vdcref, ec, sg, true, false, traced ? 0 : 1);
+            if (traced) PVDER_TRACE_DEP(20, Y[0].x + Y[2].z);
             float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
                         fabsf(Y[1].z) + fabsf(Y[1].w) + fabsf(Y[2].x) + fabsf(Y[2].y) + fabsf(Y[2].z);
             leave |= !(chk < 1e30f);
@@ -1463,6 +1523,7 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
                 break;
             }
             // observation and reward at (y(tStop), tStop), exactly as the per-step epilogue computes them
+            if (traced) PVDER_TRACE_AT(2);
             const RollArgs &Q2 = roll_args();
             const EtdArgs &B = Q2.G.A;
             ksub += B.C.n_sub;
@@ -1470,13 +1531,11 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
             float ys[NS];
             lin_to_rows<PH>(Y, ys);
             SubK<float, PH> S;
-            {
-                const int row = event_row(ksub, B.C.ev_s0, B.C.ev_ds, B.C.ev_count);
-                make_sub<float, PH>(B.P, B.ev_vg[(size_t)row * N + ec], B.ev_si[(size_t)row * N + ec], S);
-            }
+            make_sub<float, PH>(B.P, sg_next.in_vg, sg_next.in_si, S);
             float iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
             outputs<float, PH>(B.P, S, ys, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
             last_reward = reward_of<float>(B.C, B.P, vrms, Ppcc, Qpcc, ys[6 * PH], vdcref);
+            if (traced) PVDER_TRACE_DEP(22, last_reward + ppv);
             if (e < B.n_env) {
                 float *o = B.out + k * Q2.Rk.out_stride;
                 write_obs<float>(o, N, e, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ys[6 * PH], ppv, vdcref, qref,
@@ -1484,6 +1543,9 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
                 st(&o[PVDER_O_REWARD * N + e], last_reward);
                 st(&o[PVDER_O_DONE * N + e], 0.f);
             }
+            if (traced) PVDER_TRACE_AT(21);
+            a_now = a_next;
+            sg = sg_next;
         }
     }
     // state -> memory (as of the last completed step), statistics of the last step if it was completed here
@@ -1909,6 +1971,7 @@ __global__ __launch_bounds__(kBlock) void carry_stale_kernel(const int32_t *__re
 
 struct pvder_plan {
     int integrator, ph, n_env;
+    int episode_steps;               // env steps of an episode (max_sim_time, TimeLimit): bounds the episode ends inside a rollout
     LinArgs lin;                     // etdlin; lin.A alone is the ETDRK4 argument block
     ModelK<float> Pf;                // classic RK4 / single-phase follow-up
     StepK<float> Cf, C4;
@@ -1927,6 +1990,8 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     p.integrator = integrator;
     p.ph = (int)par[PVDER_PAR_PHASES];
     p.n_env = n_env;
+    p.episode_steps = (cfg->max_ksub + cfg->n_sub - 1) / cfg->n_sub;
+    if (cfg->max_steps > 0 && cfg->max_steps < p.episode_steps) p.episode_steps = cfg->max_steps;
     rc = fold_reset(par, cfg, ar, p.R);
     if (rc) return rc;
     if (integrator == PVDER_INT_RK45) {
@@ -2137,10 +2202,11 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
 }
 
 // Open-loop rollout with the env steps FUSED into one launch (etdlin, three-phase): same results as
-// pvder_plan_rollout, bit for bit.  Four launches whatever n_steps: the fused kernel (state in registers
-// from step to step) until a workgroup meets a step it does not carry -- the one that ends an episode,
-// an env off balance / near a limit --, the finish kernel takes those workgroups through that ONE step
-// (per-step body, through memory), the fused kernel resumes, the finish kernel takes whatever is left.
+// pvder_plan_rollout, bit for bit.  The fused kernel (state in registers from step to step) runs until a
+// workgroup meets a step it does not carry -- the one that ends an episode, an env off balance / near a
+// limit --, the finish kernel takes those workgroups through that ONE step (per-step body, through
+// memory), the fused kernel resumes; one such pair per episode end the rollout can contain, and a last
+// finish pass for whatever is left.
 int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                              const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
                              int32_t *progress, void *stream) {
@@ -2157,12 +2223,16 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
     A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
     Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
-    Rk.resume = 0; Rk.max_finish = 1;
-    hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
-    hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
-    Rk.resume = 1; Rk.max_finish = n_steps;
-    hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
-    hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    // (fused kernel, finish kernel for ONE step) once per episode end a workgroup can meet inside the rollout,
+    // then the finish kernel for whatever is left (workgroups with deferred / finished envs)
+    const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
+    const int pairs = n_steps / ep + 2;
+    for (int r = 0; r < pairs; ++r) {
+        Rk.resume = r > 0 ? 1 : 0;
+        Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
+        hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
+        hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    }
     return hip_rc(hipGetLastError());
 }
 

@@ -271,7 +271,7 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
  * only the 13 output rows are stored.  Results are bit-identical to pvder_plan_rollout: the steps a
  * workgroup cannot carry in registers (the one that ends an episode -- done / same-step auto-reset --, an
  * env that is unbalanced, near a limit, not running or non-finite) are taken by the per-step body, through
- * memory, by a follow-up launch; four launches per call whatever n_steps.
+ * memory, by a follow-up launch; 2 * (n_steps / episode length + 2) launches per call.
  *   progress : device scratch, int32[ceil(n_env / pvder_block_size())] (contents need not be initialised).
  *   stats    : as pvder_plan_step; on return the slots hold the statistics of the LAST step. */
 int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,

@@ -16,6 +16,7 @@ if guard is not None:
 env.reset()
 gen = torch.Generator(device=dev); gen.manual_seed(1)
 acts = torch.randint(0, 5, (steps, 65536), generator=gen, device=dev, dtype=torch.uint8)
-env.rollout(acts[:100]); torch.cuda.synchronize()
-t0 = time.perf_counter(); env.rollout(acts); th = time.perf_counter() - t0; torch.cuda.synchronize(); t1 = time.perf_counter() - t0
-print("guard %s: host %.2f us/step, total %.2f us/step" % (guard, th / steps * 1e6, t1 / steps * 1e6))
+for fused in (False, True, False, True):
+    env.rollout(acts[:100], fused=fused); torch.cuda.synchronize()
+    t0 = time.perf_counter(); env.rollout(acts, fused=fused); th = time.perf_counter() - t0; torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+    print("guard %s fused %d: host %.2f us/step, total %.2f us/step" % (guard, fused, th / steps * 1e6, t1 / steps * 1e6))

@@ -75,6 +75,20 @@ def main():
             t = buf.reshape(4096, 32)[:nblk].astype(np.int64)
             rows.append((t - t[:, 0].min()) * 0.01)
             evs.append(float("nan"))
+    if os.environ.get("PVDER_TRACE_ROLLOUT"):
+        # fused rollout (pvder_plan_rollout_fused): timeline of the FOURTH step of the launch
+        # slot 0 loop top | 1 next step's loads issued, state parked | 3.. integrator iterations |
+        # 20 integration done | 2 workgroup agreed to go on | 22 outputs + reward | 21 output rows stored
+        K = int(os.environ["PVDER_TRACE_ROLLOUT"])
+        rows, evs = [], []
+        for rep in range(10):
+            env.rollout(acts[40:40 + K], fused=True)
+            torch.cuda.synchronize()
+            rc = L.pvder_debug_trace(buf.ctypes.data, buf.size)
+            assert rc == 0, rc
+            t = buf.reshape(4096, 32)[:nblk].astype(np.int64)
+            rows.append((t - t[:, 0:1]) * 0.01)       # per workgroup, relative to ITS loop top
+            evs.append(float("nan"))
     R = np.stack(rows)                     # [launch, block, slot]
     print("N=%d blocks=%d   event-timed step (both launches) median %.1f us" % (N, nblk, float(np.median(evs))))
     names = {0: "entry", 1: "lds staged", 2: "state loaded", 20: "integration done", 22: "outputs+reward done", 23: "stores issued", 21: "epilogue issued"}
