@@ -77,6 +77,9 @@ def parse(argv=None):
                     help="bracket every K-th step kernel with HIP events (clamped so that even a short run gets samples); 0 = none")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
                     help="length of the sustained leg that follows the --steps window (0 = skip)")
+    ap.add_argument("--preroll-steps", type=int, default=20000,
+                    help="untimed steps BEFORE the --warmup steps (0.2 s of GPU work: clocks, TLBs and code paths at their "
+                         "steady state when the warm-up starts; a 5-step warm-up alone leaves a 20-step window ramping)")
     ap.add_argument("--fused-seconds", type=float, default=0.5,
                     help="length of the separately labelled fused-rollout leg (0 = skip)")
     ap.add_argument("--fused-steps", type=int, default=160, help="env steps per fused launch in that leg")
@@ -442,6 +445,18 @@ def run_rank(args):
         env.kernel_timing(False)
         return el, host, k, r0.elapsed_time(r1) / count
 
+    # pre-roll (reported as config.preroll_steps): more untimed steps of the same workload ahead of the warm-up
+    preroll = max(0, args.preroll_steps) if args.integrator in ("etdlin", "etdrk4") else 0
+    if preroll and dist is None:
+        done_pre = 0
+        while done_pre < preroll:
+            n = min(preroll - done_pre, pool)
+            env.rollout(actions[:n], fused=False)
+            done_pre += n
+    elif preroll:
+        for i in range(min(preroll, 2000)):
+            one_step(i)
+        preroll = min(preroll, 2000)
     for i in range(args.warmup):
         one_step(i)
     drain()
@@ -558,6 +573,13 @@ def run_rank(args):
                 if env.micro_coarse > 0 else args.micro * args.n_sub
         else:
             steps_per_env_step = args.micro * args.n_sub
+        if args.integrator == "rk45" and avg_kern_s and env.hstep is not None:
+            # adaptive: integrator steps per env step estimated from the per-env step sizes the controller settled
+            # on (stability-limited, nearly constant): 7 stages x (right-hand side ~300 flop + 23-state stage sums)
+            h = env.hstep[env.hstep > 0]
+            if h.numel():
+                steps_per_env_step = float((args.n_sub / 60.0) / float(h.double().mean().item()))
+                fps = 7 * 300 + 23 * 60
         flops = fps * steps_per_env_step * N / avg_kern_s if (fps and avg_kern_s) else None
         if flops and args.integrator == "etdlin":
             flops += FLOP_PER_TICK * segs * N / avg_kern_s
@@ -581,7 +603,7 @@ def run_rank(args):
                                                                  + ", every other one: %d step(s)") % (args.micro, env.micro_coarse or args.micro),
                                                       "rk4": "fp32 fixed-step classic RK4, %d micro-steps per 1/60 s" % args.micro,
                                                       "rk45": "fp64 adaptive RK45"}[args.integrator]),
-                       "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro,
+                       "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro, "preroll_steps": preroll,
                        "micro_coarse": env.micro_coarse, "graded": bool(env.graded),
                        "integrator": args.integrator,
                        "collective": ("all-gather of the [13, N_local] fp32 block per step: %s; %s"

@@ -1246,6 +1246,43 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
     bool done = !run;
     SubPk S;
     cur = __builtin_amdgcn_readfirstlane(cur);           // (wave-uniform by construction: tell hipcc)
+    // ---- the standard env step, straight-line: every lane that runs has ONE segment (no event row change
+    // inside the env step) covered by the tick and two steps of the resident set -- PVDER-v0 with its envs
+    // in step.  Same arithmetic, same commits as the general loop below, without its bookkeeping (at one
+    // wave per SIMD every instruction is 2-3 ns: the loop's ballots, schedule bytes and segment counters were
+    // a quarter of an env step's integration time).
+    {
+        const bool standard = sg.seg >= C.n_sub && (sg.sch & 0xffffffull) == (unsigned long long)(cur | (cur << 8));
+        if (__builtin_amdgcn_readfirstlane(__any((int)(run && !defer && !standard))) == 0) {
+            if (!__builtin_amdgcn_readfirstlane(__any((int)(run && !defer)))) return defer;
+            if (trace_step == 0) PVDER_TRACE_AT(3);
+            v2 yp[6], F[6];
+            float m2a, ir2a;
+            make_sub_pk(P, sg.in_vg, sg.in_si, S);
+            lin_pairs(Y, yp);
+            bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
+            v4f acc[3] = {Y[0], Y[1], Y[2]};
+            lin_mfma1(At, F, acc);
+            const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
+            const float guard = sg.evjump ? Ec.sat2_event : Ec.sat2_smooth;
+            bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+            if (run) {
+                defer |= trip;
+                Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (trace_step == 0 && st == 1) PVDER_TRACE_AT(4);
+                v4f Yn[3];
+                trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, i2m, Yn, trace_step == 0 && st == 1);
+                if (run) {
+                    defer |= trip;
+                    Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
+                }
+            }
+            return defer;
+        }
+    }
     for (int it = 0;; ++it) {
         if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
         if (trace_step == 0 && it < 16) PVDER_TRACE_AT(3 + it);
@@ -1463,7 +1500,6 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
         if constexpr (PH == 3) bail |= lin_unbalanced(ys);
         lin_from_rows<PH>(ys, Y);
     }
-    __shared__ float park[13][kBlock];          // the state at the start of the current step, should the workgroup leave
     float last_reward = 0.f, bad = 0.f;
     const int k_first = Q.Rk.resume ? Q.Rk.progress[blockIdx.x] : 0;
     int k = k_first;
@@ -1493,11 +1529,9 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
             // (the row in force at the end of this step is the one the next step starts with: its inputs
             // also serve the observation at tStop)
             const LinSeg sg_next = lin_first_segment(A.C, Q1.G.Lk, ksub + A.C.n_sub, A.ev_vg, A.ev_si, N, ec);
-            park[0][threadIdx.x] = Y[0].x; park[1][threadIdx.x] = Y[0].y; park[2][threadIdx.x] = Y[0].z;
-            park[3][threadIdx.x] = Y[0].w; park[4][threadIdx.x] = Y[1].x; park[5][threadIdx.x] = Y[1].y;
-            park[6][threadIdx.x] = Y[1].z; park[7][threadIdx.x] = Y[1].w; park[8][threadIdx.x] = Y[2].x;
-            park[9][threadIdx.x] = Y[2].y; park[10][threadIdx.x] = Y[2].z;
-            park[11][threadIdx.x] = qref; park[12][threadIdx.x] = vdcref;
+            // the state at the start of the step, should the workgroup leave (13 registers: there are enough)
+            const v4f Y0 = Y[0], Y1 = Y[1], Y2 = Y[2];
+            const float qref0 = qref, vdcref0 = vdcref;
             // the step that would END the episode is not taken here (done / auto-reset live in the per-step body)
             bool leave = ksub + A.C.n_sub >= A.C.max_ksub || (A.C.max_steps > 0 && steps + 1 >= A.C.max_steps);
             // action_calc (PVDER_env.py:198-229)
@@ -1516,10 +1550,8 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
                         fabsf(Y[1].z) + fabsf(Y[1].w) + fabsf(Y[2].x) + fabsf(Y[2].y) + fabsf(Y[2].z);
             leave |= !(chk < 1e30f);
             if (__syncthreads_or((int)leave)) {
-                Y[0] = {park[0][threadIdx.x], park[1][threadIdx.x], park[2][threadIdx.x], park[3][threadIdx.x]};
-                Y[1] = {park[4][threadIdx.x], park[5][threadIdx.x], park[6][threadIdx.x], park[7][threadIdx.x]};
-                Y[2] = {park[8][threadIdx.x], park[9][threadIdx.x], park[10][threadIdx.x], 0.f};
-                qref = park[11][threadIdx.x]; vdcref = park[12][threadIdx.x];
+                Y[0] = Y0; Y[1] = Y1; Y[2] = Y2;
+                qref = qref0; vdcref = vdcref0;
                 break;
             }
             // observation and reward at (y(tStop), tStop), exactly as the per-step epilogue computes them

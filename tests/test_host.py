@@ -232,3 +232,37 @@ def test_etdrk4_coefficient_block_matches_independent_phi_functions():
         assert np.abs(G[4] + 2 * G[8] - h * f[1]).max() < 1e-6 * h                       # a41 + a42 + a43
         assert np.abs(G[5] + 2 * G[9] + G[10] - 0.5 * h * g[1]).max() < 1e-6 * h         # a51 + 2 a52 + a54
         assert np.abs(G[6] + G[11] + G[12] - h * f[1]).max() < 1e-6 * h                  # b1 + b4 + b5
+
+
+def test_plan_and_rollout_argument_validation_without_a_gpu():
+    """pvder_plan_create folds on the host (no device call); the rollout entry points reject bad arguments
+    with PVDER_EINVAL before anything is launched -- fused rollouts exist for etdlin / three-phase only."""
+    import torch  # noqa: F401
+    from gym_PVDER_amd import _native, der_model
+    L = _native.lib()
+    C = ctypes
+    par = der_model.param_vector("50")
+    par_c = (C.c_double * len(par))(*par)
+    y0 = der_model.steady_state(par, "50")
+    y0_c = (C.c_double * len(y0))(*y0)
+    cfg = _native.StepCfg()
+    cfg.n_sub, cfg.micro, cfg.max_ksub, cfg.max_steps = 15, 4096, 2400, 500
+    cfg.ev_s0, cfg.ev_ds, cfg.ev_count = 60, 60, 38
+    cfg.del_qref, cfg.del_vdcref, cfg.inv_max_sim_time = 0.0075, 6e-4, 1.0 / 40.0
+    cfg.p_target, cfg.q_target, cfg.rtol, cfg.atol = 0.9, 0.1, 1e-6, 1e-8
+    ar = _native.AutoReset()
+    ar.enabled, ar.y0 = 1, C.cast(y0_c, C.POINTER(C.c_double))
+    ar.spec.ev_count = 38
+    h = C.c_void_p()
+    rc = L.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS["rk4"], par_c, C.byref(cfg), C.byref(ar), None, None, 1024)
+    assert rc == 0 and h.value
+    one = C.c_void_p(8)               # any non-null value: validation fails before a pointer is touched
+    assert L.pvder_plan_rollout_fused(h, one, one, one, one, one, 4, one, 0, None, one, None) == _native.EINVAL   # not etdlin
+    assert L.pvder_plan_rollout(h, one, one, one, one, None, 4, one, 0, None, None, None) == _native.EINVAL        # no actions
+    assert L.pvder_plan_rollout(h, one, one, one, one, one, -1, one, 0, None, None, None) == _native.EINVAL
+    assert L.pvder_plan_rollout(h, one, one, one, one, one, 0, one, 0, None, None, None) == 0                      # nothing to do
+    L.pvder_plan_destroy(h)
+    assert L.pvder_plan_create(C.byref(h), 9, par_c, C.byref(cfg), C.byref(ar), None, None, 1024) == _native.EINVAL
+    assert L.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS["etdlin"], par_c, C.byref(cfg), C.byref(ar), None, None, 1024) \
+        == _native.EINVAL             # etdlin without coefficient sets
+    assert L.pvder_plan_rollout_fused(None, one, one, one, one, one, 4, one, 0, None, one, None) == _native.EINVAL
