@@ -65,6 +65,8 @@ __device__ unsigned long long g_trace[4096 * 32];
 #define PVDER_LAUNDER_ROLL(p) asm volatile("" : "+s"(p))
 #endif
 
+typedef float v4 __attribute__((ext_vector_type(4)));
+
 using pvder::ModelK;
 using pvder::SubK;
 using pvder::v2;
@@ -334,26 +336,22 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
         st(&out[PVDER_O_DONE * N + e], (T)done_f);
     }
     PVDER_TRACE_AT(23);
-    // ---- statistics: DPP wave reduction, the 4 waves of the workgroup combined through LDS, then ONE
-    // plain store per statistic into THIS workgroup's slot stats[4*blockIdx.x + k] -- no atomics: 256
-    // workgroups finishing together on four same-address float atomics (~10 ns each, serialised at the
-    // memory side) held every launch back by 2.7 us.  stats_fresh: overwrite the slot (first launch
-    // of an env step) or add to it (a follow-up launch / the 23-state tail of the same step).
+    // ---- statistics: DPP wave reduction, then ONE 16-byte store by lane 63 into THIS WAVE's slot
+    // stats[4 * wave + k] -- no atomics (256 workgroups finishing together on four same-address float atomics,
+    // ~10 ns each, serialised at the memory side, held every launch back by 2.7 us), and no LDS / barrier
+    // either (combining the four waves of a workgroup cost a __syncthreads at the very end of the launch:
+    // every wave waited for the slowest of its workgroup).  stats_fresh: overwrite the slot (first launch of
+    // an env step) or add to it (a follow-up launch / the 23-state tail of the same step).
     if (stats) {
-        __shared__ float wsum[4][kBlock / 64];
         const float r = wave_sum_to_lane63(L.run ? (float)reward : 0.f);
         const float d = wave_sum_to_lane63(done_f);
         const float nf = wave_sum_to_lane63(nonfinite);
         const float ba = wave_sum_to_lane63(L.live ? L.bad_action : 0.f);
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 63) { wsum[0][w] = r; wsum[1][w] = d; wsum[2][w] = nf; wsum[3][w] = ba; }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < kBlock / 64; ++k) t += wsum[threadIdx.x][k];
-            float *slot = stats + 4 * (size_t)blockIdx.x + threadIdx.x;
-            *slot = stats_fresh ? t : *slot + t;
+        if ((threadIdx.x & 63) == 63) {
+            v4 *slot = (v4 *)stats + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+            v4 t = {r, d, nf, ba};
+            if (!stats_fresh) t += *slot;
+            *slot = t;
         }
     }
 }
@@ -553,7 +551,6 @@ struct EtdArgs {
     int force_full;          // A/B and tests: every env takes the 23-state path
 };
 
-typedef float v4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4 lds_v4;     // LDS-resident coefficient entries
 
 // one complex matrix entry c = (re, im):  acc += c * z  -- two v_pk_fma_f32: the broadcast of re / im,
@@ -1596,18 +1593,11 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollA
         st(&A.istate[PVDER_I_STEPS * N + e], (int32_t)steps);
     }
     if (k == Q3.Rk.n_steps && k > k_first && A.stats) {
-        __shared__ float wsum[2][kBlock / 64];
         const float r = wave_sum_to_lane63(live ? last_reward : 0.f);
         const float ba = wave_sum_to_lane63(live ? bad : 0.f);
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 63) { wsum[0][w] = r; wsum[1][w] = ba; }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            float t = 0.f;
-            if (threadIdx.x == 0 || threadIdx.x == 3)
-#pragma unroll
-                for (int q = 0; q < kBlock / 64; ++q) t += wsum[threadIdx.x == 0 ? 0 : 1][q];
-            A.stats[4 * (size_t)blockIdx.x + threadIdx.x] = t;         // (#done = #non-finite = 0 in a step taken here)
+        if ((threadIdx.x & 63) == 63) {              // (#done = #non-finite = 0 in a step taken here)
+            v4 *slot = (v4 *)A.stats + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+            *slot = v4{r, 0.f, 0.f, ba};
         }
     }
     if (threadIdx.x == 0) Q3.Rk.progress[blockIdx.x] = k;

@@ -213,7 +213,8 @@ class PVDERVec(EnvSpecMixin):
         self.out = torch.zeros((13, N), dtype=self.fdtype, device=self.device)
         # per-workgroup partial statistics of the last step ([n_wg, 4]; summed on demand by step_stats)
         n_wg = (num_envs + self._lib.pvder_block_size() - 1) // self._lib.pvder_block_size()
-        self.stats = torch.zeros((n_wg, 4), dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros((n_wg * (self._lib.pvder_block_size() // 64), 4), dtype=torch.float32,
+                                 device=self.device)           # one slot per wave (include/pvder_hip.h)
         self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator == "rk45" else None
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 7
+#define PVDER_ABI_VERSION 8
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -160,10 +160,10 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
  *   Envs whose status != 0 on entry are not advanced (stale tuple, :145-152).
  *   ar (may be NULL): when ar->enabled, envs that finish in this step are reset in the same
  *     launch: obs rows = reset observation, reward/done rows = the transition that ended.
- *   stats (device, may be NULL): float[4 * n_wg], n_wg = ceil(n_env / pvder_block_size()): slot
- *     [4*g + k] holds workgroup g's partial of [k=0] sum of rewards, [1] #done, [2] #non-finite,
- *     [3] #invalid actions (wave-level reduction, one plain store per workgroup and statistic, no
- *     atomics); the caller sums the n_wg slots when it wants the totals.  zero_stats != 0: this
+ *   stats (device, may be NULL, 16-byte aligned): float[4 * n_waves], n_waves = ceil(n_env / pvder_block_size())
+ *     * (pvder_block_size() / 64): slot [4*w + k] holds wave w's partial of [k=0] sum of rewards, [1] #done,
+ *     [2] #non-finite, [3] #invalid actions (wave-level DPP reduction, one 16-byte store per wave, no
+ *     atomics, no barrier); the caller sums the slots when it wants the totals.  zero_stats != 0: this
  *     call starts the statistics of an env step (every slot is overwritten); 0: it adds to them.
  *
  * pvder_step_etdrk4_f32: fp32 fixed-step ETDRK4 (explicit exponential Runge-Kutta method of stiff
