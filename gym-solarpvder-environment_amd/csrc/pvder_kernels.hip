@@ -1369,16 +1369,19 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
 // output block of the step (rollouts); the kernel arguments are re-read through laundered copies of
 // the kernarg pointer where keeping them live across the step loop would not fit the scalar
 // register file (hipcc then spills SGPRs and gives the kernel a private segment).
-template <int PH>
+// KOFF: byte offset of G in the kernel-argument segment; fstate / istate / n_env: the copies the caller
+// holds (step_etdlin_kernel: preloaded into SGPRs by the dispatcher, see there).
+template <int PH, int KOFF>
 __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
-                                              int &cur, const uint8_t *__restrict__ act, long long out_off, int stats_fresh) {
+                                              int &cur, const uint8_t *__restrict__ act, long long out_off, int stats_fresh,
+                                              const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env) {
     using namespace pvder;
     const EtdArgs &A = G.A;
     constexpr int NS = 6 * PH + 5;
-    const size_t N = (size_t)A.n_env;
+    const size_t N = (size_t)n_env;
     Lane<float> L;
     float ys[NS];
-    prologue<float, NS>(A.C, A.fstate, A.istate, act, A.n_env, L, ys);
+    prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
     // ksub is the first state word to arrive: the event inputs and the schedule row of the first segment
     // are requested while the other state rows are still in flight
     const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
@@ -1399,7 +1402,8 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         }
     }
     PVDER_TRACE_AT(20);
-    KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef __attribute__((address_space(4))) const char *KernargBytes;
+    KernargPtr ka = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
     PVDER_LAUNDER_EPI(ka);
     const EtdArgs &E = *(const EtdArgs *)ka;
     if (defer) {
@@ -1414,16 +1418,32 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state
         // path right here -- no second launch
         if (__syncthreads_or((int)defer)) {
-            KernargPtr kb = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
             asm volatile("" : "+s"(kb));
             etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
         }
     }
 }
 
+// The leading scalar arguments -- what the first loads of a launch need -- are PRELOADED into SGPRs by the
+// dispatcher (-mllvm -amdgpu-kernarg-preload-count: gfx950 kernel-argument preload; the code object keeps
+// the s_load prologue for firmware without it): the wave does not sit out a scalar-memory round trip
+// (~0.3 us from kernel entry, tools/trace_timeline.py slot 18) before it can issue its first vector load.
+// They repeat G.A.fstate / .istate / .action / G.Lk.lcoef / G.A.n_env; G itself follows at kLinHeadBytes.
+struct LinHead {
+    float *fstate;
+    int32_t *istate;
+    const uint8_t *action;
+    const float *lcoef;
+    int n_env, pad;
+};
+constexpr int kLinHeadBytes = (int)sizeof(LinHead);
+
 template <int PH>
-__global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
+__global__ __launch_bounds__(kBlock) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
+                                                             const float *lcoef, int n_env, int pad, const LinArgs G) {
     using namespace pvder;
+    (void)pad;
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
     // first ETD3RK set stay in registers for the whole launch; another set replaces the latter only when
@@ -1432,10 +1452,12 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(const LinArgs G) {
     const int lane = threadIdx.x & 63;
     LinMatRegs At;
     LinSetRegs Ac;
-    lin_load_mat(G.Lk.lcoef, lane, At);
-    lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
+    PVDER_TRACE_DEP(18, (float)n_env);                  // (trace builds: the leading kernel arguments are there)
+    lin_load_mat(lcoef, lane, At);
+    lin_load_set(lcoef + kLinMatFloats, lane, Ac);
+    PVDER_TRACE_DEP(19, At[0] + Ac[5][2]);               // (... the coefficient registers are loaded)
     int cur = 1;
-    lin_step_body<PH>(G, lane, At, Ac, cur, G.A.action, 0, G.A.stats_fresh);
+    lin_step_body<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, 0, G.A.stats_fresh, fstate, istate, n_env);
 }
 
 // =============================================================================================
@@ -1629,7 +1651,8 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
         lin_load_mat(G.Lk.lcoef, lane, At);
         lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
         int cur = 1;
-        lin_step_body<PH>(G, lane, At, Ac, cur, Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1);
+        lin_step_body<PH, 0>(G, lane, At, Ac, cur, Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1, G.A.fstate,
+                             G.A.istate, G.A.n_env);
         __threadfence();                 // the next step of this workgroup reads what this one wrote
         __syncthreads();
     }
@@ -2076,8 +2099,10 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         // "balanced" kernel IS the model; an env near a limit is redone by classic RK4 micro-steps
         // (8192 per 1/60 s) in a follow-up launch.
         if (p.integrator == PVDER_INT_ETDLIN) {
-            if (p.ph == 3) hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, G);
-            else hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, G);
+            if (p.ph == 3)
+                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, 0, G);
+            else
+                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, 0, G);
         } else {
             if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);

@@ -64,6 +64,13 @@ class LinCoef(C.Structure):
                 ("sched", C.c_void_p), ("est_guard", C.c_float)]
 
 
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs (the VALU code reads them without
+# v_accvgpr_read copies); -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (pointers and
+# sizes a launch needs for its first loads) arrive in SGPRs with the wave instead of through an s_load
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+               "-mllvm", "-amdgpu-kernarg-preload-count=12"]
+
+
 def hipcc_path() -> str:
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
@@ -78,10 +85,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())          # build aside, then rename: never a half-written library
-    # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs (the VALU code reads them without
-    # v_accvgpr_read copies); the 231 A operands of the etdlin kernels are pinned to the AGPR half instead
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-I" + INCLUDE, "-I" + CSRC, "-o", tmp] + srcs
+    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC, "-o", tmp] + srcs
     if verbose:
         print(" ".join(cmd))
     try:

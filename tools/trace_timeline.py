@@ -29,8 +29,8 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libpvder_hip_trace.so")
     srcs = [os.path.join(_native.CSRC, f) for f in sorted(os.listdir(_native.CSRC)) if f.endswith(".hip")]
-    subprocess.check_call([_native.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DPVDER_TRACE", "-I" + _native.INCLUDE, "-I" + _native.CSRC, "-o", lib] + srcs)
+    subprocess.check_call([_native.hipcc_path()] + _native.HIPCC_FLAGS + ["-fPIC", "-shared", "-DPVDER_TRACE",
+                           "-I" + _native.INCLUDE, "-I" + _native.CSRC, "-o", lib] + srcs)
     _native.LIB_PATH = lib
     L = _native.lib()
     L.pvder_debug_trace.restype = C.c_int
@@ -93,7 +93,8 @@ def main():
     print("N=%d blocks=%d   event-timed step (both launches) median %.1f us" % (N, nblk, float(np.median(evs))))
     names = {0: "entry", 1: "lds staged", 2: "state loaded", 20: "integration done", 22: "outputs+reward done", 23: "stores issued", 21: "epilogue issued"}
     names.update({24: "it1: F1", 25: "it1: M21/31/41 F1", 26: "it1: F2", 27: "it1: M32/42 F2", 28: "it1: F3", 29: "it1: M43 F3"})
-    for s in [0, 1, 2] + list(range(3, 18)) + [24, 25, 26, 27, 28, 29, 20, 22, 23, 21]:
+    names.update({18: "kernel arguments in", 19: "coefficient regs in"})
+    for s in [0, 18, 19, 1, 2] + list(range(3, 18)) + [24, 25, 26, 27, 28, 29, 20, 22, 23, 21]:
         x = R[:, :, s]
         print("slot %2d %-18s min %6.2f  med %6.2f  p90 %6.2f  max %6.2f us" % (
             s, names.get(s, "sub-step %d" % (s - 3)), np.median(x.min(1)), np.median(np.median(x, 1)),
