@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import cmath
 import math
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -56,11 +56,25 @@ PAR = ["PHASES", "RF", "LF", "C", "KVG_RE", "KVG_IM", "KVI_RE", "KVI_IM", "KP_GC
 IDX = {k: i for i, k in enumerate(PAR)}
 
 
-def param_vector(der_id: str = "50") -> np.ndarray:
-    """Per-unit constants of one DER as the C ABI's ``double par[PVDER_PAR_COUNT]``."""
+def der_config(der_id: str = "50", overrides: Optional[Dict[str, float]] = None) -> Dict[str, float]:
+    """The config block of ``der_id`` (values of config_der.json) with ``overrides`` applied -- a
+    parameter SET for domain randomisation: any key of the block except ``phases``."""
     if der_id not in DER_CONFIG:
         raise ValueError("unknown derId %r (available: %s)" % (der_id, sorted(DER_CONFIG)))
-    c = DER_CONFIG[der_id]
+    c = dict(DER_CONFIG[der_id])
+    for k, v in (overrides or {}).items():
+        if k not in c or k == "phases":
+            raise ValueError("der_config override %r: not a parameter of derId %s (%s)"
+                             % (k, der_id, sorted(x for x in c if x != "phases")))
+        if isinstance(v, bool) or not isinstance(v, (int, float)) or not math.isfinite(float(v)):
+            raise ValueError("der_config override %r must be a finite number" % k)
+        c[k] = float(v)
+    return c
+
+
+def param_vector(der_id: str = "50", overrides: Optional[Dict[str, float]] = None) -> np.ndarray:
+    """Per-unit constants of one DER as the C ABI's ``double par[PVDER_PAR_COUNT]``."""
+    c = der_config(der_id, overrides)
     ph = int(c["phases"])
     a = VGRIDRATED / (c["Vrmsrated"] * math.sqrt(2.0))          # transformer turns ratio
     Z1 = complex(c["R1_actual"], c["X1_actual"]) / ZBASE

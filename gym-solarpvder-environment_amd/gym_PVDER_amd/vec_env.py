@@ -155,7 +155,11 @@ class PVDERVec(EnvSpecMixin):
                  graded: bool = True,
                  model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
-                 events_spec: Optional[dict] = None):
+                 events_spec: Optional[dict] = None, der_config: Optional[dict] = None):
+        """``der_config``: overrides of the model's config block (keys of config_der.json's derId entry, e.g.
+        ``{"C_actual": 330e-6, "Kp_DC": -2.2}``) -- ONE parameter set per PVDERVec (the steady state, the
+        Jacobian of the etdlin path and the coefficient tables are derived from it); for a batch spread over
+        several parameter sets see gym_PVDER_amd.param_groups.PVDERVecGroups."""
         if not isinstance(num_envs, int) or num_envs < 1:
             raise ValueError("num_envs must be a positive integer")
         if model_type not in self.env_model_spec:
@@ -194,7 +198,8 @@ class PVDERVec(EnvSpecMixin):
         self.rtol, self.atol = float(rtol), float(atol)
         self.env_events_spec = copy.deepcopy(events_spec) if events_spec else default_events_spec()
         self.der_id = self.env_model_spec[model_type]['derId']
-        self.par = der_model.param_vector(self.der_id)
+        self.der_config = dict(der_config) if der_config else None
+        self.par = der_model.param_vector(self.der_id, self.der_config)
         self.phases = int(self.par[0])
         self.ns = 6 * self.phases + 5
         self.y0 = der_model.steady_state(self.par, self.der_id)
@@ -429,7 +434,7 @@ class PVDERVec(EnvSpecMixin):
         schedule changes."""
         lens = etd_linear.choose_sets(cfg.n_sub, cfg.micro, cfg.ev_s0, cfg.ev_ds, cfg.ev_count, cfg.max_ksub,
                                       _native.LIN_MAX_SETS)
-        key = (self.der_id, cfg.micro, cfg.n_sub, tuple(lens))
+        key = (self.der_id if not self.der_config else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, tuple(lens))
         if getattr(self, "_lin_key", None) != key:
             host = PVDERVec._lin_cache.get(key[:2] + key[3:])
             if host is None:

@@ -147,10 +147,14 @@ class DERModel:
     opts: ModelOptions = field(default_factory=ModelOptions)
 
 
-def build_model(der_id: str = "50", opts: Optional[ModelOptions] = None) -> DERModel:
-    """Per-unitise a config block the way pvder's ``initialize_DER`` does (published model)."""
+def build_model(der_id: str = "50", opts: Optional[ModelOptions] = None, overrides: Optional[dict] = None) -> DERModel:
+    """Per-unitise a config block the way pvder's ``initialize_DER`` does (published model).
+    ``overrides``: other values for keys of the block (a parameter set of a domain-randomised batch)."""
     opts = opts or ModelOptions()
-    c = DER_CONFIG[der_id]
+    c = dict(DER_CONFIG[der_id])
+    for k, v in (overrides or {}).items():
+        assert k in c and k != "phases", k
+        c[k] = float(v)
     phases = int(c["phases"])
     Varated = c["Vrmsrated"] * math.sqrt(2.0)
     a = VGRIDRATED / Varated

@@ -351,3 +351,41 @@ def test_native_step_gather_world1(gpu_device):
     nat.close()
     rc.close()
     dist.destroy_process_group()
+
+
+def test_parameter_sets_vs_converged_bridge(gpu_device):
+    """Domain randomisation over parameter sets: a batch spread over three config blocks
+    -- the reference's, a bigger DC-link capacitor with other outer-loop gains, a smaller PV array on a lossier
+    filter (another operating point: other steady state, other Jacobian in the exponential) -- stepped as
+    PVDERVecGroups; every group against the fp64 bridge integrating ITS parameter set to convergence."""
+    from gym_PVDER_amd.param_groups import PVDERVecGroups
+    cfgs = [{}, {"C_actual": 360e-6, "Kp_DC": -2.5, "Ki_DC": -12.0, "Ki_Q": 12.0},
+            {"Np": 10, "Rf_actual": 0.003, "Kp_GCC": 5000.0, "wp": 18e4}]
+    n_g, n_sub, steps = [64, 128, 64], 15, 8
+    env = PVDERVecGroups(n_g, cfgs, device=gpu_device, n_sim_time_steps_per_env_step=n_sub, seed=9,
+                         events_spec=both_events_spec(), auto_reset=False)
+    obs0 = env.reset()
+    assert obs0.shape == (sum(n_g), 11)
+    refs = []
+    for g, cfg in zip(env.groups, cfgs):
+        ref = BridgeVecEnv(g.num_envs, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11, overrides=cfg)
+        ref.reset(g.ev_vg.cpu().numpy().astype(np.float64), g.ev_si.cpu().numpy().astype(np.float64),
+                  ev_s0=g.ev_s0, ev_ds=g.ev_ds)
+        refs.append(ref)
+    rng = np.random.default_rng(31)
+    got, want = [], []
+    for t in range(steps):
+        a = rng.integers(0, 5, size=sum(n_g))
+        obs, rew, done, _ = env.step(torch.as_tensor(a, device=gpu_device))
+        got.append(obs.cpu().numpy().astype(np.float64))
+        w, off = [], 0
+        for ref, n in zip(refs, n_g):
+            w.append(ref.step(a[off:off + n])[0]); off += n
+        want.append(np.concatenate(w, axis=0))
+    got, want = np.stack(got), np.stack(want)
+    N = sum(n_g)
+    err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
+    assert err.max() < FP32_TOL / 2, err.max()
+    # the sets really differ: same events and actions would give the same trajectories otherwise
+    assert not np.allclose(got[:, 0], got[:, 64 + 128], rtol=0, atol=1e-4)
+    assert env.step_stats()["n_nonfinite"] == 0

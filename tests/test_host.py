@@ -266,3 +266,20 @@ def test_plan_and_rollout_argument_validation_without_a_gpu():
     assert L.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS["etdlin"], par_c, C.byref(cfg), C.byref(ar), None, None, 1024) \
         == _native.EINVAL             # etdlin without coefficient sets
     assert L.pvder_plan_rollout_fused(None, one, one, one, one, one, 4, one, 0, None, one, None) == _native.EINVAL
+
+
+def test_parameter_set_overrides_match_the_oracle_and_are_validated():
+    """der_config overrides (a parameter set of a domain-randomised batch): the product's parameter vector and
+    steady state against the oracle's model built with the same overrides; unknown keys / bad values raise."""
+    from gym_PVDER_amd import der_model
+    from oracle import bridge, pvder_model as pm
+    ov = {"C_actual": 360e-6, "Kp_DC": -2.5, "Ki_Q": 12.0, "Np": 10, "Rf_actual": 0.003}
+    par = der_model.param_vector("50", ov)
+    m = pm.build_model("50", overrides=ov)
+    assert np.array_equal(par[:27], bridge.pack_params(m))
+    assert np.abs(der_model.steady_state(par, "50") - pm.steady_state(m)).max() < 1e-12
+    assert not np.array_equal(par, der_model.param_vector("50"))
+    assert np.array_equal(der_model.param_vector("50", {}), der_model.param_vector("50"))
+    for bad in ({"nope": 1.0}, {"phases": 1}, {"C_actual": float("nan")}, {"C_actual": "big"}, {"Np": True}):
+        with pytest.raises(ValueError):
+            der_model.param_vector("50", bad)
