@@ -432,6 +432,11 @@ def run_rank(args):
             drain()
         r1.record()
         host = time.perf_counter() - t0        # host side of the loop (launches are asynchronous)
+        # the host polls the closing event before it calls synchronize(): the blocking wait inside
+        # hipDeviceSynchronize wakes the thread tens of microseconds after the GPU is done -- nothing next to
+        # 4000 steps, a quarter of a 20-step window (the synchronize below then returns at once)
+        while not r1.query():
+            pass
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
