@@ -80,6 +80,9 @@ def parse(argv=None):
     ap.add_argument("--preroll-steps", type=int, default=20000,
                     help="untimed steps BEFORE the --warmup steps (0.2 s of GPU work: clocks, TLBs and code paths at their "
                          "steady state when the warm-up starts; a 5-step warm-up alone leaves a 20-step window ramping)")
+    ap.add_argument("--graph-window", type=int, default=1,
+                    help="1: a window shorter than 256 steps replays ONE HIP graph of its per-step launches (captured "
+                         "before the window); 0: eager launches")
     ap.add_argument("--fused-seconds", type=float, default=0.5,
                     help="length of the separately labelled fused-rollout leg (0 = skip)")
     ap.add_argument("--fused-steps", type=int, default=160, help="env steps per fused launch in that leg")
@@ -386,7 +389,7 @@ def run_rank(args):
                     pending[b].wait()
                     pending[b] = None
 
-    def timed(first, count, every, gather=True):
+    def timed(first, count, every, gather=True, graph=None):
         """`count` steps starting at action row `first`, bracketed by barrier + synchronize on both
         sides; returns (max-over-ranks seconds, host enqueue seconds, per-launch event samples in ms,
         ms per step by ONE HIP-event pair around the whole region on the launch stream)."""
@@ -398,7 +401,9 @@ def run_rank(args):
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         r0.record()
-        if dist is None or not gather:
+        if graph is not None:
+            graph.replay()        # the same `count` per-step launches, captured before the window (see below)
+        elif dist is None or not gather:
             # open-loop rollout: the launches of the stretch between two event-bracketed ones are enqueued
             # by ONE host call (env.rollout -> pvder_plan_rollout: the same per-step launch, K times)
             i, stop = first, first + count
@@ -473,7 +478,21 @@ def run_rank(args):
     every = 0 if short else sample_period(args.time_every, args.steps)
     n_post = 0 if (args.time_every <= 0 or not short) else 8
     env.reserve_timing_events((args.steps // max(every, 1) + 2 if every > 0 else 0) + n_post)   # created and warmed outside the window
-    elapsed, host_enqueue, kern_ms, region_ms = timed(args.warmup, args.steps, every)
+    # A short window is launch-bound on the HOST: the first launches into an idle queue cost ~10 us apiece
+    # (2.7 us once the queue is backed up), more than the 8 us kernel they start.  Its K per-step launches --
+    # the very same kernels, action rows and order -- are therefore captured into ONE HIP graph before the
+    # window and replayed inside it (the C entry points are asynchronous and allocation-free:
+    # tests/test_gpu_parity.py::test_step_is_graph_capturable).  Long windows stay eager (GPU-bound).
+    window_graph = None
+    if short and dist is None and args.graph_window and args.warmup + args.steps <= pool:
+        try:
+            window_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(window_graph):
+                env.rollout(actions[args.warmup:args.warmup + args.steps], fused=False)
+        except Exception as exc:
+            window_graph = None
+            warnings.append("HIP-graph capture of the window failed (%r): eager launches" % (exc,))
+    elapsed, host_enqueue, kern_ms, region_ms = timed(args.warmup, args.steps, every, graph=window_graph)
     st = env.step_stats()
     post_note = ""
     if n_post and dist is None:
@@ -609,6 +628,8 @@ def run_rank(args):
                                                       "rk4": "fp32 fixed-step classic RK4, %d micro-steps per 1/60 s" % args.micro,
                                                       "rk45": "fp64 adaptive RK45"}[args.integrator]),
                        "envs_per_gpu": N, "n_sub": args.n_sub, "micro_steps": args.micro, "preroll_steps": preroll,
+                       "launch": ("one HIP graph of the window's %d per-step launches, captured before the window" % args.steps)
+                       if window_graph is not None else "eager: one launch per env step, enqueued from C",
                        "micro_coarse": env.micro_coarse, "graded": bool(env.graded),
                        "integrator": args.integrator,
                        "collective": ("all-gather of the [13, N_local] fp32 block per step: %s; %s"
