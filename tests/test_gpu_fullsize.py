@@ -21,7 +21,7 @@ def sample_ids(rng):
     return np.unique(np.concatenate([edges, rest]))[:128]
 
 
-def run_and_compare(device, integrator, steps, tol, seed, **kw):
+def run_and_compare(device, integrator, steps, tol, seed, fused=False, **kw):
     from gym_PVDER_amd.vec_env import PVDERVec
     rng = np.random.default_rng(seed)
     ids = sample_ids(rng)
@@ -38,8 +38,14 @@ def run_and_compare(device, integrator, steps, tol, seed, **kw):
     ref.reset(env.ev_vg[:, sel].cpu().numpy().astype(np.float64), env.ev_si[:, sel].cpu().numpy().astype(np.float64),
               ev_s0=env.ev_s0, ev_ds=env.ev_ds)
     got, want = [], []
+    if fused:          # the whole rollout in ONE call, the env steps fused into one launch
+        blocks = torch.empty((steps, 13, N), dtype=torch.float32, device=device)
+        env.rollout(acts, out=blocks, fused=True)
     for t in range(steps):
-        obs, rew, done, _ = env.step(acts[t])
+        if fused:
+            obs, rew, done = blocks[t, :11].t(), blocks[t, 11], blocks[t, 12] != 0
+        else:
+            obs, rew, done, _ = env.step(acts[t])
         o2, r2, d2 = ref.step(acts[t][sel].cpu().numpy())
         got.append(obs[sel].cpu().numpy().astype(np.float64)); want.append(o2)
         assert np.array_equal(done[sel].cpu().numpy(), d2)
@@ -57,6 +63,12 @@ def run_and_compare(device, integrator, steps, tol, seed, **kw):
 @pytest.mark.parametrize("integrator,tol", [("etdlin", 5e-5), ("etdrk4", 1e-4)])
 def test_configs2_full_size_vs_converged_bridge(gpu_device, integrator, tol):
     run_and_compare(gpu_device, integrator, steps=8, tol=tol, seed=31)
+
+
+def test_configs2_full_size_fused_rollout_vs_converged_bridge(gpu_device):
+    """The same full-size batch as ONE fused rollout (pvder_plan_rollout_fused): against the oracle directly,
+    not only through its bit-identity with the per-step launches."""
+    run_and_compare(gpu_device, "etdlin", steps=8, tol=5e-5, seed=31, fused=True)
 
 
 def test_configs4_fp64_rk45_full_size_vs_converged_bridge(gpu_device):
