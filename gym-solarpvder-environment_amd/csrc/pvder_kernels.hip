@@ -3,15 +3,18 @@
 // every global access of a wave is one fully coalesced 256-byte row segment); model constants in
 // SGPRs (kernel argument); the whole env transition
 //     action_calc -> integrate n_sub sim time steps -> reward_calc -> done -> state [-> auto-reset]
-// (PVDER_env.py:138-196, :198-229, :231-301, :531-542, :316-334) is ONE launch with the 23 states
-// held in registers for the entire step; wave-level (DPP) reduction of the reward-sum / done-count
-// statistics into one plain store per workgroup and statistic, no atomics (env_utilities.py:32-38
-// aggregate).
+// (PVDER_env.py:138-196, :198-229, :231-301, :531-542, :316-334) is ONE launch with the states held
+// in registers for the entire step; wave-level (DPP) reduction of the reward-sum / done-count
+// statistics into one 16-byte store per wave, no atomics, no barrier (env_utilities.py:32-38 aggregate).
 //
 // Integrators (fixed per launch, selected by the entry point / plan):
 //   step_etdlin_kernel<PH>     fp32 ETD3RK (Cox-Matthews) on dy/dt = L y + N(y), L = the full 11x11
-//                              Jacobian at the nominal operating point: two steps per env step;
-//                              balanced 11-state fast path + 23-state tail in ONE launch (default)
+//                              Jacobian at the nominal operating point: a tick + two steps per env step,
+//                              the dense 11x11 matrix-vector products on the matrix cores (fp32 MFMA
+//                              4x4x1, coefficient operands packed sixteen to a register); balanced
+//                              11-state fast path + 23-state tail in ONE launch (default)
+//   step_etdlin_rollout_kernel K env steps of an open-loop action sequence FUSED into one launch, state
+//   + ..._finish_kernel        in registers from step to step (pvder_plan_rollout_fused); bit-identical
 //   step_etdrk4_bal_kernel<PH> fp32 exponential Runge-Kutta method of stiff order 4 (Hochbruck-Ostermann,
 //                              5 stages): only the stiff current loop (i_p,u_p) is in the exponential;
 //                              balanced 11-state fast path + 23-state tail (etdrk4_full_tail) in ONE launch
@@ -19,7 +22,9 @@
 //   step_rk4_kernel<T,PH>      classic RK4 micro-stepping, generic (single phase / A-B reference)
 //   step_rk45_kernel<T,PH> fp64 adaptive Dormand-Prince 5(4)
 //
-// No MFMA: there is no dense contraction in this path (per-env 23-state nonlinear ODE).
+// The right-hand side itself has no dense contraction (per-env nonlinear ODE: VALU, packed fp32); the
+// matrix cores enter through the exponential integrator, whose coefficients are dense matrices shared
+// by all envs -- a GEMM with one operand per parameter set and one column per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -277,12 +282,17 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
                                          T *y, T *__restrict__ fstate, int32_t *__restrict__ istate,
                                          float *__restrict__ ev_vg, float *__restrict__ ev_si,
                                          T *__restrict__ out, float *__restrict__ stats, int n_env,
-                                         int stats_fresh = 0) {
+                                         int stats_fresh = 0, bool have_inputs = false, float vg_stop = 0.f,
+                                         float si_stop = 0.f) {
+    // have_inputs: the caller fetched the event inputs in force at tStop ahead of the integration (same table
+    // entries; a lone wave per SIMD would otherwise sit out a memory round trip right here)
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     const int ec = L.ec;
     SubK<T, PH> S;
-    {
+    if (have_inputs) {
+        pvder::make_sub<T, PH>(P, (T)vg_stop, (T)si_stop, S);
+    } else {
         const int row = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count);
         pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + ec], (T)ev_si[(size_t)row * N + ec], S);
     }
@@ -1385,6 +1395,12 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     // ksub is the first state word to arrive: the event inputs and the schedule row of the first segment
     // are requested while the other state rows are still in flight
     const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
+    // ... and so are the inputs in force at tStop (the observation is taken there): the row the first segment
+    // runs on, the next one if it changes exactly at tStop, a second division only if an event cuts the env step
+    int row_stop = sg.row;
+    if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
+    else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
+    const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
     PVDER_TRACE_AT(1);
     bool defer = PH == 3 && A.force_full != 0;
     if constexpr (PH == 3) defer |= L.run && lin_unbalanced(ys);
@@ -1412,7 +1428,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         L.live = false;
     }
     epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out + out_off, E.stats, E.n_env,
-                        stats_fresh);
+                        stats_fresh, true, vg_stop, si_stop);
     PVDER_TRACE_AT(21);
     if constexpr (PH == 3) {
         // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state
