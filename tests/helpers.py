@@ -23,3 +23,27 @@ def both_events_spec():
     s = {k: dict(v) for k, v in DEFAULT_EVENTS_SPEC.items()}
     s["insolation"]["ENABLE"] = True
     return s
+
+
+_BRIDGE_EPISODES = {}
+
+
+def bridge_episode(vg, si, ev_s0, ev_ds, actions, n=15, rtol=1e-8, atol=1e-11):
+    """Observation / reward / done trajectory of the converged fp64 bridge (RK45) for the given event tables
+    and actions ([steps, N]); cached per process -- the whole-episode tests of several integrators replay the
+    same episode, and 160 env steps at rtol 1e-8 are ~100 s of CPU."""
+    import hashlib
+    from oracle.bridge_env import BridgeVecEnv
+    vg, si = np.ascontiguousarray(vg, dtype=np.float64), np.ascontiguousarray(si, dtype=np.float64)
+    actions = np.ascontiguousarray(actions, dtype=np.int64)
+    key = hashlib.sha1(vg.tobytes() + si.tobytes() + actions.tobytes()
+                       + repr((ev_s0, ev_ds, n, rtol, atol)).encode()).hexdigest()
+    if key not in _BRIDGE_EPISODES:
+        ref = BridgeVecEnv(actions.shape[1], n=n, method="rk45", rtol=rtol, atol=atol)
+        ref.reset(vg, si, ev_s0=ev_s0, ev_ds=ev_ds)
+        obs, rew, done = [], [], []
+        for a in actions:
+            o, r, d = ref.step(a)
+            obs.append(o.copy()); rew.append(np.array(r, copy=True)); done.append(np.array(d, copy=True))
+        _BRIDGE_EPISODES[key] = (np.stack(obs), np.stack(rew), np.stack(done))
+    return _BRIDGE_EPISODES[key]

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import both_events_spec, rel_l2
+from helpers import both_events_spec, bridge_episode, rel_l2
 from oracle.bridge_env import BridgeVecEnv
 from test_gpu_golden import CASES, run_case
 
@@ -78,15 +78,13 @@ def test_etdlin_full_episode_does_not_drift(gpu_device):
     env = make_vec(N, gpu_device, integrator="etdlin", seed=1234, events_spec=both_events_spec(), auto_reset=False)
     env.reset()
     vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
-    ref = BridgeVecEnv(N, n=15, method="rk45", rtol=1e-8, atol=1e-11)
-    ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
-    got, want = [], []
+    want, _, want_d = bridge_episode(vg, si, env.ev_s0, env.ev_ds, actions)             # (shared with the ETDRK4 test)
+    got = []
     for t in range(steps):
         obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
-        o2, r2, d2 = ref.step(actions[t])
-        got.append(obs.cpu().numpy().astype(np.float64)); want.append(o2)
-        assert np.array_equal(done.cpu().numpy(), d2)
-    got, want = np.stack(got), np.stack(want)
+        got.append(obs.cpu().numpy().astype(np.float64))
+        assert np.array_equal(done.cpu().numpy(), want_d[t])
+    got = np.stack(got)
     flat = lambda a: a.transpose(1, 0, 2).reshape(N, -1)
     assert rel_l2(flat(got), flat(want), axis=1).max() < FP32_TOL / 2
     assert rel_l2(flat(got[-20:]), flat(want[-20:]), axis=1).max() < FP32_TOL / 2      # the last 5 s alone

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import both_events_spec, counter_tables, rel_l2
+from helpers import both_events_spec, bridge_episode, counter_tables, rel_l2
 from oracle import pvder_model as pm
 from oracle.bridge_env import BridgeVecEnv
 
@@ -282,17 +282,15 @@ def test_full_episode_drift_vs_converged_bridge(gpu_device):
     env = make_vec(N, gpu_device, integrator="etdrk4", seed=1234, events_spec=both_events_spec(), auto_reset=False)
     env.reset()
     vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
-    ref = BridgeVecEnv(N, n=15, method="rk45", rtol=1e-8, atol=1e-11)
-    ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
-    got, want, rmis = [], [], 0
+    want, want_r, want_d = bridge_episode(vg, si, env.ev_s0, env.ev_ds, actions)        # (shared with the etdlin test)
+    got, rmis = [], 0
     for t in range(steps):
         obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
-        o2, r2, d2 = ref.step(actions[t])
-        got.append(obs.cpu().numpy().astype(np.float64)); want.append(o2)
-        rmis += int((rew.cpu().numpy() != r2).sum())
-        assert np.array_equal(done.cpu().numpy(), d2)
-    assert bool(done.all()) and d2.all()                 # 160 * 0.25 s = max_sim_time
-    got, want = np.stack(got), np.stack(want)
+        got.append(obs.cpu().numpy().astype(np.float64))
+        rmis += int((rew.cpu().numpy() != want_r[t]).sum())
+        assert np.array_equal(done.cpu().numpy(), want_d[t])
+    assert bool(done.all()) and want_d[-1].all()         # 160 * 0.25 s = max_sim_time
+    got = np.stack(got)
     err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
     assert err.max() < FP32_TOL, "whole-episode rel-L2 %.3e" % err.max()
     last = rel_l2(got[-20:].transpose(1, 0, 2).reshape(N, -1), want[-20:].transpose(1, 0, 2).reshape(N, -1), axis=1)
