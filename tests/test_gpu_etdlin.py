@@ -387,3 +387,38 @@ def test_parameter_sets_vs_converged_bridge(gpu_device):
     # the sets really differ: same events and actions would give the same trajectories otherwise
     assert not np.allclose(got[:, 0], got[:, 64 + 128], rtol=0, atol=1e-4)
     assert env.step_stats()["n_nonfinite"] == 0
+
+
+@pytest.mark.parametrize("goal,discrete,n_sub", [("power_regulation", True, 15), ("Q_regulation", False, 15),
+                                                  ("voltage_regulation", False, 7), ("voltage_regulation", True, 4)])
+def test_fused_rollout_other_goals_and_event_grids(gpu_device, goal, discrete, n_sub):
+    """The fused rollout with the other goals' reward terms (discrete and continuous, power_regulation with the
+    optional Vdc_error term) and with event grids that CUT env steps (0.2 s grid, n = 7 / 4: the general per-lane
+    loop and its mid-step event fetches run inside the fused kernel) == single steps, bit for bit."""
+    N, K = 1536, 18
+    spec = both_events_spec()
+    if n_sub != 15:
+        spec["voltage"]["t_events_start"] = spec["insolation"]["t_events_start"] = 0.2
+        spec["voltage"]["t_events_step"] = 0.2
+    kw = dict(n_sim_time_steps_per_env_step=n_sub, seed=3, events_spec=spec, auto_reset=True, max_sim_time=1.5,
+              goals_list=[goal], DISCRETE_REWARD=discrete)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(5)
+    acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    envs = [make_vec(N, gpu_device, **kw) for _ in range(2)]
+    for env in envs:
+        if goal == "power_regulation":
+            env.set_reward_spec(['power_error', 'Vdc_error'])
+        env.reset()
+    a, b = envs
+    singles = []
+    for k in range(K):
+        a.step(acts[k], return_tensors=False)
+        singles.append(a.out.clone())
+    blocks = torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device)
+    b.rollout(acts, out=blocks, fused=True)
+    assert torch.equal(blocks, torch.stack(singles))
+    assert _same_env_state(a, b) and a.step_stats() == b.step_stats()
+    rew = blocks[:, 11]
+    assert bool(torch.isfinite(rew).all())
+    if not discrete:
+        assert bool((rew <= 0).all()) and bool((rew < 0).any())          # -(error)^2
