@@ -354,9 +354,10 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
     // an env step) or add to it (a follow-up launch / the 23-state tail of the same step).
     if (stats) {
         const float r = wave_sum_to_lane63(L.run ? (float)reward : 0.f);
-        const float d = wave_sum_to_lane63(done_f);
-        const float nf = wave_sum_to_lane63(nonfinite);
-        const float ba = wave_sum_to_lane63(L.live ? L.bad_action : 0.f);
+        // the three counters are 0 / 1 per lane: a ballot and a population count each (scalar), not a DPP tree
+        const float d = (float)__popcll(__ballot((int)(done_f != 0.f)));
+        const float nf = (float)__popcll(__ballot((int)(nonfinite != 0.f)));
+        const float ba = (float)__popcll(__ballot((int)(L.live && L.bad_action != 0.f)));
         if ((threadIdx.x & 63) == 63) {
             v4 *slot = (v4 *)stats + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
             v4 t = {r, d, nf, ba};
@@ -1477,17 +1478,17 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(float *fstate, int3
 }
 
 // =============================================================================================
-// Open-loop rollouts (pvder_plan_rollout with a scratch buffer, etdlin, three-phase): n_steps env steps in
-// ONE launch, the 11-state reduction in registers from the first step to the last.  A per-step launch
-// spends 3 us waiting for its state rows and 2 us writing them back (41 rows) around 4.6 us of
-// integration; the fused loop reads the state once, writes it once, and per step only computes and stores
-// the 13 output rows -- with the SAME code the per-step launch runs (lin_integrate; rotation into the
+// Open-loop rollouts (pvder_plan_rollout_fused; etdlin, three-phase): n_steps env steps in ONE launch, the
+// 11-state reduction in registers from the first step to the last.  A per-step launch spends 2 us waiting
+// for its state rows, 1.7 us on outputs and the write-back of 41 rows and 1.2 us between launches around
+// 3.3 us of integration; the fused loop reads the state once, writes it once, and per step only computes and
+// stores the 13 output rows -- with the SAME code the per-step launch runs (lin_integrate; rotation into the
 // 23-row form; outputs / reward_of), so the results are bit-identical to n_steps single launches.
 // What the loop does NOT carry is everything rare: a workgroup leaves the loop -- its state as of the
-// start of that step written back -- at the first step in which one of its envs is off balance or near a
+// start of that step restored -- at the first step in which one of its envs is off balance or near a
 // limit (23-state path), would finish its episode (done / auto-reset logic, known BEFORE the step: time
 // and step counters), is not running, or comes out non-finite.  step_etdlin_finish_kernel then takes
-// the workgroup through the remaining steps one at a time, through memory, with the per-step body.
+// the workgroup through that step (per-step body, through memory) and the fused kernel resumes.
 // =============================================================================================
 struct RollArgs {
     LinArgs G;                       // at kernarg offset 0 (the 23-state tail of the finish kernel re-reads G.A from there)
@@ -1504,7 +1505,11 @@ __device__ __forceinline__ const RollArgs &roll_args() {
 }
 
 template <int PH>
-__global__ __launch_bounds__(kBlock) void step_etdlin_rollout_kernel(const RollArgs Q) {
+__global__ __launch_bounds__(kBlock)
+#ifndef PVDER_ROLLOUT_OCC2
+__attribute__((amdgpu_waves_per_eu(3)))      // 168 VGPRs: three waves per SIMD for batches beyond 131 072 envs
+#endif
+void step_etdlin_rollout_kernel(const RollArgs Q) {
     using namespace pvder;
     constexpr int NS = 6 * PH + 5;
     if (Q.Rk.resume && Q.Rk.progress[blockIdx.x] >= Q.Rk.n_steps) return;      // (workgroup-uniform) nothing left
