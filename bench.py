@@ -220,7 +220,7 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "gym-solarpvder-environment_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp")) and f != "pvder_agent.hip":      # (the agent kernel is not on the step path)
             h.update(open(os.path.join(csrc, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "pvder_hip.h"), "rb").read())
     return h.hexdigest()[:16]

@@ -29,6 +29,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused"]
+AGENT_SYMBOLS = ["pvder_qagent_step_f32"]            # include/pvder_agent.h
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
 LIN_MAX_SETS = 8
@@ -58,6 +59,14 @@ class AutoReset(C.Structure):
                 ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double))]
 
 
+class QAgentCfg(C.Structure):
+    """``struct pvder_qagent_cfg`` (include/pvder_agent.h)."""
+    _fields_ = [("bins", C.c_int32), ("n_act", C.c_int32), ("first", C.c_int32), ("choose", C.c_int32),
+                ("lr", C.c_float), ("gamma", C.c_float), ("epsilon", C.c_float), ("q_done", C.c_float),
+                ("low", C.c_double), ("win", C.c_double), ("seed", C.c_uint64), ("counter", C.c_uint64),
+                ("env_id_base", C.c_int64)]
+
+
 class LinCoef(C.Structure):
     """``struct pvder_lin_coef`` (include/pvder_hip.h)."""
     _fields_ = [("sets", C.c_void_p), ("n_sets", C.c_int32), ("len_ticks", C.c_int32 * LIN_MAX_SETS),
@@ -79,7 +88,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into gym_PVDER_amd/lib/libpvder_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    deps.append(os.path.join(INCLUDE, "pvder_hip.h"))
+    deps += [os.path.join(INCLUDE, "pvder_hip.h"), os.path.join(INCLUDE, "pvder_agent.h")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
         return LIB_PATH
@@ -116,7 +125,7 @@ def lib() -> C.CDLL:
             % LIB_PATH)
     import torch  # noqa: F401  (loads torch/lib/libamdhip64.so first: single HIP runtime)
     L = C.CDLL(LIB_PATH)
-    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    missing = [s for s in SYMBOLS + AGENT_SYMBOLS if not hasattr(L, s)]
     if missing:
         raise ImportError("libpvder_hip.so lacks symbols: %s" % missing)
     if L.pvder_version() != ABI_VERSION:
@@ -149,6 +158,8 @@ def lib() -> C.CDLL:
     L.pvder_plan_rollout.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.pvder_plan_rollout_fused.restype = i32
     L.pvder_plan_rollout_fused.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
+    L.pvder_qagent_step_f32.restype = i32
+    L.pvder_qagent_step_f32.argtypes = [C.POINTER(QAgentCfg), vp, vp, vp, vp, vp, vp, i32, vp]
     L.pvder_gather_create.restype = i32
     L.pvder_gather_create.argtypes = [C.POINTER(vp), vp, vp]
     L.pvder_gather_destroy.restype = None

@@ -12,10 +12,12 @@ When several envs hit the same (state, action) in one step, one of their updates
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, List, Optional
 
 import torch
 
+from .. import _native
 from ..vec_env import PVDERVec
 
 
@@ -39,6 +41,7 @@ class BatchedQAgent:
         self.epsilon = 1.0                                         # qagent.py:27
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
+        self.seed = int(seed)
         self.aggregate_episode_rewards: Dict[str, List[float]] = {'episode': [], 'average': [], 'max': [], 'min': []}
 
     def get_discrete_state(self, obs: torch.Tensor) -> torch.Tensor:
@@ -66,6 +69,67 @@ class BatchedQAgent:
         new_q = (1.0 - lr) * cur + lr * (r + gamma * self.q_table[s2].max(dim=1).values)          # :88-95
         new_q = torch.where(done, torch.zeros_like(new_q), new_q)                                   # :100-103
         self.q_table.index_put_((s[alive], a[alive]), new_q[alive])
+
+    # -- the same loop with the agent side as ONE HIP launch per env step (include/pvder_agent.h) ------------
+    def _agent_cfg(self, first: bool, choose: bool, counter: int) -> "_native.QAgentCfg":
+        c = _native.QAgentCfg()
+        c.bins, c.n_act, c.first, c.choose = self.bins, self.n_act, int(first), int(choose)
+        c.lr, c.gamma = self.train_spec['LEARNING_RATE'], self.train_spec['DISCOUNT']
+        c.epsilon, c.q_done = self.epsilon, 0.0
+        c.low, c.win = self.low, self.win
+        c.seed, c.counter, c.env_id_base = self.seed & (2 ** 64 - 1), counter, self.env.env_id_base
+        return c
+
+    def fused_step(self, state: torch.Tensor, action: torch.Tensor, alive: torch.Tensor, ep_reward: torch.Tensor,
+                   first: bool, choose: bool = True, counter: int = 0):
+        """Discretise ``env.out``, learn from the transition that led to it, choose the next action -- one
+        launch (pvder_qagent_step_f32) on torch's current stream; all arguments are device tensors updated in
+        place (``state`` int64 [N], ``action`` uint8 [N], ``alive`` uint8 [N], ``ep_reward`` float64 [N])."""
+        env = self.env
+        cfg = self._agent_cfg(first, choose, counter)
+        rc = env._lib.pvder_qagent_step_f32(C.byref(cfg), self.q_table.data_ptr(), env.out.data_ptr(), state.data_ptr(),
+                                            action.data_ptr(), alive.data_ptr(), ep_reward.data_ptr(), env.num_envs,
+                                            env._stream())
+        _native.check(rc, "pvder_qagent_step_f32")
+
+    def train_fused(self, episodes: Optional[int] = None) -> Dict[str, List[float]]:
+        """``train`` with TWO launches per env step (the env step + the agent step) and no host
+        synchronisation inside an episode: the episode length is known (max_sim_time / TimeLimit), envs that
+        end early simply stop learning (``alive``).  Exploration draws come from the counter generator of the
+        event tables, keyed (seed, global env id, step count): runs are reproducible."""
+        env = self.env
+        assert not env.auto_reset, "construct the PVDERVec with auto_reset=False: episodes are reset here"
+        assert env.fdtype == torch.float32, "the agent step reads the fp32 output block"
+        N, dev = env.num_envs, env.device
+        episodes = self.train_spec['EPISODES'] if episodes is None else episodes
+        state = torch.zeros(N, dtype=torch.int64, device=dev)
+        action = torch.zeros(N, dtype=torch.uint8, device=dev)
+        alive = torch.zeros(N, dtype=torch.uint8, device=dev)
+        ep_reward = torch.zeros(N, dtype=torch.float64, device=dev)
+        c = env._cfg()                                             # episode length: max_sim_time, TimeLimit
+        steps = -(-c.max_ksub // c.n_sub)
+        if c.max_steps > 0:
+            steps = min(steps, c.max_steps)
+        recent: List[torch.Tensor] = []
+        for episode in range(episodes):
+            env.reset()
+            self.fused_step(state, action, alive, ep_reward, first=True, counter=self._counter)
+            self._counter += 1
+            for _ in range(steps):
+                env.step(action, return_tensors=False)
+                self.fused_step(state, action, alive, ep_reward, first=False, counter=self._counter)
+                self._counter += 1
+            self.update_epsilon()
+            recent.append(ep_reward.clone())
+            if episode % self.train_spec['STATS_EVERY'] == 0:                                           # :113-120
+                block = torch.stack(recent[-self.train_spec['STATS_EVERY']:])
+                self.aggregate_episode_rewards['episode'].append(episode)
+                self.aggregate_episode_rewards['average'].append(float(block.mean()))
+                self.aggregate_episode_rewards['max'].append(float(block.max()))
+                self.aggregate_episode_rewards['min'].append(float(block.min()))
+        return self.aggregate_episode_rewards
+
+    _counter = 0
 
     def train(self, episodes: Optional[int] = None) -> Dict[str, List[float]]:
         """``episodes`` lockstep episodes of all N envs (the env must not auto-reset)."""

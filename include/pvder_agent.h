@@ -1,0 +1,54 @@
+/* pvder_agent.h -- C ABI of the device-resident tabular Q-learning step.
+ *
+ * Replaces the body of the reference's training loop, /root/reference/gym_PVDER/agents/qagent.py:
+ * discretise the observation (get_discrete_state, :43-45), update the table with the transition that just
+ * ended (:83-103), choose the next action epsilon-greedily (:63-68) -- for n_env environments learning into
+ * ONE table in lockstep, in ONE launch per env step next to the step launch of pvder_hip.h; observations,
+ * actions, rewards and the table never leave the GPU and the host never synchronises inside an episode.
+ * Same conventions as pvder_hip.h: plain pointers, a hipStream_t, asynchronous, allocation-free;
+ * 0 / PVDER_EINVAL (-10001) / -hipError_t. */
+#ifndef PVDER_AGENT_H
+#define PVDER_AGENT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pvder_qagent_cfg {
+    int32_t bins;       /* bins per observation dimension (reference: 6, DISCRETE_OS_SIZE :35); bins^11 table rows */
+    int32_t n_act;      /* actions per row (5, PVDER_env.py:50) */
+    int32_t first;      /* 1: first call of an episode -- discretise the reset observation, no table update */
+    int32_t choose;     /* 1: write the next epsilon-greedy action into `action`; 0: leave it to the caller */
+    float lr;           /* LEARNING_RATE (:14) */
+    float gamma;        /* DISCOUNT (:15) */
+    float epsilon;      /* exploration probability of this call (:27, decayed per episode by the caller) */
+    float q_done;       /* value the entry of the transition that ENDS an episode gets (0, :100-103) */
+    double low;         /* observation_space.low (-10, PVDER_env.py:51) */
+    double win;         /* discrete_os_win_size = (high - low) / bins (:38) */
+    uint64_t seed;      /* exploration stream: counter_uniform(seed, global env id, counter, 0, lane) -- the */
+    uint64_t counter;   /*   generator of the event tables; lane 0: explore?, lane 1: which action */
+    int64_t env_id_base;
+} pvder_qagent_cfg;
+
+/* One agent step for n_env envs.
+ *   q_table : device float[bins^11 * n_act], row-major (row = flat index of the 11 bin numbers, first
+ *             observation component most significant -- numpy's ravel_multi_index of the reference's tuple)
+ *   out     : the env's output block [13][n_env] of the step that just ran (rows 0..10 observation, 11 reward,
+ *             12 done), or of the reset (cfg->first)
+ *   state   : int64[n_env] in/out -- table row of the observation the pending action was chosen in
+ *   action  : uint8[n_env] in: the action that led to `out`; out (cfg->choose): the next one
+ *   alive   : uint8[n_env] in/out -- 1 while the env's episode runs (a finished env returns stale tuples,
+ *             PVDER_env.py:145-152, and must not learn from them); cfg->first sets it to 1
+ *   ep_reward : double[n_env] in/out -- return of the running episode (cfg->first zeroes it)
+ * Update rule, per env with alive != 0 (qagent.py:83-103):
+ *   done ? Q[s][a] = q_done : Q[s][a] = (1 - lr) Q[s][a] + lr (r + gamma max_a' Q[s'][a'])
+ * When several envs hit the same entry in one call, one of their updates wins (plain stores). */
+int pvder_qagent_step_f32(const pvder_qagent_cfg *cfg, float *q_table, const float *out, int64_t *state,
+                          uint8_t *action, uint8_t *alive, double *ep_reward, int n_env, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVDER_AGENT_H */

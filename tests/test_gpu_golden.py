@@ -420,3 +420,76 @@ def test_q_agent_update_vs_oracle(gpu_device):
         assert np.allclose(got, row, rtol=2e-6, atol=1e-6), (key, got, row)
     touched = int((agent.q_table != -2.0).any(dim=1).sum())
     assert touched == sum(1 for row in ref.q.values() if (row != -2.0).any())
+
+
+def test_fused_q_agent_step_vs_oracle(gpu_device):
+    """pvder_qagent_step_f32 (discretise + table update + action choice in ONE launch per env step) against the
+    oracle's restatement of qagent.py:43-45, :63-68, :83-103 on the same transitions: table entries, table rows,
+    episode returns, and the epsilon-greedy choice reproduced from the counter generator."""
+    from gym_PVDER_amd.agents import BatchedQAgent
+    from gym_PVDER_amd.vec_env import PVDERVec
+    from oracle.qagent_oracle import OracleQTable
+    from oracle.pvder_model import counter_uniform
+    env = PVDERVec(1, device=gpu_device, n_sim_time_steps_per_env_step=15, max_sim_time=6.0, auto_reset=False, seed=4)
+    agent = BatchedQAgent(env, bins=6, seed=21)
+    ref = OracleQTable(bins=6)
+    state = torch.zeros(1, dtype=torch.int64, device=gpu_device)
+    action = torch.zeros(1, dtype=torch.uint8, device=gpu_device)
+    alive = torch.zeros(1, dtype=torch.uint8, device=gpu_device)
+    ret = torch.zeros(1, dtype=torch.float64, device=gpu_device)
+    counter = 0
+    for episode in range(3):
+        agent.epsilon = [1.0, 0.5, 0.0][episode]                 # all exploration, mixed, all greedy
+        ob = env.reset()
+        agent.fused_step(state, action, alive, ret, first=True, counter=counter)
+        s_ref = ref.discrete(ob[0].cpu().numpy())
+        want_ret, done, steps = 0.0, False, 0
+        while not done:
+            # the action the kernel chose == the reference's rule on the oracle's table with the same draws
+            u0, u1 = counter_uniform(21, 0, counter, 0, 0), counter_uniform(21, 0, counter, 0, 1)
+            a_ref = min(int(np.float32(u1) * np.float32(5)), 4) if np.float32(u0) <= np.float32(agent.epsilon) \
+                else int(np.argmax(ref.q[s_ref]))
+            assert int(action[0]) == a_ref and int(state[0]) == int(np.ravel_multi_index(s_ref, (6,) * 11))
+            counter += 1
+            obs, r, d, _ = env.step(action)
+            a_taken = int(action[0])
+            agent.fused_step(state, action, alive, ret, first=False, counter=counter)
+            s2_ref = ref.discrete(obs[0].cpu().numpy())
+            done = bool(d[0])
+            ref.update(s_ref, a_taken, float(r[0]), s2_ref, done)
+            want_ret += float(r[0])
+            s_ref = s2_ref
+            steps += 1
+        assert steps == 24 and int(alive[0]) == 0 and float(ret[0]) == want_ret
+        # a finished env returns stale tuples: further agent steps must not learn from them
+        before = agent.q_table.clone()
+        env.step(action); agent.fused_step(state, action, alive, ret, first=False, counter=counter + 1000)
+        assert torch.equal(before, agent.q_table) and float(ret[0]) == want_ret
+        agent.update_epsilon(); ref.update_epsilon()
+    for key, row in ref.q.items():
+        got = agent.q_table[int(np.ravel_multi_index(key, (6,) * 11))].cpu().numpy()
+        assert np.allclose(got, row, rtol=2e-6, atol=1e-6), (key, got, row)
+    touched = int((agent.q_table != -2.0).any(dim=1).sum())
+    assert touched == sum(1 for row in ref.q.values() if (row != -2.0).any())
+
+
+def test_fused_q_agent_trains_like_the_torch_loop(gpu_device):
+    """train_fused (two launches per env step, no host synchronisation inside an episode): same bookkeeping as
+    train() -- statistics every 5th episode, epsilon decay, a table that has learnt something -- and a
+    reproducible exploration stream."""
+    from gym_PVDER_amd.agents import BatchedQAgent
+    from gym_PVDER_amd.vec_env import PVDERVec
+    runs = []
+    for rep in range(2):
+        env = PVDERVec(256, device=gpu_device, n_sim_time_steps_per_env_step=60, max_sim_time=8.0, auto_reset=False, seed=4)
+        agent = BatchedQAgent(env, bins=3, seed=1)
+        stats = agent.train_fused(episodes=6)
+        assert stats['episode'] == [0, 5] and agent.epsilon == pytest.approx(0.98 ** 6)
+        assert -5 * 8 <= stats['min'][-1] <= stats['max'][-1] <= 8          # 8 one-second steps, rewards in {-5,-1,+1}
+        assert int((agent.q_table != -2.0).any(dim=1).sum()) >= 1
+        runs.append((stats['average'], stats['min'], stats['max']))
+    # episode 0 explores with epsilon = 1: every action comes from the counter generator -> identical returns; later
+    # episodes read a table in which, of several envs that hit one entry in the same step, one update wins
+    assert runs[0][0][0] == runs[1][0][0] and runs[0][1][0] == runs[1][1][0]
+    a = agent.agent_action(env.obs)
+    assert a.dtype == torch.uint8 and int(a.max()) <= 4

@@ -41,6 +41,11 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for sym in declared:
         assert hasattr(L, sym), sym
+    agent = sorted(set(re.findall(r"\b(pvder_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(os.path.join(
+        ROOT, "include", "pvder_agent.h")).read(), flags=re.S))))
+    assert agent == sorted(_native.AGENT_SYMBOLS)
+    for sym in agent:
+        assert hasattr(L, sym), sym
     assert L.pvder_version() == _native.ABI_VERSION == 8
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
@@ -51,14 +56,16 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     """sizeof/offsetof of the two host structs as gcc sees the header == the ctypes mirrors."""
     from gym_PVDER_amd import _native
     src = tmp_path / "lay.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pvder_hip.h"\nint main(){'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pvder_hip.h"\n#include "pvder_agent.h"\nint main(){'
                    'printf("%zu %zu %zu %zu %zu %zu %d %zu %zu %zu %zu\\n", sizeof(pvder_step_cfg), offsetof(pvder_step_cfg, del_qref),'
                    'offsetof(pvder_step_cfg, atol), sizeof(pvder_event_spec), offsetof(pvder_event_spec, v_min),'
                    'offsetof(pvder_event_spec, s_max), (int)PVDER_PAR_COUNT, sizeof(pvder_autoreset),'
                    'offsetof(pvder_autoreset, seed), offsetof(pvder_autoreset, spec), offsetof(pvder_autoreset, y0));'
                    'printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(pvder_step_cfg, micro_coarse), offsetof(pvder_step_cfg, graded),'
                    'offsetof(pvder_step_cfg, extra_rewards), sizeof(pvder_lin_coef), offsetof(pvder_lin_coef, sched),'
-                   'offsetof(pvder_lin_coef, est_guard));return 0;}')
+                   'offsetof(pvder_lin_coef, est_guard));'
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(pvder_qagent_cfg), offsetof(pvder_qagent_cfg, lr), offsetof(pvder_qagent_cfg, low),'
+                   'offsetof(pvder_qagent_cfg, seed), offsetof(pvder_qagent_cfg, env_id_base));return 0;}')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
@@ -68,6 +75,8 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     assert vals[11:13] == [S.micro_coarse.offset, S.graded.offset]
     Lc = _native.LinCoef
     assert vals[13:17] == [S.extra_rewards.offset, ctypes.sizeof(Lc), Lc.sched.offset, Lc.est_guard.offset]
+    Qc = _native.QAgentCfg
+    assert vals[17:22] == [ctypes.sizeof(Qc), Qc.lr.offset, Qc.low.offset, Qc.seed.offset, Qc.env_id_base.offset]
     from gym_PVDER_amd import der_model
     assert vals[6] == len(der_model.PAR)
 
@@ -155,18 +164,28 @@ def test_no_step_kernel_reads_the_dispatch_packet(tmp_path):
     from gym_PVDER_amd import _native
     path = _native.build_native()
     llvm = "/opt/rocm/lib/llvm/bin"
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "lib.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, fat])
-    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    secs = subprocess.check_output([llvm + "/llvm-readelf", "-SW", co], text=True)
-    m = re.search(r"\.rodata\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", secs)
-    ro_addr, ro_off = int(m.group(1), 16), int(m.group(2), 16)
-    blob = open(co, "rb").read()
-    syms = subprocess.check_output([llvm + "/llvm-readelf", "-sW", co], text=True)
-    kds = [(ln.split()[-1], int(ln.split()[1], 16)) for ln in syms.splitlines() if ln.rstrip().endswith(".kd")]
+    # one offload bundle per .hip source of the library
+    whole = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), whole)]
+    assert starts
+    kds, blobs = [], {}
+    for n, st in enumerate(starts):
+        part, co = str(tmp_path / ("fat%d.bin" % n)), str(tmp_path / ("lib%d.co" % n))
+        open(part, "wb").write(whole[st:starts[n + 1] if n + 1 < len(starts) else len(whole)])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        secs = subprocess.check_output([llvm + "/llvm-readelf", "-SW", co], text=True)
+        m = re.search(r"\.rodata\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", secs)
+        blobs[n] = (open(co, "rb").read(), int(m.group(1), 16), int(m.group(2), 16))
+        syms = subprocess.check_output([llvm + "/llvm-readelf", "-sW", co], text=True)
+        kds += sorted(set((ln.split()[-1], int(ln.split()[1], 16), n) for ln in syms.splitlines()
+                          if ln.rstrip().endswith(".kd")))
     assert len(kds) >= 10
-    for name, addr in kds:
+    for name, addr, n in kds:
+        blob, ro_addr, ro_off = blobs[n]
         kd = blob[ro_off + addr - ro_addr: ro_off + addr - ro_addr + 64]
         private_seg = struct.unpack_from("<I", kd, 4)[0]
         props = struct.unpack_from("<H", kd, 56)[0]          # kernel_code_properties
