@@ -220,6 +220,7 @@ class PVDERVec(EnvSpecMixin):
         n_wg = (num_envs + self._lib.pvder_block_size() - 1) // self._lib.pvder_block_size()
         self.stats = torch.zeros((n_wg * (self._lib.pvder_block_size() // 64), 4), dtype=torch.float32,
                                  device=self.device)           # one slot per wave (include/pvder_hip.h)
+        self._progress = torch.zeros(n_wg, dtype=torch.int32, device=self.device)     # scratch of the fused rollouts
         self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator == "rk45" else None
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
@@ -593,9 +594,6 @@ class PVDERVec(EnvSpecMixin):
             if out is not None and K > 0 and not self.auto_reset:
                 out[0].copy_(self.out)               # stale tuples of finished envs: block k takes them from block k-1
             if fused:
-                if self._progress is None:
-                    self._progress = torch.zeros((self.num_envs + self._lib.pvder_block_size() - 1)
-                                                 // self._lib.pvder_block_size(), dtype=torch.int32, device=self.device)
                 rc = self._lib.pvder_plan_rollout_fused(plan, self.fstate.data_ptr(), self.istate.data_ptr(),
                                                         self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), K,
                                                         dst.data_ptr(), stride, self.stats.data_ptr(),
@@ -609,8 +607,6 @@ class PVDERVec(EnvSpecMixin):
                 _native.check(rc, "pvder_plan_rollout")
             if out is not None and K > 0:
                 self.out.copy_(out[K - 1])
-
-    _progress = None                 # scratch of the fused rollouts (one int32 per workgroup)
 
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,

@@ -422,3 +422,27 @@ def test_fused_rollout_other_goals_and_event_grids(gpu_device, goal, discrete, n
     assert bool(torch.isfinite(rew).all())
     if not discrete:
         assert bool((rew <= 0).all()) and bool((rew < 0).any())          # -(error)^2
+
+
+def test_fused_rollout_is_graph_capturable(gpu_device):
+    """pvder_plan_rollout_fused allocates nothing and never synchronises: a whole K-step rollout captured into
+    ONE HIP graph replays bit-identically to the eager call."""
+    N, K = 2048, 12
+    kw = dict(seed=6, events_spec=both_events_spec(), auto_reset=True, max_sim_time=2.0)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(2)
+    acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    a = make_vec(N, gpu_device, **kw); a.reset()
+    b = make_vec(N, gpu_device, **kw); b.reset()
+    want = torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device)
+    got = torch.empty_like(want)
+    a.rollout(acts, out=want, fused=True)
+    a.rollout(acts, out=want, fused=True)
+    state = b.state_dict()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        b.rollout(acts, out=got, fused=True)
+    b.load_state_dict(state)                           # (capture does not execute)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate)
