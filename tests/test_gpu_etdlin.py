@@ -228,7 +228,8 @@ def _same_env_state(a, b):
             and torch.equal(a.ev_vg, b.ev_vg) and torch.equal(a.ev_si, b.ev_si))
 
 
-@pytest.mark.parametrize("N,K,max_sim_time", [(1024, 12, 2.0), (1000, 23, 2.0), (4096, 40, 40.0), (300, 5, 1.0)])
+@pytest.mark.parametrize("N,K,max_sim_time", [(1024, 12, 2.0), (1000, 23, 2.0), (4096, 40, 40.0), (300, 5, 1.0),
+                                              (8, 20, 1.0), (1, 9, 2.0)])
 def test_fused_rollout_equals_single_steps(gpu_device, N, K, max_sim_time):
     """pvder_plan_rollout_fused (the K env steps inside ONE launch, state in registers from step to step;
     episode ends / auto-resets handed to the per-step body) == K step() calls, bit for bit: per-step output
@@ -238,7 +239,7 @@ def test_fused_rollout_equals_single_steps(gpu_device, N, K, max_sim_time):
               max_sim_time=max_sim_time)
     gen = torch.Generator(device=gpu_device); gen.manual_seed(8)
     acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
-    acts[K // 2, 7] = 9                              # invalid action: no-op, counted
+    acts[K // 2, min(7, N - 1)] = 9                  # invalid action: no-op, counted
     a = make_vec(N, gpu_device, **kw); a.reset()
     b = make_vec(N, gpu_device, **kw); b.reset()
     singles = []
