@@ -13,6 +13,7 @@ fused launch, no separate code path.
 from __future__ import annotations
 
 import logging
+import pprint
 import time
 from types import SimpleNamespace
 
@@ -266,3 +267,105 @@ class PVDER(EnvSpecMixin):
 
     def show_step_time(self):
         print('Time for step:{:.3f}'.format(self._step_time))
+
+    # -- the rest of the reference's public helper surface: statistics of the running episode
+    #    (env_utilities.py:12-101) and the configuration / evaluation printers (PVDER_env.py:445-529) -----------
+    pp = pprint.PrettyPrinter(indent=4)                              # env_utilities.py:10
+
+    env_goal_spec = property(lambda s: s._vec.env_goal_spec)
+    env_reward_spec = property(lambda s: s._vec.env_reward_spec)
+
+    def initialize_stats(self):                                      # env_utilities.py:12-23
+        self._action_stats = {i: 0 for i in range(5)}
+        self._reward_stats = {'step': [], 'reward': []}
+        self._time_stats = {'step': [], 'step_time': []}
+
+    def update_action_stats(self, action):                           # :25-30
+        self._action_stats[action] = self._action_stats[action] + 1
+
+    def update_reward_stats(self):                                   # :32-38
+        self._reward_stats['step'].append(self.steps)
+        self._reward_stats['reward'].append(self._reward)
+
+    def update_time_stats(self):                                     # :40-46
+        self._time_stats['step'].append(self.steps)
+        self._time_stats['step_time'].append(self._step_time)
+
+    def _plot(self, x, y, color, xlabel, ylabel, title, bar=False, ticks=None):
+        import matplotlib.pyplot as plt
+        if bar:
+            plt.bar(x, y, color=color)
+            plt.xticks(x, ticks)
+        else:
+            plt.plot(x, y, color=color)
+        plt.xlabel(xlabel); plt.ylabel(ylabel); plt.title(title)
+        plt.show()
+
+    def show_action_stats(self, SHOW_PLOT=False):                    # :59-75
+        self.pp.pprint(self._action_stats)
+        if SHOW_PLOT:
+            keys = list(self._action_stats.keys())
+            self._plot(list(range(len(keys))), list(self._action_stats.values()), 'green', "Actions", "Count",
+                       "Action totals after every episode.", bar=True, ticks=keys)
+
+    def show_reward_stats(self, SHOW_PLOT=False):                    # :77-88
+        if SHOW_PLOT:
+            self._plot(self._reward_stats['step'], self._reward_stats['reward'], 'red', "Steps", "Reward", "Reward per step")
+        else:
+            self.pp.pprint(self._reward_stats)
+
+    def show_time_stats(self, SHOW_PLOT=False):                      # :90-101
+        if SHOW_PLOT:
+            self._plot(self._time_stats['step'], self._time_stats['step_time'], 'blue', "Steps", "Time (s)", "Time per step")
+        else:
+            self.pp.pprint(self._time_stats)
+
+    def update_env_goal(self, goal_type=None, goal_spec=None):       # PVDER_env.py:445-456
+        if goal_type is None and goal_spec is None:
+            for g in self._vec.env_goal_spec:
+                self._vec.env_goal_spec[g]['reward']['my_spec'] = self._vec.env_goal_spec[g]['reward']['required']
+                self._vec.env_goal_spec[g]['action']['my_spec'] = self._vec.env_goal_spec[g]['action']['required']
+            self._vec._drop_plan()
+        else:
+            assert goal_type in self._vec.env_goal_spec, '{} is not a valid goal!'.format(goal_type)
+            print('Update function is under construction!')             # :456
+
+    def show_env_config(self):                                       # :499-504
+        print('Environment name:{}'.format(self.name))
+        self.show_goal_config()
+        self.show_sim_config()
+
+    def show_sim_config(self):                                       # :506-510
+        v = self._vec
+        print('time step:{:.4f},del Qref:{:.2f},del Vdcref:{:.2f}'.format(v._sim_time_per_env_step, v._delQref, v._delVdcref))
+        print('Voltage events:{},Insolation events:{}'.format(self.env_events_spec['voltage']['ENABLE'],
+                                                              self.env_events_spec['insolation']['ENABLE']))
+
+    def show_goal_config(self):                                      # :512-524
+        goal_type = self.goals_list[0]
+        spec = self._vec.env_goal_spec[goal_type]
+        print('Goal type:', goal_type)
+        print('Reward type:{},Discrete:{}'.format(spec['reward'].get('my_spec', spec['reward']['required']), self.DISCRETE_REWARD))
+        if goal_type == 'Q_regulation':
+            print('Q reference:{}'.format(self._vec.env_reward_spec['reference_values']['Q_ref']))
+        elif goal_type == 'power_regulation':
+            print('P reference:{}'.format(self._vec.env_reward_spec['reference_values']['P_ref']))
+        print('Action type:', spec['action'].get('my_spec', spec['action']['required']))
+
+    def calc_returns(self, episodes=2):                              # :458-497
+        """Average return per goal and fixed action policy (``env_average_return``): the reference loops
+        3 goals x 4 policies x 2 episodes of its one env; here each (goal, policy) cell is one fused
+        open-loop rollout of ``episodes`` envs on the device (gym_PVDER_amd/evaluate.py), with this env's
+        step size, episode length, reward type, integrator and event spec."""
+        from ..evaluate import calc_returns as batched
+        v = self._vec
+        kw = dict(n_sim_time_steps_per_env_step=v.n_sim_time_steps_per_env_step, max_sim_time=self.max_sim_time_user,
+                  DISCRETE_REWARD=v.DISCRETE_REWARD, integrator=v.integrator, events_spec=v.env_events_spec)
+        for goal in v.env_goal_spec:
+            print('Calculating average return for "{}" goal with "random", "inc", "dec", "no_change" actions.'.format(goal))
+        self.env_average_return = batched(episodes=episodes, device=v.device, seed=v.seed, **kw)
+        self.show_env_returns()
+        return self.env_average_return
+
+    def show_env_returns(self):                                      # :526-529
+        self.pp.pprint(self.env_average_return)

@@ -493,3 +493,42 @@ def test_fused_q_agent_trains_like_the_torch_loop(gpu_device):
     assert runs[0][0][0] == runs[1][0][0] and runs[0][1][0] == runs[1][1][0]
     a = agent.agent_action(env.obs)
     assert a.dtype == torch.uint8 and int(a.max()) <= 4
+
+
+def test_reference_helper_surface_of_the_single_env(gpu_device, capsys):
+    """The rest of the reference env's public surface: episode statistics and their printers
+    (env_utilities.py:12-101), the configuration printers, update_env_goal and calc_returns as METHODS of the env
+    (PVDER_env.py:445-529) -- same names, same printed lines, same result table."""
+    import gym_PVDER_amd as gp
+    env = gp.make('PVDER-v0', max_sim_time=2.0, device=gpu_device)
+    env.reset()
+    for a in (1, 1, 3, 0):
+        env.step(a)
+    assert env._action_stats == {0: 1, 1: 2, 2: 0, 3: 1, 4: 0}
+    assert env._reward_stats['step'] == [1, 2, 3, 4] and len(env._time_stats['step_time']) == 4
+    env.show_action_stats(); env.show_reward_stats(); env.show_time_stats(); env.show_step_time()
+    env.show_env_config()
+    out = capsys.readouterr().out
+    assert 'Environment name:GymDER_' in out and 'Goal type: voltage_regulation' in out
+    assert "Reward type:['voltage_error'],Discrete:True" in out
+    assert 'time step:0.2500,del Qref:375.00,del Vdcref:0.30' in out               # :508 with n = 15 (:616-618)
+    assert 'Voltage events:True,Insolation events:False' in out                     # :60-61 defaults
+    assert 'Time for step:' in out
+    env.initialize_stats()
+    assert env._action_stats == {i: 0 for i in range(5)} and env._reward_stats == {'step': [], 'reward': []}
+    env.update_action_stats(2); env.update_reward_stats(); env.update_time_stats()
+    assert env._action_stats[2] == 1 and env._reward_stats['step'] == [4] and env._time_stats['step'] == [4]
+    env.update_env_goal(None, None)
+    assert env.env_goal_spec['power_regulation']['reward']['my_spec'] == env.env_goal_spec['power_regulation']['reward']['required']
+    env.update_env_goal('Q_regulation', {'Q_regulation': {}})
+    assert 'under construction' in capsys.readouterr().out                          # :456
+    table = env.calc_returns()
+    assert table is env.env_average_return
+    assert sorted(table) == ['Q_regulation', 'power_regulation', 'voltage_regulation']
+    for goal, row in table.items():
+        assert sorted(row) == ['dec', 'inc', 'no_change', 'random']
+        for cell in row.values():
+            assert -5 * 8 <= cell['return'] <= 8 and len(cell['ref']) == 2          # 8 steps of 0.25 s, rewards in {-5,-1,+1}
+    # 'dec' sends action 1 (+Q_ref, the reference's labels :482-487): 8 steps x 375 VAR
+    assert table['voltage_regulation']['dec']['ref'][1] == pytest.approx(8 * 375.0, rel=1e-5)
+    assert "'return'" in capsys.readouterr().out                                    # show_env_returns printed the table
