@@ -70,6 +70,49 @@ class BatchedQAgent:
         new_q = torch.where(done, torch.zeros_like(new_q), new_q)                                   # :100-103
         self.q_table.index_put_((s[alive], a[alive]), new_q[alive])
 
+    # -- the reference's agent utilities (agents/agent_utilities.py:15-84), batched ---------------------------
+    def initialize_aggregate_rewards(self):                          # :15-27 (keys as in train()'s statistics)
+        self.aggregate_episode_rewards = {'episode': [], 'average': [], 'max': [], 'min': []}
+
+    def collect_aggregate_rewards(self, episode, **reward_stats):    # :29-40
+        print('Storing rewards @ Episode:{},Steps:{}'.format(episode, int(self.env.istate[1].max())))
+        self.aggregate_episode_rewards['episode'].append(episode)
+        for stat_type, value in reward_stats.items():
+            if stat_type in self.aggregate_episode_rewards:
+                self.aggregate_episode_rewards[stat_type].append(value)
+                print(stat_type, ':', value)
+
+    def show_plots(self, show: bool = True):                         # :50-63
+        import matplotlib.pyplot as plt
+        fig, ax = plt.subplots()
+        for stat_type in ('average', 'max', 'min'):
+            ax.plot(self.aggregate_episode_rewards['episode'], self.aggregate_episode_rewards[stat_type], label=stat_type)
+        ax.legend(loc=4)
+        if show:
+            plt.show()
+        return fig
+
+    def evaluate(self, n_episodes: int = 1) -> List[float]:          # :65-77
+        """Greedy episodes of all N envs (``agent_action`` on every step); returns and prints the mean episode
+        return of each (the reference prints every step of its one env and renders it)."""
+        env = self.env
+        assert not env.auto_reset, "construct the PVDERVec with auto_reset=False: episodes are reset here"
+        means = []
+        for i in range(n_episodes):
+            obs = env.reset()
+            ret = torch.zeros(env.num_envs, dtype=torch.float64, device=env.device)
+            alive = torch.ones(env.num_envs, dtype=torch.bool, device=env.device)
+            for _ in range(env.max_episode_steps + 1):
+                obs, r, done, _ = env.step(self.agent_action(obs))
+                ret += torch.where(alive, r.to(torch.float64), torch.zeros_like(ret))
+                alive = alive & ~done
+                if not bool(alive.any()):
+                    break
+            means.append(float(ret.mean()))
+            print('Episode:{},Steps:{},mean return:{:.3f},min:{:.1f},max:{:.1f}'.format(
+                i, int(env.istate[1].max()), means[-1], float(ret.min()), float(ret.max())))
+        return means
+
     # -- the same loop with the agent side as ONE HIP launch per env step (include/pvder_agent.h) ------------
     def _agent_cfg(self, first: bool, choose: bool, counter: int) -> "_native.QAgentCfg":
         c = _native.QAgentCfg()

@@ -493,6 +493,15 @@ def test_fused_q_agent_trains_like_the_torch_loop(gpu_device):
     assert runs[0][0][0] == runs[1][0][0] and runs[0][1][0] == runs[1][1][0]
     a = agent.agent_action(env.obs)
     assert a.dtype == torch.uint8 and int(a.max()) <= 4
+    # the reference's agent utilities (agent_utilities.py): greedy evaluation, statistics bookkeeping, plot
+    means = agent.evaluate(n_episodes=2)
+    assert len(means) == 2 and all(-5 * 8 <= m <= 8 for m in means)
+    agent.initialize_aggregate_rewards()
+    agent.collect_aggregate_rewards(3, average=1.0, min=-2.0, max=4.0)
+    assert agent.aggregate_episode_rewards == {'episode': [3], 'average': [1.0], 'max': [4.0], 'min': [-2.0]}
+    import matplotlib
+    matplotlib.use("Agg")
+    assert agent.show_plots(show=False) is not None
 
 
 def test_reference_helper_surface_of_the_single_env(gpu_device, capsys):
