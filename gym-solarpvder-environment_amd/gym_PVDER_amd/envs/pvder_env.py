@@ -126,6 +126,8 @@ class PVDER(EnvSpecMixin):
         if record_trajectory:      # the reference always keeps the solution rows (self.results, :389)
             self._vec.record_trajectory(self._vec.max_episode_steps + 1)
         self.env_events_spec = self._vec.env_events_spec
+        self.env_goal_spec = self._vec.env_goal_spec          # the instance's own copy (the class keeps the defaults)
+        self.env_reward_spec = self._vec.env_reward_spec
         self._reward = 0
         self.done = False
         self._step_time = 0.0
@@ -270,10 +272,7 @@ class PVDER(EnvSpecMixin):
 
     # -- the rest of the reference's public helper surface: statistics of the running episode
     #    (env_utilities.py:12-101) and the configuration / evaluation printers (PVDER_env.py:445-529) -----------
-    pp = pprint.PrettyPrinter(indent=4)                              # env_utilities.py:10
-
-    env_goal_spec = property(lambda s: s._vec.env_goal_spec)
-    env_reward_spec = property(lambda s: s._vec.env_reward_spec)
+    pp = property(lambda self: pprint.PrettyPrinter(indent=4))       # env_utilities.py:10 (bound to the stdout of the call)
 
     def initialize_stats(self):                                      # env_utilities.py:12-23
         self._action_stats = {i: 0 for i in range(5)}
