@@ -85,6 +85,7 @@ constexpr int kDeferred = -1; // transient istate status (single-phase ETDRK4 on
 template <typename T>
 struct StepK {
     int n_sub, micro, micro2, graded, max_ksub, max_steps, goal, discrete, ev_s0, ev_ds, ev_count, max_it, extra;
+    int off_range;          // pvder_step_cfg.off_range: 1 = an env that needs the RK4 fallback ends its episode instead
     T dq, dv, inv_tmax, p_t, q_t, rtol, atol;
 };
 
@@ -209,6 +210,7 @@ struct Lane {
     int ksub, steps, status;
     T qref, vdcref;
     float bad_action;
+    bool fail;              // left the range the fast integrators cover and cfg->off_range says: end the episode
 };
 
 // State rows are read once and result rows written once per launch: non-temporal accesses keep them
@@ -246,6 +248,7 @@ __device__ __forceinline__ void prologue(const StepK<T> &C, const T *__restrict_
     // finished envs (status 1/2) return the stale tuple (:145-152).  run_status = kDeferred selects
     // the envs a preceding fast-path kernel handed over to this launch.
     L.run = L.live && L.status == run_status;
+    L.fail = false;
     if (L.run) L.status = 0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) y[k] = ld(&fstate[(size_t)k * N + L.ec]);
@@ -307,7 +310,7 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
     for (int q = 0; q < NS; ++q) chk += fabs(y[q]);
     float nonfinite = 0.f, done_f = 0.f;
     if (L.run) {
-        if (!(chk < (T)1e30)) {                    // NaN/Inf: CONVERGENCE_FAILURE branch (:169-172)
+        if (!(chk < (T)1e30) || L.fail) {          // NaN/Inf (or off range, by request): CONVERGENCE_FAILURE branch (:169-172)
             L.status = 2; reward = (T)-100; nonfinite = 1.f;
         } else if (L.ksub >= C.max_ksub || (C.max_steps > 0 && L.steps >= C.max_steps)) {
             L.status = 1;                          // tStop >= max_sim_time (:183) / TimeLimit
@@ -801,9 +804,12 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                 for (int q = 0; q < 3; ++q)                                            // x_p candidate
                     yt[SL[q]] = pvder::fma2(h23, nsl[q], pvder::fma2(h6, k14[q], y[SL[q]]));
                 const float m2b = max_m2(P, yt);
-                if (fmaxf(m2a, m2b) > guard) {
+                if (fmaxf(m2a, m2b) > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) {
+                    L.fail = true;                 // the episode ends here (epilogue); the state no longer matters
+                } else if (fmaxf(m2a, m2b) > guard) {
                     // duty cycle near its limit: anti-windup may switch the fast dynamics -> redo
-                    // this step with classic RK4 micro-steps (rare; PVDER-v0 episodes never get here)
+                    // this step with classic RK4 micro-steps (random-action PVDER-v0 episodes never get here; a
+                    // policy that walks Vdc_ref down 6 % does: ~4000 x 686 instructions per sim time step)
                     rk4_pk_steps(P, K, S, y, comp, rk4_sub, h / (float)rk4_sub, t0, tq / (float)rk4_sub,
                                  L.qref, L.vdcref);
                 } else {
@@ -1056,7 +1062,9 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
         }
     }
     PVDER_TRACE_AT(20);
-    if (defer) {
+    if (PH == 1 && defer && C.off_range == PVDER_OFF_RANGE_TERMINATE) {
+        L.fail = L.run;     // single phase: the hand-over would be classic RK4 for the whole env step -- the episode ends instead
+    } else if (defer) {
         // hand the env over untouched: nothing stored, nothing added to the stats
         if constexpr (PH == 1) istate[PVDER_I_STATUS * N + L.e] = kDeferred;     // marker for the follow-up launch
         L.run = false;
@@ -1423,7 +1431,9 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     KernargPtr ka = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
     PVDER_LAUNDER_EPI(ka);
     const EtdArgs &E = *(const EtdArgs *)ka;
-    if (defer) {
+    if (PH == 1 && defer && E.C.off_range == PVDER_OFF_RANGE_TERMINATE) {
+        L.fail = L.run;     // single phase: the hand-over would be classic RK4 for the whole env step -- the episode ends instead
+    } else if (defer) {
         if constexpr (PH == 1) E.istate[PVDER_I_STATUS * (size_t)E.n_env + L.e] = kDeferred;   // marker for the follow-up launch
         L.run = false;
         L.live = false;
@@ -1878,6 +1888,7 @@ StepK<T> fold_cfg(const pvder_step_cfg *c) {
     C.ev_count = c->ev_count;
     C.max_it = c->reserved > 0 ? c->reserved : 20000000;   // RK45: attempts per sim time step
     C.extra = c->extra_rewards;
+    C.off_range = c->off_range;
     C.dq = (T)c->del_qref; C.dv = (T)c->del_vdcref; C.inv_tmax = (T)c->inv_max_sim_time;
     C.p_t = (T)c->p_target; C.q_t = (T)c->q_target; C.rtol = (T)c->rtol; C.atol = (T)c->atol;
     return C;

@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -43,7 +43,7 @@ class StepCfg(C.Structure):
                 ("reserved", C.c_int32), ("del_qref", C.c_double), ("del_vdcref", C.c_double),
                 ("inv_max_sim_time", C.c_double), ("p_target", C.c_double), ("q_target", C.c_double),
                 ("rtol", C.c_double), ("atol", C.c_double), ("micro_coarse", C.c_int32), ("graded", C.c_int32),
-                ("extra_rewards", C.c_int32), ("pad_", C.c_int32)]
+                ("extra_rewards", C.c_int32), ("off_range", C.c_int32)]
 
 
 class EventSpec(C.Structure):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 8
+#define PVDER_ABI_VERSION 9
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -111,9 +111,19 @@ typedef struct pvder_step_cfg {
     int32_t extra_rewards; /* reward types of env_goal_spec[goal]['reward']['my_spec'] beyond the goal's
                              required one (:249): PVDER_REWARD_VDC_ERROR adds the Vdc_error term
                              (:251-262; power_regulation only, as its target is defined at :243-245) */
-    int32_t pad_;
+    int32_t off_range;    /* what happens to an env that leaves the range the fast fp32 integrators cover -- duty
+                             cycle |m| at its limit or current reference at the overload limit, where the
+                             reference model's component-wise anti-windup switches the stiff dynamics:
+                             PVDER_OFF_RANGE_INTEGRATE (0, default): it is integrated through, as the reference
+                             does, by classic RK4 micro-steps -- correct, and ~50 ms per env step for the whole
+                             launch while ONE env is there;  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
+                             (status 2, done, reward -100: the reference's failure branch, :169-172) -- for
+                             training runs that must not stall on a saturated converter.  fp32 exponential
+                             integrators only (etdlin, ETDRK4). */
 } pvder_step_cfg;
 #define PVDER_REWARD_VDC_ERROR 1
+#define PVDER_OFF_RANGE_INTEGRATE 0
+#define PVDER_OFF_RANGE_TERMINATE 1
 
 /* ---- event generator spec for reset (PVDER_env.py:60-61, :400-411) */
 typedef struct pvder_event_spec {

@@ -371,3 +371,60 @@ def test_direct_rccl_all_gather_world1(gpu_device):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_off_range_policy(gpu_device):
+    """An env driven out of the range the fast integrators cover (Vdc_ref walked down 6 %: the duty cycle reaches
+    its limit and the reference model's anti-windup switches the stiff dynamics).  Default ('integrate'): it is
+    integrated through by classic RK4 micro-steps, like the reference -- against the fp64 bridge; 'terminate': its
+    episode ends there (done, reward -100, counted), the other envs of the batch never notice, and with auto-reset
+    it starts over."""
+    import time
+    N, n_sub = 128, 15
+    down = torch.full((N,), 4, dtype=torch.uint8, device=gpu_device)
+    down[64:] = 0                                          # envs 64.. hold their references: they stay in range
+    # (a) terminate
+    env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, seed=2, auto_reset=False, off_range="terminate")
+    env.reset()
+    done_at = torch.full((N,), -1, dtype=torch.long, device=gpu_device)
+    rew_at = torch.zeros(N, dtype=torch.float32, device=gpu_device)
+    for t in range(150):
+        obs, rew, done, _ = env.step(down)
+        new = done & (done_at < 0)
+        done_at = torch.where(new, torch.full_like(done_at, t), done_at)
+        rew_at = torch.where(new, rew, rew_at)
+    # each env on its own voltage events: they reach the limit within a few steps of each other
+    assert bool((done_at[:64] >= 60).all()) and bool((done_at[:64] <= 140).all()), done_at[:64]     # Vdc_ref ~ -4..-8 %
+    assert bool((rew_at[:64] == -100.0).all()) and bool((done_at[64:] < 0).all())
+    first_done = int(done_at[0])                          # env 0 (global id 0, seed 2: the env of part (b))
+    assert bool((env.istate[3, :64] == 2).all()) and bool((env.istate[3, 64:] == 0).all())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        env.step(down, return_tensors=False)
+    torch.cuda.synchronize()
+    assert (time.perf_counter() - t0) / 20 < 2e-3                                 # no 50 ms stalls
+    # with auto-reset the terminated envs start over (episode counter) and the batch keeps its pace
+    env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, seed=2, auto_reset=True, off_range="terminate")
+    env.reset()
+    for t in range(150):
+        env.step(down, return_tensors=False)
+    assert bool((env.istate[2, :64] >= 2).all()) and bool((env.istate[2, 64:] == 1).all())
+    # (b) integrate (default): the same drive, a few steps into the saturated regime, against the converged bridge
+    env = make_vec(1, gpu_device, n_sim_time_steps_per_env_step=n_sub, seed=2, auto_reset=False)
+    env.reset()
+    ref = BridgeVecEnv(1, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11)
+    ref.reset(env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64),
+              ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+    a4 = torch.full((1,), 4, dtype=torch.uint8, device=gpu_device)
+    got, want = [], []
+    for t in range(first_done + 3):
+        obs, rew, done, _ = env.step(a4)
+        o2, r2, d2 = ref.step(np.full(1, 4))
+        got.append(obs.cpu().numpy().astype(np.float64)); want.append(o2)
+    assert not bool(done.any()) and env.step_stats()["n_nonfinite"] == 0
+    got, want = np.stack(got), np.stack(want)
+    err = rel_l2(got.reshape(1, -1), want.reshape(1, -1), axis=1)
+    assert err.max() < FP32_TOL, err.max()
+    tail = rel_l2(got[-3:].reshape(1, -1), want[-3:].reshape(1, -1), axis=1)      # the steps inside the saturated regime
+    assert tail.max() < FP32_TOL, tail.max()
