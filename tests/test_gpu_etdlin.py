@@ -447,3 +447,28 @@ def test_fused_rollout_is_graph_capturable(gpu_device):
     g.replay(); g.replay()
     torch.cuda.synchronize()
     assert torch.equal(got, want) and torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate)
+
+
+def test_reactive_power_ramp_far_beyond_the_nominal_point(gpu_device):
+    """The reference's own evaluation driver sends ONE action for a whole episode (calc_returns, PVDER_env.py:480-487):
+    action 2 walks Q_ref to -1 pu -- past the range of the linearisation (hand-over to the 23-state ETDRK4 tail at
+    |Q_ref| ~ 0.8 pu) and into the current limit of the inverter.  Trajectory against the converged fp64 bridge: inside
+    the parity bar as a whole, and no single env step further off than 3e-4."""
+    steps = 135
+    env = make_vec(1, gpu_device, seed=1, auto_reset=False)
+    assert env.integrator == "etdlin" and env.micro_coarse == 2          # (two steps per quiet sim time step in the tail)
+    env.reset()
+    ref = BridgeVecEnv(1, n=15, method="rk45", rtol=1e-8, atol=1e-11)
+    ref.reset(env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64),
+              ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+    a = torch.full((1,), 2, dtype=torch.uint8, device=gpu_device)
+    got, want = [], []
+    for t in range(steps):
+        obs, rew, done, _ = env.step(a)
+        got.append(obs.cpu().numpy().astype(np.float64)[0]); want.append(ref.step(np.full(1, 2))[0][0])
+    got, want = np.stack(got), np.stack(want)
+    assert float(env.Q_ref[0]) == pytest.approx(-steps * 0.0075, rel=1e-5) and env.step_stats()["n_nonfinite"] == 0
+    per_step = rel_l2(got, want, axis=1)
+    assert per_step[:100].max() < TIGHT * 1.5, per_step[:100].max()      # the fast path, up to |Q_ref| = 0.75 pu
+    assert per_step.max() < 3e-4, (int(per_step.argmax()), per_step.max())
+    assert rel_l2(got.reshape(-1), want.reshape(-1)) < FP32_TOL
