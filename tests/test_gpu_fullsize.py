@@ -75,3 +75,22 @@ def test_configs4_fp64_rk45_full_size_vs_converged_bridge(gpu_device):
     """BASELINE configs[4]: 65 536 envs, fp64 adaptive RK45 (tolerance-match run); rel-L2 bar 1e-4
     (north_star), measured far below."""
     run_and_compare(gpu_device, "rk45", steps=2, tol=2e-6, seed=32, rtol=1e-7, atol=1e-9)
+
+
+def test_configs2_full_size_fused_rollout_is_bit_identical_to_single_launches(gpu_device):
+    """65 536 envs x 400 env steps (two auto-resets of every env inside): the fused rollouts against one launch
+    per env step -- every output block, the final state, counters, event tables and statistics, bit for bit."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    K = 200
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(77)
+    a = PVDERVec(N, device=gpu_device, seed=9, events_spec=both_events_spec(), auto_reset=True); a.reset()
+    b = PVDERVec(N, device=gpu_device, seed=9, events_spec=both_events_spec(), auto_reset=True); b.reset()
+    ba = torch.empty((K, 13, N), device=gpu_device); bb = torch.empty((K, 13, N), device=gpu_device)
+    for r in range(2):
+        acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+        a.rollout(acts, out=ba, fused=False)
+        b.rollout(acts, out=bb, fused=True)
+        assert torch.equal(ba, bb)
+        assert torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate) and torch.equal(a.ev_vg, b.ev_vg)
+        assert a.step_stats() == b.step_stats()
+    assert int(a.istate[2].min()) >= 3                      # episodes started: every env was reset twice in flight
