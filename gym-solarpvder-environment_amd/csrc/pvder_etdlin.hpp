@@ -25,17 +25,23 @@ constexpr int kLinRows = 12;              // matrix padded to 12 x 12 (three row
 constexpr int kLinMatFloats = kLinRows * kLinRows;       // 144: row-major, row i = 12 floats (columns 0..10 + pad)
 constexpr int kLinMats = 6;               // M21 | M31 M32 | M41 M42 M43
 constexpr int kLinSetFloats = kLinMats * kLinMatFloats;  // 864 floats = 3456 B per step size
-constexpr int kLinMaxSets = 8;
+constexpr int kLinMaxSets = 12;
 enum { LM21 = 0, LM31, LM32, LM41, LM42, LM43 };
 
 // Full right-hand side of the balanced 11-state model as six pairs (the state layout of the lin
 // path): F[0] = di, F[1] = dx, F[2] = du, F[3] = (dVdc, dxDC), F[4] = (dxQ, dxPLL), F[5] = (ddelta, 0).
-// Same equations as pvder_model.hpp::rhs for balanced phases, without the anti-windup branches
-// (the caller defers envs whose |m| / |iref| come near a limit: m2 = |m_a|^2, ir2 = |iref_a|^2).
-template <int PH>
+// Same equations as pvder_model.hpp::rhs for balanced phases, without the duty-cycle anti-windup (component-wise
+// per phase, not rotation invariant: the caller hands envs whose |m| comes near its limit to the 23-state path;
+// m2 = |m_a|^2, ir2 = |iref_a|^2).
+// AW = true (the "careful" pass for envs at the CURRENT limit, lin_integrate_careful): the conditional integration
+// of the outer PI loops -- rotation invariant, iref_a is common to the phases -- in the form the hybrid steps need:
+// an outer integrator that moves outward (derivative and state of one sign: the component the reference model
+// freezes while |iref| > iref_limit) advances at `alpha` times its rate; alpha = 1 free, 0 frozen, in between the
+// fraction of the step spent free.  alpha < 0: decided here, frozen iff |iref| > iref_limit at this state.
+template <int PH, bool AW = false>
 __device__ __forceinline__ void bal_f(const ModelK<float> &P, const PkConst &K, const SubPk &S, const v2 *__restrict__ y,
                                       float qref, float vdcref, v2 kpo, v2 kio, v2 *__restrict__ F, float &m2,
-                                      float &ir2) {
+                                      float &ir2, float alpha = 1.f) {
     const v2 ia = y[0], xa = y[1], ua = y[2];
     const float Vdc = y[3].x, xPLL = y[4].y, delta = y[5].x;
     const v2 ma = fma2(bc2(P.KpG), ua, xa);
@@ -45,8 +51,13 @@ __device__ __forceinline__ void bal_f(const ModelK<float> &P, const PkConst &K, 
     // outer loops, packed: e = (Vdc_ref - Vdc, Q_ref - Q); iref_a = (xDC, xQ) + (Kp_DC, -Kp_Q) e
     const v2 e = mk2(vdcref - Vdc, qref - Q);
     const v2 iar = fma2(kpo, e, mk2(y[3].y, y[4].x));
-    const v2 dpi = kio * e;                                               // (dxDC, dxQ)
+    v2 dpi = kio * e;                                                     // (dxDC, dxQ)
     ir2 = __builtin_fmaf(iar.y, iar.y, iar.x * iar.x);
+    if constexpr (AW) {
+        if (alpha < 0.f) alpha = ir2 > P.ilim2 ? 0.f : 1.f;
+        dpi.x = dpi.x * y[3].y > 0.f ? alpha * dpi.x : dpi.x;
+        dpi.y = dpi.y * y[4].x > 0.f ? alpha * dpi.y : dpi.y;
+    }
     float s1, c1;
     Math<float>::sincos_turns(delta * (float)(1.0 / kTwoPi), s1, c1);
     v2 V1 = fma2(bc2(P.kviR), ia, S.A0);
@@ -153,6 +164,16 @@ __device__ __forceinline__ void lin_mfma1(const LinMatRegs &A, const v2 *__restr
     lin_mfma1_pair<0>(A, f, acc, hi);
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] += hi[g];
+}
+// |iref_a|^2 at a state in accumulator layout (the limit function of the careful pass, s = |iref|^2 - iref_limit^2,
+// at the END of a step; at its start and middle bal_f reports it)
+template <int PH>
+__device__ __forceinline__ float lin_iref2(const PkConst &K, const SubPk &S, const v4f (&Y)[3], float qref, float vdcref, v2 kpo) {
+    const v2 ia = mk2(Y[0].x, Y[0].y);
+    const v2 tq = fma2(bc2((float)PH * K.qk), ia, bc2(0.5f * PH) * S.Asw[0]);
+    const float Q = __builtin_fmaf(tq.y, ia.y, tq.x * ia.x);
+    const v2 iar = fma2(kpo, mk2(vdcref - Y[1].z, qref - Q), mk2(Y[1].w, Y[2].x));
+    return __builtin_fmaf(iar.y, iar.y, iar.x * iar.x);
 }
 // state in accumulator layout (rows 0-3, 4-7, 8-11) -> the six pairs bal_f reads
 __device__ __forceinline__ void lin_pairs(const v4f (&Y)[3], v2 *__restrict__ y) {

@@ -175,29 +175,47 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 template <typename T>
 __device__ __forceinline__ T ladder(T err, T lo, T hi) { return err <= lo ? (T)1 : (err >= hi ? (T)-5 : (T)-1); }
 
+// one reward type of reward_calc (PVDER_env.py:249-299): the +1 / -1 / -5 ladder or the negative squared error
+enum { kRewVoltage = 0, kRewPower, kRewQ, kRewVdc };
 template <typename T>
-__device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T vrms, T Ppcc, T Qpcc, T Vdc, T vdcref) {
+__device__ __forceinline__ T reward_term(int type, const StepK<T> &C, const ModelK<T> &P, T vrms, T Ppcc, T Qpcc, T Vdc,
+                                         T vdcref, T qref) {
 #pragma clang fp contract(off)       // (the same bits in every kernel: see pvder::outputs)
-    // PVDER_env.py:231-301 -- the goal's 'required' term (:78-93 via :448-452) ...
-    T err, lo, hi, cont;
-    if (C.goal == PVDER_GOAL_VOLTAGE) {            // voltage_error :276-287
+    T err, lo = (T)0.01, hi = (T)0.05, cont;
+    if (type == kRewVoltage) {                     // voltage_error :276-287
         const T d = vrms - P.vrms_ref;
-        err = fabs(d) / fabs(P.vrms_ref); lo = (T)0.01; hi = (T)0.05; cont = -(d * d);
-    } else if (C.goal == PVDER_GOAL_POWER) {       // power_error :290-299
+        err = fabs(d) / fabs(P.vrms_ref); cont = -(d * d);
+    } else if (type == kRewPower) {                // power_error :290-299
         const T d = Ppcc - C.p_t;
-        err = fabs(d) / C.p_t; lo = (T)0.01; hi = (T)0.03; cont = -(d * d);
-    } else {                                       // Q_error :263-275
-        T qt = C.q_t;
+        err = fabs(d) / C.p_t; hi = (T)0.03; cont = -(d * d);
+    } else if (type == kRewQ) {                    // Q_error :263-275
+        // Qtarget = PV_model.Q_ref under voltage_regulation (:238), the spec's Q_ref / Sbase otherwise (:241)
+        T qt = C.goal == PVDER_GOAL_VOLTAGE ? qref : C.q_t;
         const T d = Qpcc - qt;
         cont = -(d * d);
         if (qt == (T)0) qt = (T)1e-6;              // :266-267 (discrete branch only)
-        err = fabs(Qpcc - qt) / fabs(qt); lo = (T)0.01; hi = (T)0.05;
-    }
-    T r = C.discrete ? ladder(err, lo, hi) : cont;
-    // ... plus the optional Vdc_error term of my_spec (:251-262; Vdctarget = Vdc_ref, :243), summed (:301)
-    if ((C.extra & PVDER_REWARD_VDC_ERROR) && C.goal == PVDER_GOAL_POWER) {
+        err = fabs(Qpcc - qt) / fabs(qt);
+    } else {                                       // Vdc_error :251-262 (Vdctarget = Vdc_ref, :243)
         const T d = vdcref - Vdc;
-        r += C.discrete ? ladder(fabs(d) / vdcref, (T)0.02, (T)0.05) : -(d * d);
+        err = fabs(d) / vdcref; lo = (T)0.02; cont = -(d * d);
+    }
+    return C.discrete ? ladder(err, lo, hi) : cont;
+}
+
+template <typename T>
+__device__ __forceinline__ T reward_of(const StepK<T> &C, const ModelK<T> &P, T vrms, T Ppcc, T Qpcc, T Vdc, T vdcref, T qref) {
+    // PVDER_env.py:231-301 -- the goal's 'required' term (:78-93 via :448-452) ...
+    T r = reward_term<T>(C.goal == PVDER_GOAL_VOLTAGE ? kRewVoltage : (C.goal == PVDER_GOAL_POWER ? kRewPower : kRewQ), C, P,
+                         vrms, Ppcc, Qpcc, Vdc, vdcref, qref);
+    // ... plus the optional terms of my_spec (:249), summed (:301): Vdc_error (its target is defined for
+    // power_regulation only, :243), Q_error under voltage_regulation, voltage_error under the other two goals
+    if (C.extra != 0) {
+        if ((C.extra & PVDER_REWARD_VDC_ERROR) && C.goal == PVDER_GOAL_POWER)
+            r += reward_term<T>(kRewVdc, C, P, vrms, Ppcc, Qpcc, Vdc, vdcref, qref);
+        if ((C.extra & PVDER_REWARD_Q_ERROR) && C.goal == PVDER_GOAL_VOLTAGE)
+            r += reward_term<T>(kRewQ, C, P, vrms, Ppcc, Qpcc, Vdc, vdcref, qref);
+        if ((C.extra & PVDER_REWARD_VOLTAGE_ERROR) && C.goal != PVDER_GOAL_VOLTAGE)
+            r += reward_term<T>(kRewVoltage, C, P, vrms, Ppcc, Qpcc, Vdc, vdcref, qref);
     }
     return r;
 }
@@ -301,7 +319,7 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
     }
     T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
     pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc, y[6 * PH], L.vdcref);
+    T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc, y[6 * PH], L.vdcref, L.qref);
 #ifdef PVDER_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 32 + 22] = wall_clock64() + (reward > (T)1e30 ? 1 : 0);
 #endif
@@ -545,6 +563,18 @@ struct EtdK {
 // matrices of one step size, in the order they are used: those applied to (z, N1) first
 enum { EM_E2 = 0, EM_E, EM_A21, EM_A31, EM_A41, EM_A51, EM_B1, EM_A32, EM_A42, EM_A52, EM_A54, EM_B4, EM_B5, EM_COUNT };
 
+// ---- the switched block: the same 13 matrices for the (i_p, u_p) pair of ONE phase as REAL 4x4 matrices on
+// (iR, iI, uR, uI), once per anti-windup MODE of the pair.  While |m_p| > m_limit the reference model freezes the
+// components of du_p/dt (and dx_p/dt) that point outward (pvder_model.hpp::rhs, the `mlim2` branch): component-wise,
+// so the pair no longer obeys a complex 2x2 system but one of four real LINEAR ones -- mode bit 0: uR frozen (its row
+// of Lz zeroed), bit 1: uI frozen.  An ETDRK4 step that meets the limit is taken with the operator set of the mode
+// found at its start (etd_switched_step) where it used to be redone by 61 440 classic-RK4 steps per env step.
+// Layout: [step size][mode][matrix][16 floats]; a matrix as column pairs (M0k, M1k) k = 0..3, then (M2k, M3k).
+constexpr int kSwModes = 4;
+constexpr int kSwMatFloats = 16;
+constexpr int kSwFloats = kCoefSets * kSwModes * kMatCount * kSwMatFloats;       // 2496 floats = 9984 B
+constexpr int kCoefTotal = kCoefFloats + kSwFloats;
+
 // The ONE by-value argument of the ETDRK4 kernel (kernarg offset 0).  A single struct so that the
 // 23-state tail (etdrk4_full_tail) can re-read every argument through a laundered copy of the kernarg
 // pointer instead of keeping ~130 scalars of the fast path alive across the hot loop.
@@ -563,6 +593,7 @@ struct EtdArgs {
     int stats_fresh;         // 1: this launch starts the step's statistics (overwrites its slots), 0: adds
     int n_env;
     int force_full;          // A/B and tests: every env takes the 23-state path
+    int rk4_fallback;        // A/B and tests: steps at the duty-cycle limit by classic RK4 micro-steps (round 2's way)
 };
 
 typedef __attribute__((address_space(3))) v4 lds_v4;     // LDS-resident coefficient entries
@@ -666,6 +697,138 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
     return fmaxf(fmaxf(a.x + a.y, b.x + b.y), c.x + c.y);
 }
 
+// ---- one ETDRK4 step of the 23-state model with the (i_p, u_p) pairs on the operator sets of their anti-windup
+// modes (see kSwModes).  Same tableau, same slow-state update as the step in etdrk4_full_tail; what differs:
+//   * per phase, the mode found at the START of the step (|m_p| > m_limit: the components of du_p/dt that point
+//     outward are frozen) selects the real 4x4 operator set of the pair and blanks the frozen rows of N_u;
+//   * dx_p/dt carries the model's sign tests at every stage.
+// The mode is held over the step: a pair that leaves the limit inside the step is released at the next one
+// (steps of 1/1920 .. 1/60 s against the 5 us the controller needs to pull |m| back), and in the regime this serves
+// the duty cycle sits AT its limit for seconds -- stuck, not chattering.  With a duty cycle at its limit the
+// trajectory is not reproducible beyond 1e-2 .. 1e-1 by ANY integrator (fp64 RK45 at 1e-8 vs 1e-10: 3e-2 .. 9e-2,
+// profiles/r03_saturation_floor.txt), so this path is checked for what is robust: the duty cycle pinned at the limit,
+// the DC link and the powers at the converged solution's level, finite states (tests/test_gpu_parity.py).
+struct Mat16 { v4 a, b, c, d; };     // (col 0, col 1 of rows i), (col 2, col 3 of rows i), the same for rows u
+__device__ __forceinline__ Mat16 load_mat16(const lds_v4 *M, int k) {
+    Mat16 m;
+    m.a = M[4 * k + 0]; m.b = M[4 * k + 1]; m.c = M[4 * k + 2]; m.d = M[4 * k + 3];
+    return m;
+}
+__device__ __forceinline__ void matvec16(const Mat16 &M, v2 ni, v2 nu, v2 &oi, v2 &ou) {
+    using namespace pvder;
+    oi = fma2(mk2(M.a.x, M.a.y), bc2(ni.x), oi); oi = fma2(mk2(M.a.z, M.a.w), bc2(ni.y), oi);
+    oi = fma2(mk2(M.b.x, M.b.y), bc2(nu.x), oi); oi = fma2(mk2(M.b.z, M.b.w), bc2(nu.y), oi);
+    ou = fma2(mk2(M.c.x, M.c.y), bc2(ni.x), ou); ou = fma2(mk2(M.c.z, M.c.w), bc2(ni.y), ou);
+    ou = fma2(mk2(M.d.x, M.d.y), bc2(nu.x), ou); ou = fma2(mk2(M.d.z, M.d.w), bc2(nu.y), ou);
+}
+// the model's sign tests on dx_p/dt at a stage state yt (ns[0..2] = dx_p), and the frozen rows of N_u
+__device__ __forceinline__ void sw_mask(const ModelK<float> &P, const v2 *__restrict__ yt, const int (&mode)[3],
+                                        v2 *__restrict__ nf, v2 *__restrict__ ns) {
+    using namespace pvder;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const v2 x = yt[3 * p + 1], m = fma2(bc2(P.KpG), yt[3 * p + 2], x);
+        if (__builtin_fmaf(m.y, m.y, m.x * m.x) > P.mlim2) {
+            ns[p].x = ns[p].x * x.x > 0.f ? 0.f : ns[p].x;
+            ns[p].y = ns[p].y * x.y > 0.f ? 0.f : ns[p].y;
+        }
+        if (mode[p] & 1) nf[2 * p + 1].x = 0.f;
+        if (mode[p] & 2) nf[2 * p + 1].y = 0.f;
+    }
+}
+__device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
+                                                  const pvder::SubPk &S, v2 *__restrict__ y, v2 *__restrict__ comp,
+                                                  const lds_v4 *Mset, float h, float t0, float tq, float qref, float vdcref) {
+    using namespace pvder;
+    constexpr int SL[6] = {1, 4, 7, 9, 10, 11};
+    const v2 h2 = bc2(0.5f * h), h4 = bc2(0.25f * h), h8 = bc2(0.125f * h), h6 = bc2(h * (float)(1.0 / 6.0)),
+             h23 = bc2(h * (float)(2.0 / 3.0));
+    const float t1 = t0 + 0.5f * tq, t2 = t0 + tq;
+    v2 n1f[6], nf[6], ns1[6], nsl[6], s23[6], k14[6], yt[NP], n23[6];
+    v2 u3[6], u4[6], u5[6], zn[6];
+    etd_eval(P, K, Ec, S, y, t0, qref, vdcref, n1f, ns1);                                  // N1
+    int mode[3];
+    const lds_v4 *Mp[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const v2 u = y[3 * p + 2], m = fma2(bc2(P.KpG), u, y[3 * p + 1]);
+        const v2 du = fma2(bc2(-P.wp), y[3 * p] + u, n1f[2 * p + 1]);                      // wp (iref_p - i_p - u_p)
+        mode[p] = __builtin_fmaf(m.y, m.y, m.x * m.x) > P.mlim2 ? ((du.x * u.x > 0.f ? 1 : 0) | (du.y * u.y > 0.f ? 2 : 0)) : 0;
+        Mp[p] = Mset + mode[p] * (kMatCount * 4);
+    }
+    sw_mask(P, y, mode, n1f, ns1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const v2 zi = y[3 * p], zu = y[3 * p + 2];
+        const v2 n1i = n1f[2 * p], n1u = n1f[2 * p + 1];
+        v2 e2i = bc2(0.f), e2u = bc2(0.f), ei = bc2(0.f), eu = bc2(0.f);
+        matvec16(load_mat16(Mp[p], EM_E2), zi, zu, e2i, e2u);
+        matvec16(load_mat16(Mp[p], EM_E), zi, zu, ei, eu);
+        v2 ai = e2i, au = e2u;
+        matvec16(load_mat16(Mp[p], EM_A21), n1i, n1u, ai, au);                             // U2
+        yt[3 * p] = ai; yt[3 * p + 2] = au;
+        u3[2 * p] = e2i; u3[2 * p + 1] = e2u;
+        matvec16(load_mat16(Mp[p], EM_A31), n1i, n1u, u3[2 * p], u3[2 * p + 1]);
+        u4[2 * p] = ei; u4[2 * p + 1] = eu;
+        matvec16(load_mat16(Mp[p], EM_A41), n1i, n1u, u4[2 * p], u4[2 * p + 1]);
+        u5[2 * p] = e2i; u5[2 * p + 1] = e2u;
+        matvec16(load_mat16(Mp[p], EM_A51), n1i, n1u, u5[2 * p], u5[2 * p + 1]);
+        zn[2 * p] = ei; zn[2 * p + 1] = eu;
+        matvec16(load_mat16(Mp[p], EM_B1), n1i, n1u, zn[2 * p], zn[2 * p + 1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) yt[SL[q]] = fma2(h2, ns1[q], y[SL[q]]);
+    etd_eval(P, K, Ec, S, yt, t1, qref, vdcref, nf, nsl);                                  // N2
+    sw_mask(P, yt, mode, nf, nsl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        n23[2 * p] = nf[2 * p]; n23[2 * p + 1] = nf[2 * p + 1];
+        matvec16(load_mat16(Mp[p], EM_A32), nf[2 * p], nf[2 * p + 1], u3[2 * p], u3[2 * p + 1]);       // U3
+        yt[3 * p] = u3[2 * p]; yt[3 * p + 2] = u3[2 * p + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s23[q] = nsl[q]; yt[SL[q]] = fma2(h2, nsl[q], y[SL[q]]); }
+    etd_eval(P, K, Ec, S, yt, t1, qref, vdcref, nf, nsl);                                  // N3
+    sw_mask(P, yt, mode, nf, nsl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        n23[2 * p] += nf[2 * p]; n23[2 * p + 1] += nf[2 * p + 1];
+        matvec16(load_mat16(Mp[p], EM_A42), n23[2 * p], n23[2 * p + 1], u4[2 * p], u4[2 * p + 1]);     // U4
+        matvec16(load_mat16(Mp[p], EM_A52), n23[2 * p], n23[2 * p + 1], u5[2 * p], u5[2 * p + 1]);
+        yt[3 * p] = u4[2 * p]; yt[3 * p + 2] = u4[2 * p + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s23[q] += nsl[q]; yt[SL[q]] = fma2(h2, s23[q], y[SL[q]]); }
+    etd_eval(P, K, Ec, S, yt, t2, qref, vdcref, nf, nsl);                                  // N4
+    sw_mask(P, yt, mode, nf, nsl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        matvec16(load_mat16(Mp[p], EM_A54), nf[2 * p], nf[2 * p + 1], u5[2 * p], u5[2 * p + 1]);       // U5
+        matvec16(load_mat16(Mp[p], EM_B4), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+        yt[3 * p] = u5[2 * p]; yt[3 * p + 2] = u5[2 * p + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        k14[q] = ns1[q] + nsl[q];
+        yt[SL[q]] = fma2(h8, s23[q], fma2(h4, ns1[q], y[SL[q]]));
+    }
+    etd_eval(P, K, Ec, S, yt, t1, qref, vdcref, nf, nsl);                                  // N5
+    sw_mask(P, yt, mode, nf, nsl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        matvec16(load_mat16(Mp[p], EM_B5), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int g = SL[q];
+        const v2 inc = fma2(h23, nsl[q], fma2(h6, k14[q], -comp[g]));
+        const v2 tsum = y[g] + inc;
+        comp[g] = (tsum - y[g]) - inc;
+        y[g] = tsum;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { y[3 * p] = zn[2 * p]; y[3 * p + 2] = zn[2 * p + 1]; }
+}
+
 // The 23-state ETDRK4 path, the tail of step_etdrk4_bal_kernel<3>: its workgroups run it for the lanes
 // they must defer (`defer`; their state in memory is untouched, every other lane of the workgroup is
 // finished).  It takes a LAUNDERED copy of the kernarg address and re-reads every argument through
@@ -697,7 +860,9 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
     // the same address: conflict-free, no VALU issue slot).
     __shared__ __attribute__((aligned(16))) float Mlds[kCoefFloats];
+    __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // the switched block (steps at the duty-cycle limit)
     for (int k = threadIdx.x; k < kCoefFloats; k += kBlock) Mlds[k] = coef[k];
+    for (int k = threadIdx.x; k < kSwFloats; k += kBlock) Msw[k] = coef[kCoefFloats + k];
     __syncthreads();
     Lane<float> L;
     float ys[NS];
@@ -728,7 +893,6 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
             for (int j = 0; j < nst; ++j) {
                 // graded schedule: first step 1/(60 micro), then ONE step over the remainder
                 const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
-                const int rk4_sub = set == 0 ? Ec.rk4_sub[0] : (set == 1 ? Ec.rk4_sub[1] : Ec.rk4_sub[2]);
                 const float h = set == 0 ? Ec.hset[0] : (set == 1 ? Ec.hset[1] : Ec.hset[2]);
                 const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
                          h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
@@ -807,11 +971,21 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                 if (fmaxf(m2a, m2b) > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) {
                     L.fail = true;                 // the episode ends here (epilogue); the state no longer matters
                 } else if (fmaxf(m2a, m2b) > guard) {
-                    // duty cycle near its limit: anti-windup may switch the fast dynamics -> redo
-                    // this step with classic RK4 micro-steps (random-action PVDER-v0 episodes never get here; a
-                    // policy that walks Vdc_ref down 6 % does: ~4000 x 686 instructions per sim time step)
-                    rk4_pk_steps(P, K, S, y, comp, rk4_sub, h / (float)rk4_sub, t0, tq / (float)rk4_sub,
-                                 L.qref, L.vdcref);
+                    // duty cycle at / near its limit: the anti-windup may have switched the fast dynamics -> this
+                    // step again on the operator sets of the pairs' anti-windup modes (random-action PVDER-v0
+                    // episodes never get here; a policy that walks Vdc_ref down 6 % does, and among 65 536 envs
+                    // some do after a +2 % grid-voltage event on top of a few per cent)
+#ifdef PVDER_RK4_FALLBACK
+                    if (A.rk4_fallback) {
+                        const int rk4_sub = set == 0 ? Ec.rk4_sub[0] : (set == 1 ? Ec.rk4_sub[1] : Ec.rk4_sub[2]);
+                        rk4_pk_steps(P, K, S, y, comp, rk4_sub, h / (float)rk4_sub, t0, tq / (float)rk4_sub, L.qref, L.vdcref);
+                    } else
+#endif
+                    {
+                        const lds_v4 *Ms = (const lds_v4 *)Msw + (kSwModes * kMatCount * 4) * set;
+                        asm volatile("" : "+v"(Ms));
+                        etd_switched_step(P, K, Ec, S, y, comp, Ms, h, t0, tq, L.qref, L.vdcref);
+                    }
                 } else {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) { y[3 * p] = yt[3 * p]; y[3 * p + 2] = yt[3 * p + 2]; }
@@ -1107,6 +1281,8 @@ struct LinK {
                                      // time steps takes behind its tick
     float est_guard;                 // a step whose indicator max |y+ - b| over (i_a, Vdc) exceeds this hands the env
                                      // to the 23-state path
+    float ir2_careful;               // |iref_a|^2 at the start of a step above which the env takes the careful pass
+                                     // (current limit: hybrid steps with the outer loops' anti-windup, finer schedule)
 };
 struct LinArgs {
     EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
@@ -1127,7 +1303,6 @@ struct RollK {
 // event-row change; the segment's inputs and schedule row are requested right away
 struct LinSeg {
     int row, until, seg;
-    bool evjump;                         // the segment starts at an EVENT (not just a new action)
     float in_vg, in_si;
     unsigned long long sch;
 };
@@ -1135,7 +1310,7 @@ __device__ __forceinline__ LinSeg lin_first_segment(const StepK<float> &C, const
                                                     const float *ev_si, size_t N, int ec) {
     constexpr int kBig = 0x3fffffff;
     LinSeg s;
-    s.row = 0; s.until = kBig; s.evjump = false;
+    s.row = 0; s.until = kBig;
     if (C.ev_count > 0) {
         const int d = ksub - C.ev_s0;
         if (d < 0) {
@@ -1143,7 +1318,6 @@ __device__ __forceinline__ LinSeg lin_first_segment(const StepK<float> &C, const
         } else {
             const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
             s.row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
-            s.evjump = rd == 0 && qd < C.ev_count;
             s.until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
         }
     }
@@ -1193,12 +1367,12 @@ __device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys)
 }
 
 // One ETD3RK step of every lane from Y with the coefficient set in Ac: Yn = y+, returns whether the lane
-// must be handed to the 23-state path (|m| / |iref| guards at the start, the middle -- stage a --, the end
-// of the step; embedded error indicator)
+// must be handed to the 23-state path (|m| guard at the start, the middle -- stage a --, the end of the step;
+// embedded error indicator); near_ilim: |iref| at the start of the step is within 10 % of the current limit
 template <int PH>
 __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
-                                           const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float i2m,
-                                           pvder::v4f (&Yn)[3], bool traced) {
+                                           const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
+                                           pvder::v4f (&Yn)[3], bool traced, bool &near_ilim) {
     using namespace pvder;
     const ModelK<float> &P = G.A.P;
     const EtdK &Ec = G.A.Ec;
@@ -1235,15 +1409,46 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
     const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
-    return fmaxf(mmax, ir2a * i2m) > Ec.sat2_smooth || est > G.Lk.est_guard;
+    near_ilim = ir2a > irg;          // the current reference comes near its limit: the careful pass redoes the env step
+    return mmax > Ec.sat2_smooth || est > G.Lk.est_guard;
+}
+
+// Does the duty cycle stay clear of its limit over the TICK behind an input jump (Y -> acc)?  The jump kicks the
+// under-damped current loop (poles -1.0e5 +- j5.8e5 1/s, zeta = 0.17): m = Kp_GCC u + x rings around its new value --
+// reached well inside the tick, 20 decay times -- with a first overshoot of exp(-pi zeta / sqrt(1 - zeta^2)) = 0.58
+// of the jump.  Peak = |m_new| + 0.6 |m_new - m_old| against the smooth-step guard: the clearance an env needs
+// follows the jump it actually sees (an action alone: none; a 2 % grid-voltage event: 1.2 %) where a blanket 3 % sent
+// every env beyond |m| = 0.97 to the 23-state path at every event (among 65 536 envs on a Vdc_ref ramp: thousands).
+__device__ __forceinline__ bool lin_tick_trip(const ModelK<float> &P, const EtdK &Ec, const pvder::v4f (&Y)[3],
+                                              const pvder::v4f (&acc)[3], float m2a) {
+    using namespace pvder;
+    const v2 m0 = fma2(bc2(P.KpG), mk2(Y[1].x, Y[1].y), mk2(Y[0].z, Y[0].w));
+    const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
+    const v2 dm = mn - m0;
+    const float n2 = __builtin_fmaf(mn.y, mn.y, mn.x * mn.x), d2 = __builtin_fmaf(dm.y, dm.y, dm.x * dm.x);
+    const float peak2 = n2 + 1.2f * __builtin_sqrtf(n2 * d2) + 0.36f * d2;          // (|m_new| + 0.6 |dm|)^2
+    return fmaxf(m2a, peak2) > Ec.sat2_smooth;
+}
+
+// next byte of a lane's schedule row; a byte with bit 7 set continues the row in another one (rows behind the
+// 2 * n_sub regular ones: segments that need more than seven steps)
+__device__ __forceinline__ unsigned long long lin_sched_next(const LinArgs &G, unsigned long long sch) {
+    sch >>= 8;
+#ifndef PVDER_NO_CONT
+    if (sch & 0x80ull) sch = G.Lk.sched[2 * G.A.C.n_sub + (int)(sch & 0x7full)];
+#endif
+    return sch;
 }
 
 // One env step of the lanes with `run` set, state Y in registers: per-lane schedule, wave-uniform trip
-// count.  Returns the lanes that must be handed to the 23-state path (their Y is then meaningless).
-template <int PH>
+// count.  Returns the lanes that must be handed to the 23-state path (their Y is then meaningless);
+// `careful`: the lanes whose current reference comes near its limit -- the careful pass (lin_integrate_careful)
+// redoes their env step from the state they started with (their Y is meaningless too).
+// SPLIT = false (the fused rollout kernel, which hands both kinds to the per-step body): one flag, returned.
+template <int PH, bool SPLIT = true>
 __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
                                               int &cur, pvder::v4f (&Y)[3], float qref, float vdcref, int ec, LinSeg sg,
-                                              bool run, bool defer, int trace_step) {
+                                              bool run, bool defer, bool &careful, int trace_step) {
     using namespace pvder;
     constexpr int kBig = 0x3fffffff;
     const ModelK<float> &P = G.A.P;
@@ -1255,11 +1460,12 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
     float g_kpdc = P.KpDC, g_kpq = -P.KpQ, g_kidc = P.KiDC, g_kiq = -P.KiQ;
     asm volatile("" : "+s"(g_kpdc), "+s"(g_kpq), "+s"(g_kidc), "+s"(g_kiq));
     const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
-    float i2m = Ec.i2_to_m2;
-    asm volatile("" : "+v"(i2m));
+    float irg = G.Lk.ir2_careful;
+    asm volatile("" : "+v"(irg));
     int spos = 0;                        // sim time steps of the env step behind this lane
     bool start = true;                   // this lane is at the start of a segment (its tick is due)
     bool done = !run;
+    careful = false;
     SubPk S;
     cur = __builtin_amdgcn_readfirstlane(cur);           // (wave-uniform by construction: tell hipcc)
     // ---- the standard env step, straight-line: every lane that runs has ONE segment (no event row change
@@ -1279,20 +1485,24 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
-            const float guard = sg.evjump ? Ec.sat2_event : Ec.sat2_smooth;
-            bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+            bool trip = lin_tick_trip(P, Ec, Y, acc, m2a);
             if (run) {
-                defer |= trip;
+                if constexpr (SPLIT) { careful |= ir2a > irg; defer |= trip && !careful; } else defer |= trip || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
             }
+            // (a wave whose envs all sit at the current limit -- a policy that holds one Q_ref action -- goes
+            // straight to the careful pass)
+#ifndef PVDER_NO_EARLY
+            if (!__builtin_amdgcn_readfirstlane(__any((int)(run && !defer && !careful)))) return defer;
+#endif
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 if (trace_step == 0 && st == 1) PVDER_TRACE_AT(4);
                 v4f Yn[3];
-                trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, i2m, Yn, trace_step == 0 && st == 1);
+                bool near;
+                trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, Yn, trace_step == 0 && st == 1, near);
                 if (run) {
-                    defer |= trip;
+                    if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                     Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
                 }
             }
@@ -1300,7 +1510,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
         }
     }
     for (int it = 0;; ++it) {
-        if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
+        if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer && !careful)))) break;
         if (trace_step == 0 && it < 16) PVDER_TRACE_AT(3 + it);
         v2 yp[6], F[6];
         float m2a, ir2a;
@@ -1308,19 +1518,17 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             // ---- a segment starts (new action at the start of the env step, or a new event row): the
             // TICK behind the jump, exponential Euler  y+ = y + h phi1(hL) f(y).  The jump kicks the stiff
             // loop; the exponential carries that transient exactly, and over one tick the rest of f
-            // hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  An EVENT may make
-            // |m| overshoot inside the tick: 3 % clearance there (see make_etd).
+            // hardly moves (fp64 prototype: same trajectory error as an ETD3RK tick).  The jump may make
+            // |m| overshoot inside the tick: lin_tick_trip.
             // (lanes in the middle of a segment recompute S from the inputs they hold: same values)
             make_sub_pk(P, sg.in_vg, sg.in_si, S);
             lin_pairs(Y, yp);
             bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
-            const float guard = sg.evjump ? Ec.sat2_event : Ec.sat2_smooth;
-            const bool trip = fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+            const bool trip = lin_tick_trip(P, Ec, Y, acc, m2a);
             if (start && !done) {
-                defer |= trip;
+                if constexpr (SPLIT) { careful |= ir2a > irg; defer |= trip && !careful; } else defer |= trip || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 start = false;
             }
@@ -1334,11 +1542,12 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
         // have drifted apart.  Same arithmetic either way: a lane's result does not depend on its neighbours.
         if (__builtin_amdgcn_readfirstlane(__any((int)(todo && sidx != cur))) == 0) {
             v4f Yn[3];
-            const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, i2m, Yn, trace_step == 0 && it == 1);
+            bool near;
+            const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, Yn, trace_step == 0 && it == 1, near);
             if (todo) {
-                defer |= trip;
+                if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                 Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
-                sg.sch >>= 8;
+                sg.sch = lin_sched_next(G, sg.sch);
             }
         } else {
             for (;;) {
@@ -1350,11 +1559,12 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
                     cur = s_now;
                 }
                 v4f Yn[3];
-                const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, i2m, Yn, false);
+                bool near;
+                const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, Yn, false, near);
                 if (todo && sidx == s_now) {
-                    defer |= trip;
+                    if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                     Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
-                    sg.sch >>= 8;
+                    sg.sch = lin_sched_next(G, sg.sch);
                     todo = false;
                 }
             }
@@ -1369,12 +1579,201 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
                 if (!done) {                         // an event row starts here
                     sg.row += 1;
                     sg.until = sg.row < C.ev_count ? C.ev_ds : kBig;
-                    sg.evjump = true;
                     const int left = C.n_sub - spos;
                     sg.seg = sg.until < left ? sg.until : left;
                     sg.in_vg = G.A.ev_vg[(size_t)sg.row * N + ec];
                     sg.in_si = G.A.ev_si[(size_t)sg.row * N + ec];
                     sg.sch = G.Lk.sched[sg.seg - 1];
+                    start = true;
+                }
+            }
+        }
+    }
+    return defer;
+}
+
+// =============================================================================================
+// The careful pass: envs at the CURRENT LIMIT on the matrix-core path.
+// Beyond |iref| = iref_limit the reference model integrates its outer PI loops conditionally -- xDC / xQ stop
+// whenever they would move outward (pvder_model.hpp::rhs, the `ilim2` branch).  That logic is common to the three
+// phases (iref_a is), so the balanced reduction keeps it; what it breaks is the smoothness the big ETD3RK steps
+// rely on.  With s = |iref|^2 - iref_limit^2 the env is FREE (s <= 0), FROZEN (s > 0) or SLIDING along s = 0
+// (free dynamics push s up, frozen dynamics pull it down), and where it enters the limit the frozen integrators
+// remember the instant they stopped: a chattering explicit scheme needs 1/240 s steps for 3e-4 per env step
+// (fp64 prototype, tools/limit_proto.py).  The hybrid step below takes the SAME big step up to three times with
+// the outward-moving integrators advancing at alpha times their rate (bal_f<PH, true>):
+//   1. alpha = 1 from a free state / 0 from a frozen one; accepted if s keeps its sign over the step;
+//   2. otherwise the crossing is located (quadratic through s at the start, stage a, the end) and alpha = the
+//      fraction of the step spent free; accepted if the env then stays on the far side (stuck behind the crossing);
+//   3. otherwise it slides: alpha by the secant rule such that the step ends ON the limit, s = 0.
+// Schedule: the careful rows of the table (n_sub .. 2 n_sub - 1): a standard env step = tick + EIGHT equal steps
+// (fp64 prototype along the reference's fixed-action ramps to Q_ref = +-1.2 pu, eight envs, worst env step against the
+// converged solution: four steps 3.5e-4, eight 1.1e-4; the chattering scheme with 60 steps 5.8e-4).
+// =============================================================================================
+template <int PH>
+__device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
+                                              const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float alpha,
+                                              pvder::v4f (&Yn)[3], float &ir2_mid, float &ir2_end) {
+    using namespace pvder;
+    const ModelK<float> &P = G.A.P;
+    const EtdK &Ec = G.A.Ec;
+    const PkConst K = make_pkconst(P);
+    v2 yp[6], F[6];
+    float m2a, ir2a, m2x, m2b, ir2b;
+    lin_pairs(Y, yp);
+    bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a, alpha);
+    v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
+    {
+        const int m3[3] = {LM21, LM31, LM41};
+        lin_mfma<3>(Ac, m3, F, acc3);
+    }
+    lin_pairs(acc3[0], yp);
+    bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2x, ir2_mid, alpha);
+    v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
+    {
+        const int m2[2] = {LM32, LM42};
+        lin_mfma<2>(Ac, m2, F, acc2);
+    }
+    lin_pairs(acc2[0], yp);
+    bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2b, ir2b, alpha);
+    Yn[0] = acc2[1][0]; Yn[1] = acc2[1][1]; Yn[2] = acc2[1][2];
+    lin_mfma1(Ac[LM43], F, Yn);
+    ir2_end = lin_iref2<PH>(K, S, Yn, qref, vdcref, kpo);
+    const float est = fmaxf(fmaxf(fabsf(Yn[0].x - acc2[0][0].x), fabsf(Yn[0].y - acc2[0][0].y)),
+                            fabsf(Yn[1].z - acc2[0][1].z));
+    const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
+    const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+    return mmax > Ec.sat2_smooth || est > G.Lk.est_guard;
+}
+
+// where the quadratic through (0, s0), (1/2, sm), (1, s1) crosses zero, as a fraction of the step (s0, s1 of
+// opposite sign); the chord's crossing when the parabola has none inside
+__device__ __forceinline__ float lin_cross_frac(float s0, float sm, float s1) {
+    const float cq = 2.f * (s1 - 2.f * sm + s0), bq = s1 - s0 - cq;
+    const float chord = s0 / (s0 - s1);
+    const float disc = bq * bq - 4.f * cq * s0;
+    float t = chord;
+    if (fabsf(cq) > 1e-12f && disc >= 0.f) {
+        const float r = __builtin_sqrtf(disc);
+        // the numerically stable pair of roots:  q = -(b + sign(b) r)/2,  t1 = q/c,  t2 = s0/q
+        const float q = -0.5f * (bq + (bq >= 0.f ? r : -r));
+        const float t1 = q / cq, t2 = q != 0.f ? s0 / q : -1.f;
+        if (t1 >= 0.f && t1 <= 1.f) t = t1;
+        else if (t2 >= 0.f && t2 <= 1.f) t = t2;
+    }
+    return fminf(1.f, fmaxf(0.f, t));
+}
+
+// one hybrid step of every lane (`act`: the lanes that will commit it); Yn = y+; returns the hand-over flag
+template <int PH>
+__device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
+                                                const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, bool act,
+                                                pvder::v4f (&Yn)[3]) {
+    using namespace pvder;
+    const float lim = G.A.P.ilim2;
+    const PkConst K = make_pkconst(G.A.P);
+    const float s0 = lin_iref2<PH>(K, S, Y, qref, vdcref, kpo) - lim;
+    const bool from_free = s0 <= 0.f;
+    const float a1 = from_free ? 1.f : 0.f;
+    float irm, ire;
+    bool trip = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a1, Yn, irm, ire);
+    const float s1 = ire - lim;
+    const bool need2 = act && (from_free ? s1 > 0.f : s1 < 0.f);
+    if (__builtin_amdgcn_readfirstlane(__any((int)need2))) {
+        // the limit is crossed inside the step: the integrators run free for the fraction `tau` (1 - tau) of it
+        const float tau = lin_cross_frac(s0, irm - lim, s1);
+        const float a2 = need2 ? (from_free ? tau : 1.f - tau) : a1;
+        v4f Y2[3];
+        const bool trip2 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a2, Y2, irm, ire);
+        const float s2 = ire - lim;
+        if (need2) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip2; }
+        const bool need3 = need2 && (from_free ? s2 < 0.f : s2 > 0.f);
+        if (__builtin_amdgcn_readfirstlane(__any((int)need3))) {
+            // it does not stay on the far side: sliding along the limit -- the step ends on s = 0 (secant between
+            // the two evaluations that bracket it)
+            const float a3 = need3 ? (from_free ? a2 - s2 * (1.f - a2) / (s1 - s2) : a2 * s1 / (s1 - s2)) : a2;
+            const bool trip3 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a3, Y2, irm, ire);
+            if (need3) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip3; }
+        }
+    }
+    return trip;
+}
+
+// The env step of the lanes with `run` set (the careful lanes of lin_integrate), from the state they started the
+// env step with.  Same frame as lin_integrate's general loop -- per-lane schedule rows (the careful ones), one pass
+// per distinct coefficient set, wave-uniform trip counts, a lane's arithmetic independent of its neighbours.
+template <int PH>
+__device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane, const pvder::LinMatRegs &At,
+                                                      pvder::LinSetRegs &Ac, int &cur, pvder::v4f (&Y)[3], float qref,
+                                                      float vdcref, int ec, LinSeg sg, bool run, bool defer) {
+    using namespace pvder;
+    constexpr int kBig = 0x3fffffff;
+    const ModelK<float> &P = G.A.P;
+    const StepK<float> &C = G.A.C;
+    const EtdK &Ec = G.A.Ec;
+    const size_t N = (size_t)G.A.n_env;
+    const PkConst K = make_pkconst(P);
+    float g_kpdc = P.KpDC, g_kpq = -P.KpQ, g_kidc = P.KiDC, g_kiq = -P.KiQ;
+    asm volatile("" : "+s"(g_kpdc), "+s"(g_kpq), "+s"(g_kidc), "+s"(g_kiq));
+    const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
+    int spos = 0;
+    bool start = true;
+    bool done = !run;
+    SubPk S;
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    sg.sch = G.Lk.sched[C.n_sub + sg.seg - 1];           // the careful row of the first segment
+    for (;;) {
+        if (!__builtin_amdgcn_readfirstlane(__any((int)(!done && !defer)))) break;
+        if (__builtin_amdgcn_readfirstlane(__any((int)(start && !done)))) {
+            // the tick behind the jump: frozen or free by the side of the limit the env starts on
+            v2 yp[6], F[6];
+            float m2a, ir2a;
+            make_sub_pk(P, sg.in_vg, sg.in_si, S);
+            lin_pairs(Y, yp);
+            bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a, -1.f);
+            v4f acc[3] = {Y[0], Y[1], Y[2]};
+            lin_mfma1(At, F, acc);
+            const bool trip = lin_tick_trip(P, Ec, Y, acc, m2a);
+            if (start && !done) {
+                defer |= trip;
+                Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
+                start = false;
+            }
+        }
+        const int sidx = (int)(sg.sch & 0xffull);
+        bool todo = !done && !defer && sidx != 0;
+        for (;;) {
+            const unsigned long long tm = __ballot((int)todo);
+            if (tm == 0) break;
+            const int s_now = __builtin_amdgcn_readlane(sidx, (int)__builtin_ctzll(tm));
+            if (s_now != cur) {
+                lin_load_set(G.Lk.lcoef + kLinMatFloats + (size_t)(s_now - 1) * kLinSetFloats, lane, Ac);
+                cur = s_now;
+            }
+            v4f Yn[3];
+            const bool mine = todo && sidx == s_now;
+            const bool trip = lin_hybrid_step<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, mine, Yn);
+            if (mine) {
+                defer |= trip;
+                Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
+                sg.sch = lin_sched_next(G, sg.sch);
+                todo = false;
+            }
+        }
+        const bool fin = !done && !start && (sg.sch & 0xffull) == 0;
+        if (__builtin_amdgcn_readfirstlane(__any((int)fin))) {
+            if (fin) {
+                spos += sg.seg;
+                sg.until -= sg.seg;
+                done = spos >= C.n_sub;
+                if (!done) {
+                    sg.row += 1;
+                    sg.until = sg.row < C.ev_count ? C.ev_ds : kBig;
+                    const int left = C.n_sub - spos;
+                    sg.seg = sg.until < left ? sg.until : left;
+                    sg.in_vg = G.A.ev_vg[(size_t)sg.row * N + ec];
+                    sg.in_si = G.A.ev_si[(size_t)sg.row * N + ec];
+                    sg.sch = G.Lk.sched[C.n_sub + sg.seg - 1];
                     start = true;
                 }
             }
@@ -1419,7 +1818,17 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         v4f Y[3];
         lin_from_rows<PH>(ys, Y);
         PVDER_TRACE_AT(2);
-        defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, 0);
+        bool careful;
+        defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, careful, 0);
+        careful = careful && L.run && !defer;
+        if (__builtin_amdgcn_readfirstlane(__any((int)careful))) {
+            // envs at the current limit: their env step again, from the state it started with, by the careful pass
+            v4f Yc[3];
+            lin_from_rows<PH>(ys, Yc);
+            if (careful) { Y[0] = Yc[0]; Y[1] = Yc[1]; Y[2] = Yc[2]; }
+            const bool dc = lin_integrate_careful<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, careful, false);
+            defer |= careful && dc;
+        }
         if (L.run && !defer) {
             lin_to_rows<PH>(Y, ys);
             L.ksub += A.C.n_sub;
@@ -1593,8 +2002,10 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
             else if (a == 3) vdcref += A.C.dv;
             else if (a == 4) vdcref -= A.C.dv;
             else if (a != 0) bad = 1.f;
-            if (!__builtin_amdgcn_readfirstlane(__any((int)leave)))
-                leave = lin_integrate<PH>(Q1.G, lane, At, Ac, cur, Y, qref, vdcref, ec, sg, true, false, traced ? 0 : 1);
+            if (!__builtin_amdgcn_readfirstlane(__any((int)leave))) {
+                bool careful;          // (an env at the current limit leaves too: its step belongs to the per-step body's careful pass)
+                leave = lin_integrate<PH, false>(Q1.G, lane, At, Ac, cur, Y, qref, vdcref, ec, sg, true, false, careful, traced ? 0 : 1);
+            }
             if (traced) PVDER_TRACE_DEP(20, Y[0].x + Y[2].z);
             float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
                         fabsf(Y[1].z) + fabsf(Y[1].w) + fabsf(Y[2].x) + fabsf(Y[2].y) + fabsf(Y[2].z);
@@ -1616,7 +2027,7 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
             make_sub<float, PH>(B.P, sg_next.in_vg, sg_next.in_si, S);
             float iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
             outputs<float, PH>(B.P, S, ys, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
-            last_reward = reward_of<float>(B.C, B.P, vrms, Ppcc, Qpcc, ys[6 * PH], vdcref);
+            last_reward = reward_of<float>(B.C, B.P, vrms, Ppcc, Qpcc, ys[6 * PH], vdcref, qref);
             if (traced) PVDER_TRACE_DEP(22, last_reward + ppv);
             if (e < B.n_env) {
                 float *o = B.out + k * Q2.Rk.out_stride;
@@ -1943,7 +2354,100 @@ void pack_m2(const M2 &M, float *o) {
     const cd e[4] = {M.a, M.b, M.c, M.d};
     for (int k = 0; k < 4; ++k) { o[2 * k] = (float)e[k].real(); o[2 * k + 1] = (float)e[k].imag(); }
 }
-EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float *coef /* host, kCoefFloats, may be NULL */) {
+// ---- the switched block (kSwModes): phi-functions of the REAL 4x4 operator of a pair's anti-windup mode, by the
+// exponential of the augmented matrix [[hL, I, 0, 0], [0, 0, I, 0], [0, 0, 0, I], [0, 0, 0, 0]] (first block row =
+// phi_0 .. phi_3), Taylor series with scaling and squaring in long double (|hL| reaches 1.5e4: 15 squarings)
+typedef long double lreal;
+struct R4 { lreal a[4][4]; };
+struct R16 { lreal a[16][16]; };
+R16 mul16(const R16 &A, const R16 &B) {
+    R16 Cm;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            lreal t = 0;
+            for (int k = 0; k < 16; ++k) t += A.a[i][k] * B.a[k][j];
+            Cm.a[i][j] = t;
+        }
+    return Cm;
+}
+void phis4(const R4 &L, double h, R4 (&out)[4]) {
+    R16 M{};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) M.a[i][j] = (lreal)h * L.a[i][j];
+    for (int b = 0; b < 3; ++b)
+        for (int i = 0; i < 4; ++i) M.a[4 * b + i][4 * (b + 1) + i] = 1;
+    lreal norm = 0;
+    for (int j = 0; j < 16; ++j) {
+        lreal c = 0;
+        for (int i = 0; i < 16; ++i) c += fabsl(M.a[i][j]);
+        norm = c > norm ? c : norm;
+    }
+    int sq = 0;
+    while (norm > 0.25L) { norm *= 0.5L; ++sq; }
+    const lreal sc = ldexpl(1.0L, -sq);
+    for (auto &row : M.a)
+        for (auto &v : row) v *= sc;
+    R16 T{}, term{};
+    for (int i = 0; i < 16; ++i) T.a[i][i] = term.a[i][i] = 1;
+    for (int k = 1; k <= 22; ++k) {
+        term = mul16(term, M);
+        for (auto &row : term.a)
+            for (auto &v : row) v /= (lreal)k;
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) T.a[i][j] += term.a[i][j];
+    }
+    // (the identity blocks were scaled with the rest: T = exp(sc W), and squaring sq times gives exp(W) itself)
+    for (int q = 0; q < sq; ++q) T = mul16(T, T);
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) out[k].a[i][j] = T.a[i][4 * k + j];
+}
+R4 lin4(double s1, const R4 &A, double s2, const R4 &B, double s3, const R4 &Cm) {
+    R4 o;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) o.a[i][j] = (lreal)s1 * A.a[i][j] + (lreal)s2 * B.a[i][j] + (lreal)s3 * Cm.a[i][j];
+    return o;
+}
+void pack_r4(const R4 &M, float *o) {           // column pairs of rows (0, 1), then of rows (2, 3)
+    for (int k = 0; k < 4; ++k) { o[2 * k] = (float)M.a[0][k]; o[2 * k + 1] = (float)M.a[1][k]; }
+    for (int k = 0; k < 4; ++k) { o[8 + 2 * k] = (float)M.a[2][k]; o[8 + 2 * k + 1] = (float)M.a[3][k]; }
+}
+void make_switched(const cd Z0, double c0kp, double wp, const double (&hs)[kCoefSets], float *sw /* kSwFloats */) {
+    for (int set = 0; set < kCoefSets; ++set)
+        for (int mode = 0; mode < kSwModes; ++mode) {
+            // rows / columns (iR, iI, uR, uI) of  Lz = [[-Z0, c0 Kp], [-wp, -wp]];  a frozen component of u: its row zeroed
+            R4 L{};
+            L.a[0][0] = -Z0.real(); L.a[0][1] = Z0.imag(); L.a[0][2] = c0kp;
+            L.a[1][0] = -Z0.imag(); L.a[1][1] = -Z0.real(); L.a[1][3] = c0kp;
+            if (!(mode & 1)) { L.a[2][0] = -wp; L.a[2][2] = -wp; }
+            if (!(mode & 2)) { L.a[3][1] = -wp; L.a[3][3] = -wp; }
+            const double h = hs[set];
+            R4 ph[4], pf[4];
+            phis4(L, 0.5 * h, ph);
+            phis4(L, h, pf);
+            const R4 Z{};
+            const R4 a52 = lin4(0.5, ph[2], -1.0, pf[3], 0.25, pf[2]);
+            const R4 a52f = lin4(1.0, a52, -0.5, ph[3], 0, Z);
+            const R4 a54 = lin4(0.25, ph[2], -1.0, a52f, 0, Z);
+            const R4 a51 = lin4(0.5, ph[1], -2.0, a52f, -1.0, a54);
+            float(*m)[kSwMatFloats] = reinterpret_cast<float(*)[kSwMatFloats]>(sw + ((size_t)set * kSwModes + mode) * kMatCount * kSwMatFloats);
+            pack_r4(ph[0], m[EM_E2]);
+            pack_r4(pf[0], m[EM_E]);
+            pack_r4(lin4(0.5 * h, ph[1], 0, Z, 0, Z), m[EM_A21]);
+            pack_r4(lin4(0.5 * h, ph[1], -h, ph[2], 0, Z), m[EM_A31]);
+            pack_r4(lin4(h, ph[2], 0, Z, 0, Z), m[EM_A32]);
+            pack_r4(lin4(h, pf[1], -2 * h, pf[2], 0, Z), m[EM_A41]);
+            pack_r4(lin4(h, pf[2], 0, Z, 0, Z), m[EM_A42]);
+            pack_r4(lin4(h, a51, 0, Z, 0, Z), m[EM_A51]);
+            pack_r4(lin4(h, a52f, 0, Z, 0, Z), m[EM_A52]);
+            pack_r4(lin4(h, a54, 0, Z, 0, Z), m[EM_A54]);
+            pack_r4(lin4(h, pf[1], -3 * h, pf[2], 4 * h, pf[3]), m[EM_B1]);
+            pack_r4(lin4(-h, pf[2], 4 * h, pf[3], 0, Z), m[EM_B4]);
+            pack_r4(lin4(4 * h, pf[2], -8 * h, pf[3], 0, Z), m[EM_B5]);
+        }
+}
+
+EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float *coef /* host, kCoefTotal, may be NULL */) {
     const double iLf = 1.0 / par[PVDER_PAR_LF];
     const cd kvi(par[PVDER_PAR_KVI_RE], par[PVDER_PAR_KVI_IM]);
     const cd Z0 = iLf * (kvi + par[PVDER_PAR_RF]) + cd(0.0, 1.0);
@@ -1991,6 +2495,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float 
         pack_m2(lin(4 * h, pf[2], -8 * h, pf[3], 0, Z), m[set][EM_B5]);
         // classic RK4 needs h <~ 4.1 us on this spectrum: 4096 micro-steps per 1/60 s
     }
+    if (coef) make_switched(Z0, c0 * kp, wp, hs, coef + kCoefFloats);
     E.c0kp = (float)(c0 * kp);
     // Anti-windup switches the fast dynamics only while |m_p| > m_limit.  On a step that starts at
     // an input jump the under-damped current loop (zeta ~ 0.17) overshoots, so |m| may cross the
@@ -2093,15 +2598,19 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     // PVDER_ETD_VARIANT=full / cfg->reserved bit 0 send every env down the 23-state path (A/B, tests)
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
+    A.rk4_fallback = (cfg->reserved & 2) ? 1 : 0;
     if (integrator == PVDER_INT_ETDLIN) {
         if (!lin || !lin->sets || !lin->sched || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
         if (lin->len_ticks[0] < 1 || !(lin->est_guard > 0.f)) return PVDER_EINVAL;
+        if (lin->n_sched_rows < 2 * cfg->n_sub || lin->n_sched_rows > 2 * cfg->n_sub + 128) return PVDER_EINVAL;
         for (int s = 1; s < lin->n_sets; ++s)
             if (lin->len_ticks[s] < 1) return PVDER_EINVAL;
         LinK &K = p.lin.Lk;
         K.lcoef = lin->sets;
         K.sched = (const unsigned long long *)lin->sched;
         K.est_guard = lin->est_guard;
+        // the careful pass takes over where |iref| comes within 10 % of the current limit
+        K.ir2_careful = (float)(0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]);
     }
     return 0;
 }
@@ -2199,7 +2708,7 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
     return reset_impl<double>(par, cfg, ar, fstate, istate, ev_vg, ev_si, mask, out, n_env, stream);
 }
 
-int pvder_etdrk4_coef_count(void) { return kCoefFloats; }
+int pvder_etdrk4_coef_count(void) { return kCoefTotal; }
 int pvder_lin_set_floats(void) { return pvder::kLinSetFloats; }
 int pvder_lin_max_sets(void) { return pvder::kLinMaxSets; }
 

@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -32,7 +32,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
 AGENT_SYMBOLS = ["pvder_qagent_step_f32"]            # include/pvder_agent.h
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
-LIN_MAX_SETS = 8
+LIN_MAX_SETS = 12
 
 
 class StepCfg(C.Structure):
@@ -70,7 +70,7 @@ class QAgentCfg(C.Structure):
 class LinCoef(C.Structure):
     """``struct pvder_lin_coef`` (include/pvder_hip.h)."""
     _fields_ = [("sets", C.c_void_p), ("n_sets", C.c_int32), ("len_ticks", C.c_int32 * LIN_MAX_SETS),
-                ("sched", C.c_void_p), ("est_guard", C.c_float)]
+                ("sched", C.c_void_p), ("est_guard", C.c_float), ("n_sched_rows", C.c_int32)]
 
 
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs (the VALU code reads them without

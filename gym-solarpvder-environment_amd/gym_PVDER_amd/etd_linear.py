@@ -282,17 +282,20 @@ def tick_length(micro: int) -> int:
 
 
 def choose_sets(n_sub: int, micro: int, ev_s0: int, ev_ds: int, ev_count: int, max_ksub: int,
-                max_sets: int = 8) -> List[int]:
+                max_sets: int = 12) -> List[float]:
     """Step lengths (ticks of 1/(60*micro) s) of the coefficient sets of a launch: [tick, the set PVDER-v0
     env steps use, others].  An env takes the tick (exponential Euler) behind every input jump and then
-    the largest eligible ETD3RK step of the menu (rule: include/pvder_hip.h, pvder_lin_coef), which holds
+    the ETD3RK steps its schedule row lists (``build_schedule``).  The menu holds
 
     * HALF of ``L*micro - tick`` for the segment lengths L (sim time steps between two jumps) that envs
       running in lockstep with the event grid meet, most frequent first.  PVDER-v0: L = n_sub only
       (events sit on env-step boundaries), so an env step is tick + two equal ETD3RK steps;
+    * an EIGHTH of it for the most frequent L: the careful pass (envs at the current limit) takes eight steps;
     * ``micro - tick`` and ``micro``: together they tile any segment (an env reset off the grid, an event
       spec that is not a multiple of the env step);
     * power-of-two multiples of ``micro`` while there is room, so that such segments take O(log L) steps.
+
+    Lengths are whole ticks except the eighth, which may end on a fraction of a tick.
     """
     from collections import Counter
     cnt: Counter = Counter()
@@ -305,61 +308,119 @@ def choose_sets(n_sub: int, micro: int, ev_s0: int, ev_ds: int, ev_count: int, m
         k += n_sub
     t0 = tick_length(micro)
     base = sorted({micro - t0, micro} - {0}, reverse=True) or [1]
-    lens: List[int] = []                         # set 1 = the most frequent one: the kernel keeps it in registers
-    for L, _ in cnt.most_common():
-        if len(lens) + len([b for b in base if b not in lens]) >= max_sets - 1:
+    lens: List[float] = []                       # set 1 = the most frequent one: the kernel keeps it in registers
+    powers = []
+    p = 2
+    while p < n_sub and len(powers) < 7:
+        powers.append(p * micro)
+        p *= 2
+    room = max_sets - 1 - len(base) - len(powers)         # what is left for halves / the quarter
+
+    def genuine_half(rest):
+        return rest >= 2 and rest % 2 == 0 and rest // 2 % micro != 0 and (rest // 2 + t0) % micro != 0
+
+    for i, (L, _) in enumerate(cnt.most_common()):
+        if len(lens) >= room:
             break
         rest = L * micro - t0
-        if rest >= 2 and rest % 2 == 0 and rest // 2 % micro != 0 and (rest // 2 + t0) % micro != 0:
-            t = rest // 2                        # a genuine half (neither whole steps nor whole minus the tick)
-        else:
-            t = rest                             # (odd remainder / tiny segment: one step over all of it)
-        if t >= 1 and t not in lens:
+        t = rest // 2 if genuine_half(rest) else rest      # (odd remainder / tiny segment: one step over all of it)
+        if t >= 1 and t not in lens and t not in base and t not in powers:
             lens.append(t)
+            if i == 0 and genuine_half(rest) and len(lens) < room:
+                lens.append(rest / float(CAREFUL_STEPS) if rest % CAREFUL_STEPS else rest // CAREFUL_STEPS)   # the careful pass's step
     lens += [b for b in base if b not in lens]
-    p = 2
-    while len(lens) < max_sets - 1 and p < n_sub:
-        if p * micro not in lens:
-            lens.append(p * micro)
-        p *= 2
+    lens += [q for q in powers if q not in lens]
     return [t0] + lens
 
 
-SCHED_BYTES = 8       # bytes per schedule row: up to 7 ETD3RK steps + the terminating 0
+CAREFUL_STEPS = 8     # equal ETD3RK steps of a standard env step in the careful pass (fp64 prototype along the reference's
+#                       Q_ref ramps into the current limit, worst env step vs the converged solution: 4 steps 3.5e-4, 8 steps 0.9e-4)
+SCHED_BYTES = 8       # bytes per schedule row: up to 7 ETD3RK steps + the terminating 0, or a continuation byte
+SCHED_MAX_CONT = 127  # continuation rows a table may hold
 
 
-def build_schedule(n_sub: int, micro: int, len_ticks: Sequence[int]) -> np.ndarray:
-    """uint8 [n_sub, 8]: row L-1 = the set numbers (1-based positions in ``len_ticks``, 0-terminated) of
-    the ETD3RK steps that cover a segment of L sim time steps behind its tick.  Rule: a HALF (a length
-    that is neither whole sim time steps nor that minus the tick) is taken when exactly two or one of
-    it are left; otherwise the largest length that fits among the whole ones and -- while the env is
-    still one tick past a boundary -- the whole-minus-tick ones."""
+def _tile_segment(L: int, micro: int, len_ticks: Sequence[float], careful: bool) -> List[int]:
+    """Set numbers (1-based positions in ``len_ticks``) of the ETD3RK steps that cover a segment of L sim time
+    steps behind its tick.  Rule: HALVES (a length that is neither whole sim time steps nor that minus the tick)
+    are taken when exactly two of them are left -- the careful pass takes CAREFUL_STEPS equal parts instead when the
+    menu has them --, one when one is left; otherwise the largest length that fits among the whole ones and, while the env
+    is still one tick past a boundary, the whole-minus-tick ones."""
     t0 = len_ticks[0]
-    whole = lambda t: t % micro == 0
-    short1 = lambda t: not whole(t) and (t + t0) % micro == 0
-    table = np.zeros((n_sub, SCHED_BYTES), dtype=np.uint8)
-    for L in range(1, n_sub + 1):
-        rem, behind, steps = L * micro - t0, True, []
-        while rem > 0:
+    whole = lambda t: float(t).is_integer() and int(t) % micro == 0
+    short1 = lambda t: float(t).is_integer() and not whole(t) and int(t + t0) % micro == 0
+    frac = [s for s in range(1, len(len_ticks)) if not whole(len_ticks[s]) and not short1(len_ticks[s])]
+    rem, behind, steps = float(L * micro - t0), True, []
+    while rem > 1e-9:
+        fit = []
+        if careful and not steps:
+            fit = [s for s in frac if abs(rem - CAREFUL_STEPS * len_ticks[s]) < 1e-9]
+            if fit:
+                steps += [fit[0]] * CAREFUL_STEPS
+                break
+        fit = [s for s in frac if abs(rem - len_ticks[s]) < 1e-9 or abs(rem - 2 * len_ticks[s]) < 1e-9]
+        if not fit:
             fit = [s for s in range(1, len(len_ticks))
-                   if not whole(len_ticks[s]) and not short1(len_ticks[s]) and rem in (len_ticks[s], 2 * len_ticks[s])]
-            if not fit:
-                fit = [s for s in range(1, len(len_ticks))
-                       if (whole(len_ticks[s]) or (short1(len_ticks[s]) and behind)) and len_ticks[s] <= rem]
-                fit.sort(key=lambda s: -len_ticks[s])
-            if not fit:
-                raise ValueError("step menu %s cannot tile a segment of %d sim time steps" % (list(len_ticks), L))
-            s = fit[0]
-            rem -= len_ticks[s]
-            behind = behind and not short1(len_ticks[s])
-            steps.append(s)
-        if len(steps) > SCHED_BYTES - 1:
-            raise ValueError("segment of %d sim time steps needs %d steps (> %d)" % (L, len(steps), SCHED_BYTES - 1))
-        table[L - 1, :len(steps)] = steps
-    return table
+                   if (whole(len_ticks[s]) or (short1(len_ticks[s]) and behind)) and len_ticks[s] <= rem + 1e-9]
+            fit.sort(key=lambda s: -len_ticks[s])
+        if not fit:
+            raise ValueError("step menu %s cannot tile a segment of %d sim time steps" % (list(len_ticks), L))
+        s = fit[0]
+        rem -= len_ticks[s]
+        behind = behind and not short1(len_ticks[s])
+        steps.append(s)
+    return steps
 
 
-def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[int]) -> np.ndarray:
+def build_schedule(n_sub: int, micro: int, len_ticks: Sequence[float]) -> np.ndarray:
+    """uint8 [2 * n_sub + n_cont, 8] (include/pvder_hip.h, pvder_lin_coef.sched): row L-1 = the set numbers,
+    0-terminated, of the steps a segment of L sim time steps takes behind its tick; row n_sub + L-1 = the same
+    for the careful pass; a segment that needs more than seven steps ends its row with 0x80 | c and goes on in
+    continuation row 2 * n_sub + c (any n_sub >= 1 is tiled; ValueError beyond 127 continuation rows)."""
+    rows: List[List[int]] = []
+    cont: List[List[int]] = []
+
+    index: Dict[tuple, int] = {}              # tail -> its continuation row (tilings share their tails)
+
+    def emit(steps: List[int]) -> List[int]:
+        if len(steps) <= SCHED_BYTES - 1:
+            return steps + [0] * (SCHED_BYTES - len(steps))
+        head, tail = steps[:SCHED_BYTES - 1], tuple(steps[SCHED_BYTES - 1:])
+        if tail not in index:
+            if len(cont) >= SCHED_MAX_CONT:
+                raise ValueError("schedule needs more than %d continuation rows (n_sub %d)" % (SCHED_MAX_CONT, n_sub))
+            index[tail] = len(cont)
+            cont.append([])                   # reserve the slot (the tail may itself continue)
+            cont[index[tail]] = emit(list(tail))
+        return head + [0x80 | index[tail]]
+
+    memo: Dict[tuple, List[int]] = {}
+    for careful in (False, True):
+        for L in range(1, n_sub + 1):
+            steps = _tile_segment(L, micro, len_ticks, careful)
+            key = tuple(steps)
+            if key not in memo:
+                memo[key] = emit(steps)
+            rows.append(memo[key])
+    return np.array(rows + cont, dtype=np.uint8).reshape(-1, SCHED_BYTES)
+
+
+def schedule_steps(table: np.ndarray, n_sub: int, row: int) -> List[int]:
+    """The set numbers row ``row`` of a ``build_schedule`` table lists, continuation rows followed."""
+    out: List[int] = []
+    r = table[row]
+    while True:
+        for b in r:
+            if b == 0:
+                return out
+            if b & 0x80:
+                r = table[2 * n_sub + int(b & 0x7f)]
+                break
+            out.append(int(b))
+        else:
+            return out
+
+
+def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[float]) -> np.ndarray:
     """fp32 coefficient block of a launch: the tick matrix  h phi1(hL)  (h = len_ticks[0] ticks), then one
     ETD3RK set per entry of len_ticks[1:]."""
     tick = 1.0 / (60.0 * micro)
@@ -369,7 +430,7 @@ def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[int]) -> np.ndarra
     return np.concatenate(parts)
 
 
-def build_coefficients(par: np.ndarray, der_id: str, micro: int, len_ticks: Sequence[int]) -> np.ndarray:
+def build_coefficients(par: np.ndarray, der_id: str, micro: int, len_ticks: Sequence[float]) -> np.ndarray:
     """fp32 coefficient block [MAT + (n_sets - 1) * SET_FLOATS] for the step lengths ``len_ticks`` (ticks)."""
     L, _ = jacobian(par, der_id)
     return pack_block(L, micro, len_ticks)
@@ -381,3 +442,77 @@ def euler_tick(c, P1: np.ndarray, y, inputs, dtype=np.float64):
     inp = [np.asarray(v, dtype=dtype) for v in inputs]
     cc = {k: (dtype(v) if isinstance(v, float) else v) for k, v in c.items()}
     return y + P1.astype(dtype) @ f_bal(cc, y, *inp).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the careful pass (envs at the current limit): numpy statement of csrc lin_hybrid_step / lin_integrate_careful
+# ---------------------------------------------------------------------------------------------------
+def iref2(c, y, vg, qref, vdcref):
+    """|iref_a|^2 at a balanced state: iref_a = xDC + Kp_DC (Vdc_ref - Vdc) + j [xQ - Kp_Q (Q_ref - Im S_PCC)]."""
+    iR, iI = y[0], y[1]
+    aR, aI = c["GR"] * vg, c["GI"] * vg
+    vR = aR + c["kviR"] * iR - c["kviI"] * iI
+    vI = aI + c["kviR"] * iI + c["kviI"] * iR
+    Q = 0.5 * c["PH"] * (vI * iR - vR * iI)
+    rR = y[7] + c["KpDC"] * (vdcref - y[6])
+    rI = y[8] - c["KpQ"] * (qref - Q)
+    return rR * rR + rI * rI
+
+
+def f_bal_limited(c, y, inputs, alpha, ilim2):
+    """f_bal with the reference model's conditional integration of the outer PI loops in the form the hybrid steps
+    use: an outer integrator that moves outward (derivative and state of one sign -- the component the model freezes
+    while |iref| > iref_limit) advances at ``alpha`` times its rate; alpha < 0: 0 or 1 by the side of the limit."""
+    f = f_bal(c, y, *inputs)
+    if alpha < 0:
+        alpha = 0.0 if iref2(c, y, inputs[0], inputs[2], inputs[3]) > ilim2 else 1.0
+    for k in (7, 8):
+        if f[k] * y[k] > 0:
+            f[k] = alpha * f[k]
+    return f
+
+
+def cross_fraction(s0: float, sm: float, s1: float) -> float:
+    """Where the parabola through (0, s0), (1/2, sm), (1, s1) crosses zero (s0, s1 of opposite sign)."""
+    cq = 2.0 * (s1 - 2.0 * sm + s0)
+    bq = s1 - s0 - cq
+    t = s0 / (s0 - s1)
+    disc = bq * bq - 4.0 * cq * s0
+    if abs(cq) > 1e-12 and disc >= 0:
+        r = math.sqrt(disc)
+        q = -0.5 * (bq + (r if bq >= 0 else -r))
+        t1, t2 = q / cq, (s0 / q if q != 0 else -1.0)
+        if 0.0 <= t1 <= 1.0:
+            t = t1
+        elif 0.0 <= t2 <= 1.0:
+            t = t2
+    return min(1.0, max(0.0, t))
+
+
+def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
+    """One hybrid ETD3RK step of an env at the current limit (DESIGN.md "careful pass"): the same step up to three
+    times -- free / frozen; with the crossing of |iref| = iref_limit located inside the step; sliding along it.
+    Returns (y+, evaluations)."""
+    M21, M31, M32, M41, M42, M43 = mats
+
+    def step(alpha):
+        F1 = f_bal_limited(c, y, inputs, alpha, ilim2); a = y + M21 @ F1
+        F2 = f_bal_limited(c, a, inputs, alpha, ilim2); b = y + M31 @ F1 + M32 @ F2
+        F3 = f_bal_limited(c, b, inputs, alpha, ilim2)
+        yn = y + M41 @ F1 + M42 @ F2 + M43 @ F3
+        s = lambda u: iref2(c, u, inputs[0], inputs[2], inputs[3]) - ilim2
+        return yn, s(a), s(yn)
+
+    s0 = iref2(c, y, inputs[0], inputs[2], inputs[3]) - ilim2
+    free = s0 <= 0
+    a1 = 1.0 if free else 0.0
+    y1, sm, s1 = step(a1)
+    if (s1 > 0) != free or s1 == 0:
+        return y1, 1
+    tau = cross_fraction(s0, sm, s1)
+    a2 = tau if free else 1.0 - tau
+    y2, _, s2 = step(a2)
+    if (s2 < 0) != free or s2 == 0:
+        return y2, 2
+    a3 = a2 - s2 * (1.0 - a2) / (s1 - s2) if free else a2 * s1 / (s1 - s2)
+    return step(a3)[0], 3

@@ -182,11 +182,9 @@ class PVDERVec(EnvSpecMixin):
         if isinstance(micro_steps, bool) or not isinstance(micro_steps, int) or micro_steps < 1:
             raise ValueError("micro_steps must be a positive integer")
         if micro_coarse is None:
-            # etdlin: the ETDRK4 schedule only drives the 23-state tail, i.e. envs far from the nominal operating
-            # point (|Q_ref| > 0.8 pu, current / duty-cycle limits): two steps per quiet sim time step there --
-            # one is 3-4e-4 per env step off the converged solution at Q_ref = -0.9 ... -1.2 pu, two 0.4-2.4e-4
-            micro_coarse = min(DEFAULT_MICRO_COARSE, micro_steps) if integrator == "etdrk4" else \
-                (min(2, micro_steps) if integrator == "etdlin" else 0)
+            # (etdlin: the ETDRK4 schedule drives its 23-state tail -- envs off balance or at the duty-cycle limit;
+            # envs far from the nominal operating point stay on the matrix-core path since round 3: careful pass)
+            micro_coarse = min(DEFAULT_MICRO_COARSE, micro_steps) if integrator in ("etdrk4", "etdlin") else 0
         if isinstance(micro_coarse, bool) or not isinstance(micro_coarse, int) or micro_coarse < 0:
             raise ValueError("micro_coarse must be a non-negative integer")
         self.micro_coarse = int(micro_coarse)
@@ -245,7 +243,7 @@ class PVDERVec(EnvSpecMixin):
             pass
 
     # -- everything a plan folds in: assigning any of these drops the plan (rebuilt at the next step)
-    _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded",
+    _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded", "env_reward_spec",
                             "est_guard", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
                             "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "env_goal_spec", "integrator",
                             "off_range"))
@@ -253,7 +251,9 @@ class PVDERVec(EnvSpecMixin):
     def set_reward_spec(self, reward_types):
         """``env_goal_spec[goal]['reward']['my_spec'] = reward_types`` for the active goal (the reference's
         ``update_env_goal`` is "under construction", PVDER_env.py:454-456; ``reward_calc`` iterates this
-        list, :249): the goal's required term, optionally plus 'Vdc_error' (power_regulation)."""
+        list, :249): the goal's required term, optionally plus the terms whose targets ``reward_calc`` defines
+        under that goal -- 'Vdc_error' / 'voltage_error' (power_regulation), 'Q_error' with Qtarget = Q_ref
+        (voltage_regulation), 'voltage_error' (Q_regulation)."""
         self.env_goal_spec[self._goals_list[0]]['reward']['my_spec'] = list(reward_types)
         self._drop_plan()
         self._cfg()                       # validate now
@@ -409,14 +409,20 @@ class PVDERVec(EnvSpecMixin):
         # construction", :454-456 -- but reward_calc honours whatever it holds)
         goal = self._goals_list[0]
         spec = self.env_goal_spec[goal]['reward']
-        mine = spec.get('my_spec', spec['required'])
+        mine = list(spec.get('my_spec', spec['required']))
+        # which optional terms reward_calc can evaluate under a goal: the targets it defines there (:237-245) --
+        # Qtarget under voltage_regulation (= PV_model.Q_ref) and Q_regulation, Vdctarget / Ptarget under
+        # power_regulation; voltage_error needs none
+        optional = {'voltage_regulation': {'Q_error'}, 'power_regulation': {'Vdc_error', 'voltage_error'},
+                    'Q_regulation': {'voltage_error'}}[goal]
         unknown = set(mine) - set(self.env_reward_spec['reward_list']['valid'])
-        if unknown or spec['required'][0] not in mine or set(mine) - set(spec['required']) - {'Vdc_error'}:
-            raise ValueError("reward my_spec %s: must hold the goal's required term %s, optionally plus 'Vdc_error'"
-                             % (mine, spec['required']))
-        if 'Vdc_error' in mine and goal != 'power_regulation':
-            raise ValueError("'Vdc_error' needs Vdctarget, which reward_calc defines for power_regulation only (:243-245)")
-        c.extra_rewards = 1 if 'Vdc_error' in mine else 0
+        if unknown or spec['required'][0] not in mine or len(set(mine)) != len(mine) \
+                or set(mine) - set(spec['required']) - optional:
+            raise ValueError("reward my_spec %s of goal %s: must hold the goal's required term %s, optionally plus %s "
+                             "(the terms whose targets reward_calc defines for this goal, PVDER_env.py:237-245)"
+                             % (mine, goal, spec['required'], sorted(optional)))
+        c.extra_rewards = (1 if 'Vdc_error' in mine else 0) | (2 if ('Q_error' in mine and goal == 'voltage_regulation') else 0) \
+            | (4 if ('voltage_error' in mine and goal != 'voltage_regulation') else 0)
         return c
 
     def _spec(self) -> _native.EventSpec:
@@ -462,9 +468,10 @@ class PVDERVec(EnvSpecMixin):
         lc = _native.LinCoef()
         lc.sets = self._lin_dev.data_ptr()
         lc.sched = self._lin_sched.data_ptr()
+        lc.n_sched_rows = int(self._lin_sched.shape[0])
         lc.n_sets = len(lens)
         for k, t in enumerate(lens):
-            lc.len_ticks[k] = t
+            lc.len_ticks[k] = int(math.ceil(t))      # (informational: the careful pass's set may end on a fraction of a tick)
         lc.est_guard = self.est_guard
         return lc
 
@@ -473,10 +480,19 @@ class PVDERVec(EnvSpecMixin):
     def _make_plan(self):
         """Fold cfg / reset block / coefficients into a C-side plan (include/pvder_hip.h "plans")."""
         cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
-        coef = self._etd_coef(cfg).data_ptr() if self.integrator in ("etdrk4", "etdlin") else None
-        lin = C.byref(self._lin_coef(cfg)) if self.integrator == "etdlin" else None
+        integrator = self.integrator
+        coef = self._etd_coef(cfg).data_ptr() if integrator in ("etdrk4", "etdlin") else None
+        lin = None
+        if integrator == "etdlin":
+            try:
+                lin = C.byref(self._lin_coef(cfg))
+            except ValueError as e:
+                # (env steps of more than ~1000 sim time steps: the schedule table cannot list their segments)
+                logger.warning("etdlin cannot tile this step schedule (%s): this env steps with integrator='etdrk4'", e)
+                integrator = "etdrk4"
+        self._plan_integrator = integrator
         h = C.c_void_p()
-        _native.check(self._lib.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS[self.integrator], self._par_c,
+        _native.check(self._lib.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS[integrator], self._par_c,
                                                   C.byref(cfg), C.byref(ar), coef, lin, self.num_envs),
                       "pvder_plan_create")
         self._plan = h
@@ -517,8 +533,12 @@ class PVDERVec(EnvSpecMixin):
                 mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
                 assert mask.shape == (self.num_envs,)
             self._reset_launch(mask)
-            if self._plan is None:
-                self._make_plan()                    # coefficient uploads now: step() must stay capturable into a HIP graph
+            # the plan is folded anew at every reset (cheap, never inside a graph capture): specs edited in place
+            # (env_events_spec[...]['ENABLE'], env_reward_spec['reference_values'], my_spec lists) take effect here at
+            # the latest -- attribute assignments and update_env_events / set_reward_spec drop the plan at once.
+            # Coefficient uploads happen now too: step() must stay capturable into a HIP graph
+            self._drop_plan()
+            self._make_plan()
             if self.hstep is not None:
                 if mask is None:
                     self.hstep.zero_()
@@ -597,12 +617,12 @@ class PVDERVec(EnvSpecMixin):
                 if out is not None:
                     out[k].copy_(self.out)
             return
-        can_fuse = self.integrator == "etdlin" and self.ns == 23 and not self._timing
+        plan = self._plan or self._make_plan()
+        can_fuse = self._plan_integrator == "etdlin" and self.ns == 23 and not self._timing
         if fused and not can_fuse:
             raise ValueError("fused rollouts: integrator='etdlin', three-phase model, no per-launch timing")
         if fused is None:
             fused = can_fuse and K >= 4
-        plan = self._plan or self._make_plan()
         with self._device_ctx():
             if out is not None and K > 0 and not self.auto_reset:
                 out[0].copy_(self.out)               # stale tuples of finished envs: block k takes them from block k-1
@@ -647,9 +667,9 @@ class PVDERVec(EnvSpecMixin):
         if self.hstep is not None:
             self.hstep.copy_(d["hstep"])
         self._needs_reset = False
-        if self._plan is None:
-            with self._device_ctx():
-                self._make_plan()
+        with self._device_ctx():
+            self._drop_plan()
+            self._make_plan()
 
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------
     _timing = False

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 9
+#define PVDER_ABI_VERSION 10
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -94,7 +94,8 @@ typedef struct pvder_step_cfg {
     int32_t ev_ds;        /* ksub between events      (t_events_step*60)  */
     int32_t ev_count;     /* K events; event tables have K+1 rows (row 0 = nominal) */
     int32_t reserved;     /* integrator-specific test knob, 0 in production: RK45 = cap on attempts per
-                             sim time step; ETDRK4 bit 0 = run the full 23-state kernel only */
+                             sim time step; ETDRK4 / etdlin bit 0 = run the full 23-state kernel only, bit 1 = steps
+                             at the duty-cycle limit by classic RK4 micro-steps instead of the switched operator sets */
     double del_qref;      /* _delQref/Sbase   per env step (:617, :225) */
     double del_vdcref;    /* _delVdcref/Vdcbase per env step (:618, :229) */
     double inv_max_sim_time; /* obs[10] = tStart/max_sim_time (:540) */
@@ -109,19 +110,24 @@ typedef struct pvder_step_cfg {
                              what sets the error -- then the remainder (1 - 1/micro)/60.
                              PVDER defaults: micro 32, micro_coarse 1, graded 1 */
     int32_t extra_rewards; /* reward types of env_goal_spec[goal]['reward']['my_spec'] beyond the goal's
-                             required one (:249): PVDER_REWARD_VDC_ERROR adds the Vdc_error term
-                             (:251-262; power_regulation only, as its target is defined at :243-245) */
+                             required one (:249), a mask: PVDER_REWARD_VDC_ERROR adds the Vdc_error term
+                             (:251-262; power_regulation only, as its target is defined at :243-245),
+                             PVDER_REWARD_Q_ERROR the Q_error term under voltage_regulation (:263-275 with
+                             Qtarget = PV_model.Q_ref, :238 -- 1e-6 when it is 0 in the discrete branch, :266-267),
+                             PVDER_REWARD_VOLTAGE_ERROR the voltage_error term (:276-287) under the other goals */
     int32_t off_range;    /* what happens to an env that leaves the range the fast fp32 integrators cover -- duty
                              cycle |m| at its limit or current reference at the overload limit, where the
                              reference model's component-wise anti-windup switches the stiff dynamics:
                              PVDER_OFF_RANGE_INTEGRATE (0, default): it is integrated through, as the reference
-                             does, by classic RK4 micro-steps -- correct, and ~50 ms per env step for the whole
-                             launch while ONE env is there;  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
+                             does -- the 23-state path on the operator sets of the anti-windup modes, ~0.1 ms per env
+                             step for the launch while an env is there;  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
                              (status 2, done, reward -100: the reference's failure branch, :169-172) -- for
                              training runs that must not stall on a saturated converter.  fp32 exponential
                              integrators only (etdlin, ETDRK4). */
 } pvder_step_cfg;
 #define PVDER_REWARD_VDC_ERROR 1
+#define PVDER_REWARD_Q_ERROR 2
+#define PVDER_REWARD_VOLTAGE_ERROR 4
 #define PVDER_OFF_RANGE_INTEGRATE 0
 #define PVDER_OFF_RANGE_TERMINATE 1
 
@@ -188,10 +194,13 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
                           float *ev_si, const uint8_t *action, float *out, float *stats,
                           int zero_stats, int n_env, void *stream);
 
-/* ETDRK4 coefficient block: pvder_etdrk4_coef_count() floats (phi-function matrices of the constant
- * stiff 2x2 block for the step sizes of the schedule -- 1/(60*micro), 1/(60*micro_coarse) and
- * (1 - 1/micro)/60 --, folded in fp64).
- * pvder_etdrk4_coefficients() computes it on the HOST into coef_host; the caller uploads it once
+/* ETDRK4 coefficient block: pvder_etdrk4_coef_count() floats -- the phi-function matrices of the constant
+ * stiff 2x2 complex block for the step sizes of the schedule (1/(60*micro), 1/(60*micro_coarse) and
+ * (1 - 1/micro)/60), followed by the SWITCHED block: the same matrices for the (i_p, u_p) pair of one phase as real
+ * 4x4 operators, once per anti-windup mode of the pair (which components of du_p/dt the reference model's
+ * conditional integration freezes while |m_p| > m_limit) -- a step of the 23-state path that meets the duty-cycle
+ * limit is taken on the operator set of the mode found at its start.  All folded in fp64 / long double.
+ * pvder_etdrk4_coefficients() computes the block on the HOST into coef_host; the caller uploads it once
  * to a device buffer and passes that buffer as `coef` to every pvder_step_etdrk4_f32() call with the
  * same par / micro / micro_coarse / graded (kept out of the kernel-argument segment, which every workgroup
  * re-reads at launch). */
@@ -224,26 +233,34 @@ int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvde
  *                  step behind an input jump (new action / new event row) is an exponential-Euler
  *                  step  y+ = y + h phi1(hL) f(y)  of that length (1 or 2 ticks);
  *   set s >= 1   : ETD3RK over len_ticks[s] ticks;
- *   sched        : device, cfg->n_sub rows of 8 bytes: row L-1 lists, one set number per byte and
- *                  terminated by 0, the ETD3RK steps an env takes behind the tick to cover a SEGMENT
- *                  of L sim time steps (the stretch up to the next event row change or the end of the
- *                  env step); the tick and the listed lengths must add up to L * cfg->micro ticks.
- *                  The Python host lists, for the segment lengths PVDER-v0 meets, two steps of half
- *                  of what the tick leaves (an env step = tick + two equal ETD3RK steps with ONE
- *                  coefficient set) and tiles any other length with whole multiples of 1/60 s;
+ *   sched        : device, n_sched_rows rows of 8 bytes.  A row lists, one set number per byte and terminated
+ *                  by 0, the ETD3RK steps an env takes behind the tick to cover a SEGMENT (the stretch up to the
+ *                  next event row change or the end of the env step); the tick and the listed lengths must add
+ *                  up to the segment.  Rows 0 .. n_sub-1: row L-1 = a segment of L sim time steps.  The Python
+ *                  host lists, for the segment lengths PVDER-v0 meets, two steps of half of what the tick leaves
+ *                  (an env step = tick + two equal ETD3RK steps with ONE coefficient set) and tiles any other
+ *                  length with whole multiples of 1/60 s.  Rows n_sub .. 2 n_sub-1: the same for the CAREFUL
+ *                  pass (below; the host lists eight equal steps where the regular row lists two halves).
+ *                  A byte with bit 7 set ends a row that needs more than seven steps: the list continues in
+ *                  row 2 n_sub + (byte & 0x7f);
  *   est_guard    : an env whose embedded error indicator  max |y+ - b|  over (i_a, Vdc) exceeds it in
  *                  any ETD3RK step -- hopelessly far from the operating point L was taken at -- is
  *                  advanced by the 23-state ETDRK4 path instead (`coef`, as for
- *                  pvder_step_etdrk4_f32), like the envs that come near a limit or are not balanced. */
+ *                  pvder_step_etdrk4_f32), like the envs that come near the duty-cycle limit or are not balanced.
+ * The careful pass: an env whose current reference comes within 10 % of iref_limit (a policy that holds one
+ * Q_ref action walks there, PVDER_env.py:214-217, :480-487) stays on this path; its env step is taken by hybrid
+ * ETD3RK steps that carry the reference model's conditional integration of the outer PI loops -- free, frozen,
+ * or sliding along |iref| = iref_limit, with the crossing located inside the step (csrc: lin_integrate_careful). */
 #define PVDER_LIN_MAT_FLOATS 144
 #define PVDER_LIN_SET_FLOATS 864
-#define PVDER_LIN_MAX_SETS 8
+#define PVDER_LIN_MAX_SETS 12
 typedef struct pvder_lin_coef {
     const float *sets;       /* device, PVDER_LIN_MAT_FLOATS + (n_sets - 1) * PVDER_LIN_SET_FLOATS floats */
     int32_t n_sets;          /* 2 .. PVDER_LIN_MAX_SETS */
     int32_t len_ticks[PVDER_LIN_MAX_SETS];
-    const uint8_t *sched;    /* device, 8 * cfg->n_sub bytes */
+    const uint8_t *sched;    /* device, 8 * n_sched_rows bytes */
     float est_guard;
+    int32_t n_sched_rows;    /* >= 2 * cfg->n_sub (regular rows, careful rows, continuation rows) */
 } pvder_lin_coef;
 int pvder_lin_set_floats(void);
 int pvder_lin_max_sets(void);

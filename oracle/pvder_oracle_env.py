@@ -52,11 +52,13 @@ GOAL_REWARDS = {                    # 'required' lists, PVDER_env.py:78-93 via :
 
 
 def reward_terms(goal: str, discrete: bool, Vrms: float, Vrms_ref: float, S_PCC: complex, Vdc: float, Vdc_ref: float,
-                 my_spec: Optional[List[str]] = None):
+                 my_spec: Optional[List[str]] = None, Q_ref: float = 0.0):
     """``reward_calc`` (PVDER_env.py:231-301) on explicit model quantities: one entry per reward type
     of ``env_goal_spec[goal]['reward']['my_spec']`` (default: the goal's 'required' list, :448-452),
-    summed (:301).  ``Vdc_error`` (:251-262) is only defined for power_regulation (its target,
-    ``Vdctarget = PV_model.Vdc_ref``, is set at :243-245 for that goal alone)."""
+    summed (:301).  The targets are the ones ``reward_calc`` defines per goal (:237-245): under
+    voltage_regulation ``Qtarget = PV_model.Q_ref`` (:238, argument ``Q_ref``), under Q_regulation the spec's
+    ``Q_ref / Sbase`` (:241), under power_regulation ``Vdctarget = PV_model.Vdc_ref`` and ``Ptarget`` (:243-245);
+    a reward type whose target the goal does not define is a NameError in the reference -- ValueError here."""
     rewards: List = []
     for rt in (my_spec if my_spec is not None else GOAL_REWARDS[goal]):   # :249
         if rt == "Vdc_error":                                           # :251-262
@@ -72,7 +74,9 @@ def reward_terms(goal: str, discrete: bool, Vrms: float, Vrms_ref: float, S_PCC:
             else:
                 rewards.append(-(Vrms - Vrms_ref) ** 2)
         elif rt == "Q_error":                                           # :263-275
-            Qt = Q_REF_TARGET / pm.SBASE                                # :241
+            if goal == "power_regulation":
+                raise ValueError("Q_error needs Qtarget, which reward_calc does not define for power_regulation")
+            Qt = Q_ref if goal == "voltage_regulation" else Q_REF_TARGET / pm.SBASE      # :238 / :241
             if discrete:
                 if Qt == 0.0:
                     Qt = 1e-6
@@ -80,6 +84,8 @@ def reward_terms(goal: str, discrete: bool, Vrms: float, Vrms_ref: float, S_PCC:
             else:
                 rewards.append(-(S_PCC.imag - Qt) ** 2)
         elif rt == "power_error":                                       # :290-299
+            if goal != "power_regulation":
+                raise ValueError("power_error needs Ptarget, which reward_calc defines for power_regulation only")
             Pt = P_REF / pm.SBASE                                       # :245
             if discrete:
                 rewards.append(discrete3(abs(S_PCC.real - Pt) / Pt, 0.01, 0.03))
@@ -224,7 +230,7 @@ class OraclePVDER:
     def reward_calc(self):
         o = self.outputs()
         return reward_terms(self.goals_list[0], self.DISCRETE_REWARD, o.Vrms, self.model.Vrms_ref, o.S_PCC, o.Vdc,
-                            self.Vdc_ref, getattr(self, "reward_spec", None))
+                            self.Vdc_ref, getattr(self, "reward_spec", None), Q_ref=self.Q_ref)
 
     # -- observation (PVDER_env.py:531-542) ------------------------------------------------------
     @property

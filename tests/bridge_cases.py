@@ -1,0 +1,58 @@
+"""Named episodes of the converged fp64 bridge (oracle/pvder_bridge.c, RK45 at rtol 1e-8) that the -m gpu tests
+replay on the device: the case definitions live here, ``tests/golden/make_bridge_goldens.py`` integrates them on
+the CPU (minutes each) and commits ``tests/golden/bridge_<name>.npz``, the tests load them -- the GPU suite no longer
+spends its time in the checker.  Event tables come from the oracle's counter generator, which the device generator
+reproduces bit for bit: a test asserts that equality before it trusts a golden.  BUILD-ORACLE goldens (parity
+unpinned: SURVEY.md 8(c)), not reference outputs."""
+import os
+
+import numpy as np
+
+from helpers import both_events_spec, counter_tables
+from oracle.pvder_oracle_env import DEFAULT_EVENTS_SPEC
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _ramp(action):
+    # the reference's evaluation driver holds ONE action for a whole episode (calc_returns, PVDER_env.py:480-487);
+    # four envs on their own event tables (voltage + insolation), 160 env steps = max_sim_time
+    return dict(N=4, seed=11, spec="both", n=15, steps=160, actions=("const", action))
+
+
+CASES = {
+    "ramp_a1": _ramp(1), "ramp_a2": _ramp(2), "ramp_a3": _ramp(3), "ramp_a4": _ramp(4),
+    # a complete PVDER-v0 episode, random actions (tests of drift: etdlin and ETDRK4 replay it)
+    "episode_random": dict(N=8, seed=1234, spec="both", n=15, steps=160, actions=("random", 2718)),
+}
+
+
+def case_inputs(name):
+    """(event tables [K+1, N] x 2, actions [steps, N], case dict) of a case, from its definition alone."""
+    c = CASES[name]
+    spec = both_events_spec() if c["spec"] == "both" else {k: dict(v) for k, v in DEFAULT_EVENTS_SPEC.items()}
+    vg, si = counter_tables(c["N"], c["seed"], episode=1, spec=spec)
+    kind, arg = c["actions"]
+    if kind == "const":
+        acts = np.full((c["steps"], c["N"]), arg, dtype=np.int64)
+    else:
+        acts = np.random.default_rng(arg).integers(0, 5, size=(c["steps"], c["N"]))
+    return vg, si, acts, dict(c, spec_dict=spec)
+
+
+def path(name):
+    return os.path.join(GOLD, "bridge_%s.npz" % name)
+
+
+def load(name):
+    """The golden of a case: dict with vgrid, sinsol, actions, obs [steps, N, 11], reward, done, m_abs [steps, N]
+    (|m_a| at the end of each step: where the duty cycle saturates the solution stops being reproducible),
+    iref_abs [steps, N]."""
+    p = path(name)
+    if not os.path.exists(p):
+        raise FileNotFoundError("%s missing: run python tests/golden/make_bridge_goldens.py %s" % (p, name))
+    g = dict(np.load(p))
+    vg, si, acts, _ = case_inputs(name)
+    assert np.array_equal(g["vgrid"], vg) and np.array_equal(g["sinsol"], si) and np.array_equal(g["actions"], acts), \
+        "golden %s does not belong to its case definition any more: regenerate it" % name
+    return g

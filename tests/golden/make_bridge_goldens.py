@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Integrate the named bridge episodes of tests/bridge_cases.py on the CPU and store them as
+tests/golden/bridge_<name>.npz (BUILD-ORACLE goldens: parity unpinned, see make_goldens.py).
+
+    python tests/golden/make_bridge_goldens.py [case ...]        (default: every case without a file)
+
+One process per env (the C bridge is single-threaded); ~25 s per env and 160-step episode."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import bridge_cases  # noqa: E402
+from oracle import pvder_model as pm  # noqa: E402
+from oracle.bridge_env import BridgeVecEnv  # noqa: E402
+
+
+def run_env(job):
+    name, e = job
+    vg, si, acts, c = bridge_cases.case_inputs(name)
+    m = pm.build_model("50")
+    ref = BridgeVecEnv(1, n=c["n"], method="rk45", rtol=1e-8, atol=1e-11)
+    ref.reset(vg[:, e:e + 1], si[:, e:e + 1], ev_s0=60, ev_ds=60)
+    obs, rew, done, mabs, iabs = [], [], [], [], []
+    for a in acts[:, e]:
+        o, r, d = ref.step(np.array([a]))
+        obs.append(o[0].copy()); rew.append(r[0]); done.append(d[0])
+        Y = ref.Y[0]
+        mabs.append(abs(complex(Y[2] + m.Kp_GCC * Y[4], Y[3] + m.Kp_GCC * Y[5])))
+        iabs.append(float(np.hypot(Y[19] + m.Kp_DC * (ref.vdcref[0] - Y[18]), Y[20] - m.Kp_Q * (ref.qref[0] - o[0, 5]))))
+    return name, e, np.array(obs), np.array(rew), np.array(done), np.array(mabs), np.array(iabs)
+
+
+def main():
+    names = sys.argv[1:] or [n for n in bridge_cases.CASES if not os.path.exists(bridge_cases.path(n))]
+    jobs = [(n, e) for n in names for e in range(bridge_cases.CASES[n]["N"])]
+    t0 = time.time()
+    with mp.Pool(min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as pool:
+        res = pool.map(run_env, jobs, chunksize=1)
+    for n in names:
+        vg, si, acts, c = bridge_cases.case_inputs(n)
+        mine = sorted([r for r in res if r[0] == n], key=lambda r: r[1])
+        np.savez_compressed(bridge_cases.path(n), vgrid=vg, sinsol=si, actions=acts,
+                            obs=np.stack([r[2] for r in mine], axis=1), reward=np.stack([r[3] for r in mine], axis=1),
+                            done=np.stack([r[4] for r in mine], axis=1), m_abs=np.stack([r[5] for r in mine], axis=1),
+                            iref_abs=np.stack([r[6] for r in mine], axis=1), ev_s0=60, ev_ds=60, n=c["n"],
+                            rtol=1e-8, atol=1e-11)
+        print("%s: %d envs x %d steps" % (n, c["N"], c["steps"]))
+    print("%.0f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

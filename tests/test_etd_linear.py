@@ -112,18 +112,71 @@ def test_f_form_equals_n_form(lin50):
 def test_step_menu_tiles_every_segment(n_sub, micro, s0, ds):
     lens = el.choose_sets(n_sub, micro, s0, ds, 38, 2400)
     t0 = lens[0]
-    assert t0 == el.tick_length(micro) and 2 <= len(lens) <= 8
+    assert t0 == el.tick_length(micro) and 2 <= len(lens) <= 12
     assert len(set(lens[1:])) == len(lens) - 1
-    table = el.build_schedule(n_sub, micro, lens)            # raises if a segment cannot be tiled in 7 steps
-    assert table.shape == (n_sub, el.SCHED_BYTES) and table.dtype == np.uint8
-    for L in range(1, n_sub + 1):                            # tick + listed steps = the segment, 0-terminated
-        steps = [int(s) for s in table[L - 1] if s]
-        assert all(1 <= s < len(lens) for s in steps) and table[L - 1, len(steps)] == 0
-        assert t0 + sum(lens[s] for s in steps) == L * micro, (L, steps)
-        assert len(steps) <= 3 + 2 * int(np.log2(max(L, 1))) + (micro if micro == 1 else 0)
+    table = el.build_schedule(n_sub, micro, lens)
+    assert table.shape[1] == el.SCHED_BYTES and table.shape[0] >= 2 * n_sub and table.dtype == np.uint8
+    for careful in (0, 1):
+        for L in range(1, n_sub + 1):                        # tick + listed steps = the segment
+            steps = el.schedule_steps(table, n_sub, careful * n_sub + L - 1)
+            assert all(1 <= s < len(lens) for s in steps)
+            assert abs(t0 + sum(lens[s] for s in steps) - L * micro) < 1e-9, (L, steps)
+            assert len(steps) <= max(3, el.CAREFUL_STEPS * careful) + 2 * int(np.log2(max(L, 1))) + (micro if micro == 1 else 0)
     if micro >= 4 and micro % 2 == 0 and ds % n_sub == 0 and s0 % n_sub == 0 and n_sub > 1:
-        steps = [int(s) for s in table[n_sub - 1] if s]      # events on env-step boundaries:
-        assert len(steps) == 2 and steps[0] == steps[1] == 1 # tick + two EQUAL steps with set 1, the resident one
+        steps = el.schedule_steps(table, n_sub, n_sub - 1)   # events on env-step boundaries:
+        assert steps == [1, 1]                               # tick + two EQUAL steps with set 1, the resident one
+        assert el.schedule_steps(table, n_sub, 2 * n_sub - 1) == [2] * el.CAREFUL_STEPS      # the careful pass: equal parts
+        assert abs(lens[2] * el.CAREFUL_STEPS - 2 * lens[1]) < 1e-9
+
+
+def test_every_env_step_length_gets_a_schedule():
+    """the default integrator must accept any legal n_sim_time_steps_per_env_step (the reference does,
+    PVDER_env.py:603-620).  Rows that need more than seven steps continue in continuation rows."""
+    for n_sub in list(range(1, 131)) + [200, 351, 500, 1000]:
+        lens = el.choose_sets(n_sub, 32, 60, 60, 38, 2400)
+        assert len(lens) <= 12
+        table = el.build_schedule(n_sub, 32, lens)
+        assert table.shape[0] <= 2 * n_sub + el.SCHED_MAX_CONT
+        for row in range(2 * n_sub):
+            L = row % n_sub + 1
+            steps = el.schedule_steps(table, n_sub, row)
+            assert abs(lens[0] + sum(lens[s] for s in steps) - L * 32) < 1e-9, (n_sub, row)
+        cont = table[2 * n_sub:]
+        assert not (table[:, :7] & 0x80).any()               # a continuation byte only ever sits in the last column
+    with pytest.raises(ValueError):
+        el.build_schedule(3000, 32, el.choose_sets(3000, 32, 60, 60, 38, 2400))
+
+
+def test_current_limit_hybrid_steps_fp64(lin50):
+    """The careful pass's scheme (el.hybrid_step: free / frozen / crossing located / sliding) in numpy fp64 on the
+    balanced model, against LSODA at 1e-10 on the same right-hand side with the reference model's conditional
+    integration: an env pushed into the current limit by a Q_ref ramp, CAREFUL_STEPS hybrid steps per env step
+    (DESIGN.md "careful pass")."""
+    from scipy.integrate import solve_ivp
+    par, c, L, ystar = lin50
+    ilim2 = par[der_model.IDX["IREF_LIMIT"]] ** 2
+    vdc0 = par[der_model.IDX["VDC_REF0"]]
+    f_ref = lambda t, y, inp: el.f_bal_limited(c, y, inp, -1.0, ilim2)
+    # settle at Q_ref = 0.95 pu (|iref| ~ 0.93 of the limit), then ramp Q_ref by 0.0075 pu per env step
+    y = solve_ivp(lambda t, y: el.f_bal(c, y, 1.0, 100.0, 0.95, vdc0), (0, 3.0), ystar, method="LSODA", rtol=1e-10, atol=1e-12).y[:, -1]
+    yr = y.copy()
+    tick = 2 / 1920.0
+    P1 = tick * el.phis(L, tick, 1)[1]
+    M = el.etd3rk_f_matrices(L, (0.25 - tick) / el.CAREFUL_STEPS)
+    worst, evals, crossed = 0.0, 0, False
+    for k in range(24):
+        inp = (1.0, 100.0, 0.95 + 0.0075 * (k + 1), vdc0)
+        yr = solve_ivp(f_ref, (0, 0.25), yr, args=(inp,), method="LSODA", rtol=1e-10, atol=1e-12, max_step=1e-3).y[:, -1]
+        y = y + P1 @ el.f_bal_limited(c, y, inp, -1.0, ilim2)
+        for _ in range(el.CAREFUL_STEPS):
+            y, ne = el.hybrid_step(c, M, y, inp, ilim2)
+            evals += ne
+        crossed = crossed or el.iref2(c, yr, 1.0, inp[2], vdc0) > ilim2
+        sel = [0, 1, 6, 7, 8]
+        worst = max(worst, float(np.linalg.norm((y - yr)[sel]) / np.linalg.norm(yr[sel])))
+    assert crossed, "the scenario must reach the current limit"
+    assert evals > el.CAREFUL_STEPS * 24                   # the crossing / sliding branches ran
+    assert worst < 2e-4, worst
 
 
 @pytest.mark.parametrize("name", ["random_both_n15", "random_both_n4", "vdcalt_both_n15"])

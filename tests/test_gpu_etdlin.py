@@ -449,26 +449,59 @@ def test_fused_rollout_is_graph_capturable(gpu_device):
     assert torch.equal(got, want) and torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate)
 
 
-def test_reactive_power_ramp_far_beyond_the_nominal_point(gpu_device):
+@pytest.mark.parametrize("action", [1, 2, 3, 4])
+def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
     """The reference's own evaluation driver sends ONE action for a whole episode (calc_returns, PVDER_env.py:480-487):
-    action 2 walks Q_ref to -1 pu -- past the range of the linearisation (hand-over to the 23-state ETDRK4 tail at
-    |Q_ref| ~ 0.8 pu) and into the current limit of the inverter.  Trajectory against the converged fp64 bridge: inside
-    the parity bar as a whole, and no single env step further off than 3e-4."""
-    steps = 135
-    env = make_vec(1, gpu_device, seed=1, auto_reset=False)
-    assert env.integrator == "etdlin" and env.micro_coarse == 2          # (two steps per quiet sim time step in the tail)
+    actions 1 / 2 walk Q_ref to +-1.2 pu -- into the inverter's current limit from |Q_ref| ~ 0.9 pu: the careful pass
+    (hybrid ETD3RK steps with the outer loops' conditional integration) --, actions 3 / 4 walk Vdc_ref +9 % / -9 %:
+    action 4 ends at the duty-cycle limit (23-state path on the switched operator sets).  Four envs on their own
+    voltage + insolation events against the committed converged-bridge goldens (tests/golden/bridge_ramp_a*.npz,
+    tests/bridge_cases.py): whole trajectory and worst single env step.  Where the duty cycle has saturated the
+    solution is not reproducible by ANY integrator (DESIGN.md "Saturation"): compared up to there, and beyond it
+    only for what is robust -- finite states, the duty cycle pinned at its limit."""
+    import bridge_cases
+    name = "ramp_a%d" % action
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    env = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"])
+    assert env.integrator == "etdlin" and env.off_range == "integrate"
     env.reset()
-    ref = BridgeVecEnv(1, n=15, method="rk45", rtol=1e-8, atol=1e-11)
-    ref.reset(env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64),
-              ev_s0=env.ev_s0, ev_ds=env.ev_ds)
-    a = torch.full((1,), 2, dtype=torch.uint8, device=gpu_device)
-    got, want = [], []
-    for t in range(steps):
+    # the device generator reproduces the golden's event tables bit for bit
+    assert np.array_equal(env.ev_vg.cpu().numpy(), vg.astype(np.float32)) and np.array_equal(env.ev_si.cpu().numpy(), si.astype(np.float32))
+    a = torch.full((c["N"],), action, dtype=torch.uint8, device=gpu_device)
+    got, mmax = [], []
+    for t in range(c["steps"]):
         obs, rew, done, _ = env.step(a)
-        got.append(obs.cpu().numpy().astype(np.float64)[0]); want.append(ref.step(np.full(1, 2))[0][0])
-    got, want = np.stack(got), np.stack(want)
-    assert float(env.Q_ref[0]) == pytest.approx(-steps * 0.0075, rel=1e-5) and env.step_stats()["n_nonfinite"] == 0
-    per_step = rel_l2(got, want, axis=1)
-    assert per_step[:100].max() < TIGHT * 1.5, per_step[:100].max()      # the fast path, up to |Q_ref| = 0.75 pu
-    assert per_step.max() < 3e-4, (int(per_step.argmax()), per_step.max())
-    assert rel_l2(got.reshape(-1), want.reshape(-1)) < FP32_TOL
+        got.append(obs.cpu().numpy().astype(np.float64))
+        f = env.fstate
+        mmax.append(float(torch.maximum((torch.complex(f[2], f[3]) + 6000.0 * torch.complex(f[4], f[5])).abs(),
+                                        (torch.complex(f[8], f[9]) + 6000.0 * torch.complex(f[10], f[11])).abs()).max()))
+        assert env.step_stats()["n_nonfinite"] == 0
+    got, want = np.stack(got), g["obs"]
+    assert bool(done.all())
+    sat = g["m_abs"].max(axis=1) > 0.999
+    last = int(np.argmax(sat)) if sat.any() else c["steps"]           # first step with a saturated duty cycle in the bridge
+    per_step = rel_l2(got[:last], want[:last], axis=2)
+    traj = rel_l2(got[:last].transpose(1, 0, 2).reshape(c["N"], -1), want[:last].transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
+    if action in (1, 2):
+        assert g["iref_abs"].max() > 1.7316                            # the ramp does reach the current limit
+        free = int(np.argmax(g["iref_abs"].max(axis=1) > 0.9 * 1.7316))
+        assert per_step[:free].max() < TIGHT * 1.5, per_step[:free].max()     # the standard path
+        assert per_step.max() < 1.5e-4, (int(per_step.max(axis=1).argmax()), per_step.max())    # the careful pass
+        assert traj.max() < 5e-5, traj.max()
+    else:
+        assert per_step.max() < 1e-4, (int(per_step.max(axis=1).argmax()), per_step.max())
+        assert traj.max() < TIGHT, traj.max()
+    if action == 4:
+        assert last < c["steps"] - 20 and max(mmax[last:]) > 0.9995   # the scenario saturates the duty cycle ...
+        assert max(mmax) < 1.03                                        # ... which stays pinned at its limit
+        # an env that has left the limit again finds its way back to the converged solution (fp64 prototype of the
+        # switched steps: 1e-2 two env steps behind a saturated stretch, 1e-3 after six)
+        e_all = rel_l2(got, want, axis=2)
+        clear = np.array([g["m_abs"][max(0, t - 8):t + 1].max(axis=0) < 0.985 for t in range(c["steps"])])     # [steps, N]
+        sel = clear[last:]
+        if sel.any():
+            assert e_all[last:][sel].max() < 2e-2, e_all[last:][sel].max()
+
+

@@ -40,10 +40,12 @@ def check(env, goal, discrete, steps, my_spec=None, vdc_row=18):
         r = rew.cpu().numpy().astype(np.float64)
         vdc = env.fstate[vdc_row].cpu().numpy().astype(np.float64)
         vdc_ref = env.Vdc_ref.cpu().numpy().astype(np.float64)
+        q_ref = env.Q_ref.cpu().numpy().astype(np.float64)
         assert np.array_equal(vdc.astype(np.float32), o[:, 6].astype(np.float32))
         for e in range(N):
             vrms = abs(complex(o[e, 2], o[e, 3])) / math.sqrt(2.0)       # balanced: sqrt(sum |v_p|^2 / 3) / sqrt 2
-            want = reward_terms(goal, discrete, vrms, m.Vrms_ref, complex(o[e, 4], o[e, 5]), vdc[e], vdc_ref[e], my_spec)
+            want = reward_terms(goal, discrete, vrms, m.Vrms_ref, complex(o[e, 4], o[e, 5]), vdc[e], vdc_ref[e], my_spec,
+                                Q_ref=q_ref[e])
             if discrete:
                 seen.add(int(r[e]))
                 if r[e] != want:
@@ -51,9 +53,15 @@ def check(env, goal, discrete, steps, my_spec=None, vdc_row=18):
                            "power_regulation": abs(o[e, 4] - P_REF / pm.SBASE) / (P_REF / pm.SBASE),
                            "Q_regulation": abs(o[e, 5] - Q_REF_TARGET / pm.SBASE) / (Q_REF_TARGET / pm.SBASE)}[goal]
                     evdc = abs(vdc[e] - vdc_ref[e]) / vdc_ref[e]
+                    qt = (q_ref[e] if q_ref[e] != 0.0 else 1e-6) if goal == "voltage_regulation" else Q_REF_TARGET / pm.SBASE
+                    eq = abs(o[e, 5] - qt) / abs(qt)
+                    ev = abs(vrms - m.Vrms_ref) / m.Vrms_ref
+                    extra = my_spec or []
                     close = min(abs(err - t) for t in thresholds) < 1e-6 or \
-                        (my_spec and "Vdc_error" in my_spec and min(abs(evdc - t) for t in (0.02, 0.05)) < 1e-6)
-                    assert close, (goal, e, r[e], want, err, evdc)
+                        ("Vdc_error" in extra and min(abs(evdc - t) for t in (0.02, 0.05)) < 1e-6) or \
+                        ("Q_error" in extra and min(abs(eq - t) for t in (0.01, 0.05)) < 2e-6 * max(1.0, eq)) or \
+                        ("voltage_error" in extra and min(abs(ev - t) for t in (0.01, 0.05)) < 1e-6)
+                    assert close, (goal, e, r[e], want, err, evdc, eq, ev)
                     near += 1
             else:
                 assert abs(r[e] - want) <= 2e-6 * max(1.0, abs(want)) + 1e-9, (goal, e, r[e], want)
@@ -108,6 +116,42 @@ def test_vdc_error_term_of_my_spec(gpu_device, discrete):
     other = make_vec(gpu_device, goals_list=["voltage_regulation"])
     with pytest.raises(ValueError):
         other.set_reward_spec(["voltage_error", "Vdc_error"])         # Vdctarget exists for power_regulation only
+
+
+@pytest.mark.parametrize("discrete", [True, False])
+def test_q_error_term_under_voltage_regulation(gpu_device, discrete):
+    """voltage_regulation with my_spec = [voltage_error, Q_error] (PVDER_env.py:249, :263-275): Qtarget is the env's
+    own PV_model.Q_ref (:238), and 1e-6 where that is 0 in the discrete branch (:266-267).  Q_ref from -0.3 to
+    +0.3 pu with every 16th env at exactly 0; a few steps after the jump Q_PCC is still on its way to the target,
+    so the 1 % / 5 % ladder sees both thresholds from both sides; the grid voltage sweep moves the other term."""
+    env = make_vec(gpu_device, goals_list=["voltage_regulation"], DISCRETE_REWARD=discrete)
+    env.set_reward_spec(["voltage_error", "Q_error"])
+    env.reset()
+    tables(env, np.linspace(0.93, 1.07, N), np.full(N, 100.0))
+    env.reset()
+    q = torch.linspace(-0.3, 0.3, N, device=gpu_device)
+    q[::16] = 0.0
+    env.fstate[23].copy_(q)
+    seen, near = check(env, "voltage_regulation", discrete, steps=6, my_spec=["voltage_error", "Q_error"])
+    if discrete:
+        assert {2, 0, -4, -6, -10} & seen and len(seen) >= 4          # sums of two ladders
+    with pytest.raises(ValueError):
+        env.set_reward_spec(["Q_error"])                              # the required term must stay
+    with pytest.raises(ValueError):
+        env.set_reward_spec(["voltage_error", "power_error"])         # Ptarget exists for power_regulation only
+
+
+@pytest.mark.parametrize("goal", ["power_regulation", "Q_regulation"])
+def test_voltage_error_term_under_the_other_goals(gpu_device, goal):
+    """my_spec = [required, voltage_error]: voltage_error needs no target, so reward_calc evaluates it under any goal"""
+    req = {"power_regulation": "power_error", "Q_regulation": "Q_error"}[goal]
+    env = make_vec(gpu_device, goals_list=[goal], DISCRETE_REWARD=True)
+    env.set_reward_spec([req, "voltage_error"])
+    env.reset()
+    tables(env, np.linspace(0.93, 1.07, N), np.full(N, 100.0))
+    env.reset()
+    seen, near = check(env, goal, True, steps=3, my_spec=[req, "voltage_error"])
+    assert len(seen) >= 3
 
 
 def test_done_by_max_sim_time_and_by_time_limit(gpu_device):

@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
     assert agent == sorted(_native.AGENT_SYMBOLS)
     for sym in agent:
         assert hasattr(L, sym), sym
-    assert L.pvder_version() == _native.ABI_VERSION == 9
+    assert L.pvder_version() == _native.ABI_VERSION == 10
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
     assert L.pvder_block_size() % 64 == 0
@@ -228,12 +228,41 @@ def test_etdrk4_coefficient_block_matches_independent_phi_functions():
     cfg = _native.StepCfg()
     cfg.n_sub, cfg.micro, cfg.micro_coarse, cfg.graded = 15, micro, coarse, 1
     n = L_.pvder_etdrk4_coef_count()
-    assert n == 3 * 13 * 8
+    assert n == 3 * 13 * 8 + 3 * 4 * 13 * 16           # complex 2x2 block + the switched block (4 anti-windup modes, real 4x4)
     host = (ctypes.c_float * n)()
     par_c = (ctypes.c_double * len(par))(*par)
     assert L_.pvder_etdrk4_coefficients(par_c, ctypes.byref(cfg), host) == 0
-    got = np.array(list(host), dtype=np.float64).reshape(3, 13, 4, 2)
+    full = np.array(list(host), dtype=np.float64)
+    got = full[:3 * 13 * 8].reshape(3, 13, 4, 2)
     got = got[..., 0] + 1j * got[..., 1]                                   # [set, matrix, entry 11,12,21,22]
+    # ---- the switched block: [set][mode][matrix][(M0k, M1k) k = 0..3, (M2k, M3k) k = 0..3] on (iR, iI, uR, uI)
+    sw = full[3 * 13 * 8:].reshape(3, 4, 13, 2, 4, 2)                      # [set, mode, matrix, row pair, column, row in pair]
+    sw = sw.transpose(0, 1, 2, 3, 5, 4).reshape(3, 4, 13, 4, 4)            # -> [.., row, column]
+    emb = lambda z: np.array([[z.real, -z.imag], [z.imag, z.real]])        # complex scalar as a real 2x2
+    for s in range(3):
+        for k in range(13):
+            G = got[s, k].reshape(2, 2)
+            W = np.block([[emb(G[0, 0]), emb(G[0, 1])], [emb(G[1, 0]), emb(G[1, 1])]])
+            assert np.abs(sw[s, 0, k] - W).max() <= 3e-6 * max(np.abs(W).max(), 1e-12) + 1e-12, (s, k)   # mode 0 = the complex block
+    # a frozen component of u: its row of Lz zeroed -> phi_0 keeps that component, the other matrices never feed it
+    Lr = np.block([[emb(-Z0), emb(complex(c0 * par[P["KP_GCC"]]))], [emb(complex(-par[P["WP"]])), emb(complex(-par[P["WP"]]))]])
+    for mode in (1, 2, 3):
+        Lm = Lr.copy()
+        for bit, row in ((1, 2), (2, 3)):
+            if mode & bit:
+                Lm[row] = 0.0
+        for s, h in enumerate((1.0 / (60 * micro), 1.0 / (60 * coarse), (1.0 - 1.0 / micro) / 60.0)):
+            E = expm(h * Lm)
+            assert np.abs(sw[s, mode, 1] - E).max() <= 3e-6 * np.abs(E).max()            # EM_E = phi_0(h L_mode)
+            M = np.zeros((8, 8)); M[:4, :4] = h * Lm; M[:4, 4:] = np.eye(4)
+            f1 = expm(M)[:4, 4:]
+            B = sw[s, mode, 6] + sw[s, mode, 11] + sw[s, mode, 12]                       # b1 + b4 + b5 = h phi_1(h L_mode)
+            assert np.abs(B - h * f1).max() <= 1e-5 * np.abs(h * f1).max()
+            for row in ([2] if mode & 1 else []) + ([3] if mode & 2 else []):
+                assert np.allclose(sw[s, mode, 1][row], np.eye(4)[row], atol=1e-7)
+                for k in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+                    off = np.delete(sw[s, mode, k][row], row)
+                    assert np.abs(off).max() < 1e-7, (mode, s, k)        # a frozen row only sees its own N (which is blanked)
     for s, h in enumerate((1.0 / (60 * micro), 1.0 / (60 * coarse), (1.0 - 1.0 / micro) / 60.0)):
         f, g = phis(h), phis(h / 2)                                        # phi_k(hL), phi_k(hL/2)
         a52 = 0.5 * g[2] - f[3] + 0.25 * f[2] - 0.5 * g[3]
