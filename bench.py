@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the batched PVDER-v0 hot path on N MI355X (contract: task statement).
 
-Default integrator: etdlin -- fp32 ETD3RK (Cox-Matthews exponential Runge-Kutta) on the model linearised
-at its nominal operating point: the full 11x11 Jacobian sits in the matrix exponential, so an env step
+Default integrator: etdlin -- fp32 ETD3RK (Cox-Matthews exponential Runge-Kutta) on the FULL nonlinear model,
+split as f(y) = L y + N(y) with L = its 11x11 Jacobian at the nominal operating point: L sits in the matrix
+exponential (nothing of the model is approximated -- N = f - L y is integrated by the stages), so an env step
 is an exponential-Euler tick of 2/1920 s behind the action / event jump + TWO equal ETD3RK steps over
 the rest, with the dense matrix-vector products on the matrix cores (fp32 MFMA); `--integrator etdrk4`
 is round 1's 16-step scheme, the literal classic-RK4 kernel is timed in the same run ("classic_rk4").
@@ -73,6 +74,8 @@ def parse(argv=None):
     ap.add_argument("--integrator", default="etdlin", choices=["etdlin", "etdrk4", "rk4", "rk45"])
     ap.add_argument("--classic-steps", type=int, default=3, help="classic-RK4 steps timed beside the main run (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
+    ap.add_argument("--fixed-policy", type=int, default=1, help="1: time the four fixed-action ramps of calc_returns' kind (0 = skip)")
+    ap.add_argument("--rk45-steps", type=int, default=2, help="fp64 RK45 steps (BASELINE configs[4]) timed beside the main run (0 = skip)")
     ap.add_argument("--time-every", type=int, default=64,
                     help="bracket every K-th step kernel with HIP events (clamped so that even a short run gets samples); 0 = none")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
@@ -212,6 +215,71 @@ def classic_rk4_leg(torch, dev, N, n_sub, steps):
     return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "micro_steps": 4096,
             "kernel": KERNEL_NAME["rk4"], "kernel_avg_ms": avg * 1e3,
             "valu_frac": fl / VALU_PEAK_F32, "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / avg / HBM_PEAK}
+
+
+def fixed_policy_leg(torch, dev, N, n_sub):
+    """The reference's evaluation driver holds ONE action for a whole episode (calc_returns, PVDER_env.py:480-487:
+    'dec' -> action 1, 'no_change' -> action 2; actions 3 / 4 are the Vdc_ref counterparts): 160 env steps each,
+    same envs and events as the headline, one launch per env step, timed in 10-step blocks with HIP events.
+    Action 1 / 2 end at the inverter's current limit (careful pass), action 4 at the duty-cycle limit (23-state
+    path on the switched operator sets): what a policy that holds an action costs the whole batch."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    out = {}
+    for act, name in ((1, "dec: action 1, Q_ref +375 VAR per step"), (2, "no_change: action 2, Q_ref -375 VAR per step"),
+                      (3, "action 3, Vdc_ref +0.3 V per step"), (4, "action 4, Vdc_ref -0.3 V per step")):
+        env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2024, events_spec=events_on_spec(),
+                       auto_reset=False)
+        env.reset()
+        acts = torch.full((10, N), act, dtype=torch.uint8, device=dev)
+        n_blocks = 16 if n_sub == 15 else max(1, int(env.max_sim_time * 60 / n_sub) // 10)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_blocks + 1)]
+        torch.cuda.synchronize(dev)
+        ev[0].record()
+        for b in range(n_blocks):
+            env.rollout(acts, fused=False)
+            ev[b + 1].record()
+        torch.cuda.synchronize(dev)
+        blocks = [ev[b].elapsed_time(ev[b + 1]) * 100.0 for b in range(n_blocks)]       # us per step
+        st = env.step_stats()
+        out["action_%d" % act] = {"policy": name, "steps": 10 * n_blocks, "mean_us_per_step": sum(blocks) / len(blocks),
+                                  "worst_10_step_block_us_per_step": max(blocks),
+                                  "us_per_step_by_10_step_block": [round(b, 1) for b in blocks],
+                                  "n_nonfinite": st["n_nonfinite"], "Q_ref_end": float(env.Q_ref[0]), "Vdc_ref_end": float(env.Vdc_ref[0])}
+    out["mean_us_per_step_all_four"] = sum(v["mean_us_per_step"] for v in out.values()) / 4.0
+    out["note"] = ("%d envs, off_range='integrate' (the default: nothing terminates); parity of these ramps against the converged "
+                   "bridge: tests/test_gpu_etdlin.py::test_fixed_action_ramps_vs_converged_bridge" % N)
+    return out
+
+
+def rk45_leg(torch, dev, N, n_sub, steps=2):
+    """BASELINE configs[4]: the same batch through the fp64 adaptive Dormand-Prince kernel (rtol 1e-6, atol 1e-8) --
+    the tolerance-match path; stability-bound at h ~ 4 us."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, integrator="rk45", seed=2024,
+                   events_spec=events_on_spec(), auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    acts = torch.randint(0, 5, (steps + 1, N), generator=gen, device=dev, dtype=torch.uint8)
+    env.step(acts[0], return_tensors=False)
+    r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    r0.record()
+    for i in range(1, steps + 1):
+        env.step(acts[i], return_tensors=False)
+    r1.record()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    h = env.hstep[env.hstep > 0]
+    spe = float((n_sub / 60.0) / float(h.double().mean().item())) if h.numel() else None
+    avg = r0.elapsed_time(r1) * 1e-3 / steps
+    fl = (7 * 300 + 23 * 60) * spe * N / avg if spe else None
+    return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "dtype": "f64", "rtol": env.rtol, "atol": env.atol,
+            "workload": "BASELINE configs[4]: %d envs, fp64 adaptive RK45, same events and random actions" % N,
+            "kernel": KERNEL_NAME["rk45"], "ms_per_step": 1e3 * el / steps, "kernel_avg_ms": avg * 1e3,
+            "integrator_steps_per_env_step": spe, "valu_f64_frac": finite(fl / VALU_PEAK_F64) if fl else None,
+            "hbm_frac": BYTES_PER_ENV_STEP["f64"] * N / avg / HBM_PEAK, "n_nonfinite": env.step_stats()["n_nonfinite"]}
 
 
 def kernel_source_hash() -> str:
@@ -540,7 +608,13 @@ def run_rank(args):
         fused_leg = {"value": N * reps * Kf / el_f, "unit": "env-steps/s", "steps_per_launch": Kf, "launches": reps,
                      "seconds": el_f, "ms_per_step": 1e3 * per, "region_ms_per_step": r0.elapsed_time(r1) / (reps * Kf),
                      "per_step_output_blocks": blocks is not None,
-                     "hbm_frac_on_269B_per_env_step": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK,
+                     # what a step of a fused rollout really moves: its 13 output rows, its action byte, the two event
+                     # inputs; the 25 state rows + counters are read and written once per LAUNCH
+                     "bytes_per_env_step_actual": 13 * 4 + 1 + 8 + (2 * 25 * 4 + 5 * 4) / float(Kf),
+                     "hbm_frac_actual": (13 * 4 + 1 + 8 + (2 * 25 * 4 + 5 * 4) / float(Kf)) * N / per / HBM_PEAK,
+                     "nominal_frac_on_269B_per_env_step": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK,
+                     "nominal_frac_note": "269 B is what ONE LAUNCH PER STEP moves per env step; a fused rollout keeps the state on "
+                                          "the chip, so this figure compares rates, it is not HBM utilisation (hbm_frac_actual is)",
                      "kernel": "step_etdlin_rollout_kernel<3> (+ step_etdlin_finish_kernel<3> for the step that ends an episode)",
                      "note": "same envs, events and random actions as the headline; results bit-identical to one launch per "
                              "step (tests/test_gpu_etdlin.py::test_fused_rollout_equals_single_steps); NOT the headline"}
@@ -618,8 +692,8 @@ def run_rank(args):
             "config": {"workload": ("BASELINE configs[2]" if (N, args.n_sub) == (65536, 15) else "variant of BASELINE configs[2]") +
                                    ": %d parallel PVDER-v0 envs per GPU, n=%d sim time steps "
                                    "per env step, voltage+insolation events on, %s, random actions, auto-reset"
-                                   % (N, args.n_sub, {"etdlin": "fp32 ETD3RK on the model linearised at its operating point (exponential RK, full "
-                                                                "11x11 Jacobian in the exponential, matrix-vector products on the matrix cores), "
+                                   % (N, args.n_sub, {"etdlin": "fp32 ETD3RK on the full nonlinear model, f = L y + N(y) (exponential RK: the 11x11 Jacobian at the "
+                                                                "operating point in the exponential, N in the stages; matrix-vector products on the matrix cores), "
                                                                 "per segment between input jumps: exponential-Euler tick of 2/(60*%d) s + two "
                                                                 "equal ETD3RK steps" % args.micro,
                                                       "etdrk4": ("fp32 ETDRK4 (exponential RK, stiff order 4, 5 stages), sim time step behind an input jump: "
@@ -662,6 +736,13 @@ def run_rank(args):
             # ~153 GB/s bidirectional per GPU, i.e. ~77 GB/s into a GPU per link, all peers in parallel)
             blk = 13 * N * 4
             out["compute_only"] = compute_only
+            recv = (world - 1) * blk
+            out["xgmi_roofline"] = {"bound": "xgmi", "bytes_received_per_step_per_gpu": recv,
+                                    "achieved": finite(recv / (elapsed / args.steps) / 1e9), "peak": 7 * 76.5, "unit": "GB/s",
+                                    "frac": finite(recv / (elapsed / args.steps) / (7 * 76.5e9)),
+                                    "frac_of_the_links_in_use": finite(recv / (elapsed / args.steps) / (max(world - 1, 1) * 76.5e9)),
+                                    "note": "bytes a GPU receives per step / step time, against 7 links x 76.5 GB/s into one GPU "
+                                            "(MI355X_MICROARCH.md); with fewer than 8 ranks only world-1 links carry data"}
             out["xgmi_bound"] = {"bytes_received_per_step_per_gpu": (world - 1) * blk,
                                  "link_GBps_one_direction": 76.5,
                                  "min_us_per_step": blk / 76.5e9 * 1e6 if world > 1 else 0.0,
@@ -669,6 +750,15 @@ def run_rank(args):
                                          "gather of one step cannot finish faster than one block over one link"}
         if world == 1 and args.classic_steps > 0 and args.integrator in ("etdrk4", "etdlin"):
             out["classic_rk4"] = classic_rk4_leg(torch, dev, N, args.n_sub, args.classic_steps)
+        if world == 1 and dist is None and args.integrator == "etdlin":
+            del env, actions                         # (the side legs build their own envs)
+            try:
+                if args.fixed_policy:
+                    out["fixed_policy"] = fixed_policy_leg(torch, dev, N, args.n_sub)
+                if args.rk45_steps > 0:
+                    out["rk45"] = rk45_leg(torch, dev, N, args.n_sub, args.rk45_steps)
+            except Exception as exc:                 # side legs: never lose the headline over them
+                warnings.append("side leg failed: %r" % (exc,))
         out.update(cpu)
         if warnings:
             out["warnings"] = warnings

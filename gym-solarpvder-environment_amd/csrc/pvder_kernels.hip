@@ -27,6 +27,7 @@
 // by all envs -- a GEMM with one operand per parameter set and one column per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <math.h>
 #include <stdlib.h>
 #include <complex>
@@ -883,12 +884,16 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
             const bool input_jump = row != prev_row;          // a grid-voltage / insolation event starts here
             prev_row = row;
             // two-rate schedule: the sim time step that starts at an input jump (new action: s == 0;
-            // new event row) takes C.micro steps, every other one C.micro2 (DESIGN.md "Step schedule")
-            // (wave-uniform: if any env of the wave has a jump here the whole wave takes the fine rate --
-            // never less accurate, and the step loop keeps a scalar trip count)
-            const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
-            const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
+            // new event row) takes C.micro steps, every other one C.micro2 (DESIGN.md "Step schedule").
+            // PER LANE: the lanes whose env has a jump here take the fine pass, the others the coarse one (a wave
+            // whose envs run in step executes one of the two) -- an env's trajectory does not depend on which envs
+            // share its wave (round 1 took the fine rate for the whole wave if ANY lane had a jump)
+            const bool lane_fine = (s == 0) || input_jump;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
+            for (int pass = 0; pass < 2; ++pass) {
+            const bool fine = pass == 0;
+            if (lane_fine != fine) continue;
+            const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
             float t0 = 0.f;                                   // 2*theta (turns) since the start of this sim time step
             for (int j = 0; j < nst; ++j) {
                 // graded schedule: first step 1/(60 micro), then ONE step over the remainder
@@ -999,6 +1004,7 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                     }
                 }
                 t0 = t2;
+            }
             }
         }
         from_pairs(y, ys);
@@ -1140,10 +1146,15 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
             if (s < 16) PVDER_TRACE_AT(3 + s);
             const bool input_jump = row != prev_row;
             prev_row = row;
-            // two-rate schedule, wave-uniform (see etdrk4_full_tail)
-            const bool fine = __builtin_amdgcn_readfirstlane(__any((int)((s == 0) || input_jump))) != 0;
-            const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
+            // two-rate schedule, per lane (see etdrk4_full_tail): fine pass for the lanes with a jump here, coarse
+            // pass for the others; envs in step (PVDER-v0 rollouts) execute one of the two
+            const bool lane_fine = (s == 0) || input_jump;
             pvder::make_sub_pk(P, ev_vg[(size_t)row * N + L.ec], ev_si[(size_t)row * N + L.ec], S);
+            for (int pass = 0; pass < 2; ++pass) {
+            const bool fine = pass == 0;
+            const bool mine = lane_fine == fine;          // (every lane computes; the lanes of this pass commit: no exec games)
+            if (!__builtin_amdgcn_readfirstlane(__any((int)mine))) continue;
+            const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
             for (int j = 0; j < nst; ++j) {
                 // graded schedule: first step 1/(60 micro), then ONE step over the remainder
                 const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
@@ -1201,14 +1212,17 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A
                 matvec(mB5, ni, nu, zi, zu);
                 // Kahan-compensated slow update:  y+ = y + h (N1 + N4)/6 + 2h N5/3
                 v2 inc, tsum;
-                inc = pvder::fma2(h23, ns[0], pvder::fma2(h6, k14[0], -cx)); tsum = xa + inc; cx = (tsum - xa) - inc; const v2 xn = tsum;
-                inc = pvder::fma2(h23, ns[1], pvder::fma2(h6, k14[1], -cv)); tsum = pa + inc; cv = (tsum - pa) - inc; const v2 vn = tsum;
-                inc = pvder::fma2(h23, ns[2], pvder::fma2(h6, k14[2], -cq)); tsum = pb + inc; cq = (tsum - pb) - inc; const v2 qn = tsum;
-                inc = pvder::fma2(h23, ns[3], pvder::fma2(h6, k14[3], -cd)); tsum = dl + inc; cd = (tsum - dl) - inc; const v2 dn = tsum;
+                v2 ncx, ncv, ncq, ncd;
+                inc = pvder::fma2(h23, ns[0], pvder::fma2(h6, k14[0], -cx)); tsum = xa + inc; ncx = (tsum - xa) - inc; const v2 xn = tsum;
+                inc = pvder::fma2(h23, ns[1], pvder::fma2(h6, k14[1], -cv)); tsum = pa + inc; ncv = (tsum - pa) - inc; const v2 vn = tsum;
+                inc = pvder::fma2(h23, ns[2], pvder::fma2(h6, k14[2], -cq)); tsum = pb + inc; ncq = (tsum - pb) - inc; const v2 qn = tsum;
+                inc = pvder::fma2(h23, ns[3], pvder::fma2(h6, k14[3], -cd)); tsum = dl + inc; ncd = (tsum - dl) - inc; const v2 dn = tsum;
                 const v2 mn = pvder::fma2(pvder::bc2(P.KpG), zu, xn);
                 // near duty-cycle saturation or the current limit: the 23-state path redoes this env step
-                defer |= fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
-                ia = zi; ua = zu; xa = xn; pa = vn; pb = qn; dl = dn;
+                defer |= mine && fmaxf(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)), ir2a * i2m) > guard;
+                ia = mine ? zi : ia; ua = mine ? zu : ua; xa = mine ? xn : xa; pa = mine ? vn : pa; pb = mine ? qn : pb; dl = mine ? dn : dl;
+                cx = mine ? ncx : cx; cv = mine ? ncv : cv; cq = mine ? ncq : cq; cd = mine ? ncd : cd;
+            }
             }
             {   // branch-free (a per-lane branch here costs an exec-mask save in an SGPR-starved kernel)
                 const bool chg = --until == 0;
@@ -1874,6 +1888,10 @@ struct LinHead {
     int n_env, pad;
 };
 constexpr int kLinHeadBytes = (int)sizeof(LinHead);
+// lin_step_body / the 23-state tail re-read G (and G.A at its start) from the kernel-argument segment at this byte
+// offset: the by-value LinArgs must follow the head without padding, and the blocks the tails re-read sit at offset 0
+static_assert(alignof(LinArgs) <= 8 && sizeof(LinHead) % alignof(LinArgs) == 0, "LinArgs must start right behind LinHead");
+static_assert(offsetof(LinArgs, A) == 0, "the 23-state tail reads EtdArgs at the start of LinArgs");
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
@@ -1913,6 +1931,7 @@ struct RollArgs {
     LinArgs G;                       // at kernarg offset 0 (the 23-state tail of the finish kernel re-reads G.A from there)
     RollK Rk;
 };
+static_assert(offsetof(RollArgs, G) == 0, "the finish kernel's tail reads LinArgs / EtdArgs at kernarg offset 0");
 typedef __attribute__((address_space(4))) const RollArgs *RollKernargPtr;
 // the kernel arguments through a laundered copy of the kernarg pointer: hipcc must re-read what it needs
 // (scalar loads, cache hits) instead of keeping hundreds of loop-invariant values -- parameters copied
@@ -2848,12 +2867,22 @@ int pvder_gather_create(pvder_gather **out, void *nccl_all_gather, void *comm) {
     g->all_gather = (nccl_all_gather_fn)nccl_all_gather;
     g->comm = comm;
     g->pending[0] = g->pending[1] = false;
+    g->stream = nullptr;
+    g->ready[0] = g->ready[1] = g->done[0] = g->done[1] = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&g->ready[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done[b], hipEventDisableTiming);
     }
-    if (e != hipSuccess) { delete g; return hip_rc(e); }
+    if (e != hipSuccess) {                       // partial initialisation: release what was created
+        for (int b = 0; b < 2; ++b) {
+            if (g->ready[b]) (void)hipEventDestroy(g->ready[b]);
+            if (g->done[b]) (void)hipEventDestroy(g->done[b]);
+        }
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+        delete g;
+        return hip_rc(e);
+    }
     *out = g;
     return 0;
 }

@@ -160,7 +160,9 @@ class NativeStepGather:
         with torch.cuda.device(env.device):
             _native.check(self._lib.pvder_gather_create(C.byref(self._h), fn, rccl._comm), "pvder_gather_create")
         n = env.num_envs
-        self.out = [env.out, torch.empty_like(env.out)]
+        # (the second block starts as a copy of the first: without auto-reset the first step carries the stale tuples
+        # of finished envs over from "the other block", which must hold them)
+        self.out = [env.out, env.out.clone()]
         self.recv = [torch.empty((self.world * 13, n), dtype=torch.float32, device=env.device) for _ in range(2)]
         self._k = 0
 

@@ -358,8 +358,11 @@ class PVDER(EnvSpecMixin):
         step size, episode length, reward type, integrator and event spec."""
         from ..evaluate import calc_returns as batched
         v = self._vec
+        model_type = [k for k, spec in v.env_model_spec.items() if spec['derId'] == v.der_id][0]
         kw = dict(n_sim_time_steps_per_env_step=v.n_sim_time_steps_per_env_step, max_sim_time=self.max_sim_time_user,
-                  DISCRETE_REWARD=v.DISCRETE_REWARD, integrator=v.integrator, events_spec=v.env_events_spec)
+                  DISCRETE_REWARD=v.DISCRETE_REWARD, integrator=v.integrator, events_spec=v.env_events_spec,
+                  model_type=model_type, der_config=v.der_config, micro_steps=v.micro_steps, micro_coarse=v.micro_coarse,
+                  off_range=v.off_range)                 # the env itself is what the reference evaluates (:458-497)
         for goal in v.env_goal_spec:
             print('Calculating average return for "{}" goal with "random", "inc", "dec", "no_change" actions.'.format(goal))
         self.env_average_return = batched(episodes=episodes, device=v.device, seed=v.seed, **kw)
