@@ -91,6 +91,10 @@ def parse(argv=None):
     ap.add_argument("--fused-steps", type=int, default=160, help="env steps per fused launch in that leg")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: all-gather issued directly into RCCL (default) or through torch.distributed")
+    ap.add_argument("--payload", default="full", choices=["full", "reward_done", "full_every_k"],
+                    help="N > 1: what a step collates -- the whole [13, N_local] block (default: what BASELINE configs[3] "
+                         "names), (reward, done) only, or (reward, done) with the whole block every --gather-every steps")
+    ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--sync-gather", type=int, default=0,
                     help="1: wait for each step's all-gather before the next step (no compute/comm overlap)")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -101,6 +105,26 @@ def parse(argv=None):
 # ---------------------------------------------------------------------------------------------------
 # rank launcher: `python bench.py --gpus N` outside torchrun
 # ---------------------------------------------------------------------------------------------------
+def visible_gpu_count(sysfs: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process would see, WITHOUT loading the HIP runtime (the parent that starts the ranks must not touch
+    the GPU): the length of ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set, else the
+    KFD topology nodes with compute units (simd_count > 0; CPU nodes report 0).  -1: cannot tell (no KFD sysfs)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        n = 0
+        for node in os.listdir(sysfs):
+            with open(os.path.join(sysfs, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except OSError:
+        return -1
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -402,6 +426,7 @@ def run_rank(args):
                 from gym_PVDER_amd.distributed import RcclAllGather
                 direct = RcclAllGather(dev)
                 native = direct.native(env)          # step launch + gather enqueued from C (one host call per rollout)
+                native.payload, native.gather_every = args.payload, args.gather_every
                 collective = ("ncclAllGather (RCCL) issued by the C side right behind each step launch "
                               "(pvder_plan_rollout_gather), own stream, two output blocks")
             except Exception as exc:          # keep the run: fall back to the c10d path on every rank
@@ -736,7 +761,16 @@ def run_rank(args):
             # ~153 GB/s bidirectional per GPU, i.e. ~77 GB/s into a GPU per link, all peers in parallel)
             blk = 13 * N * 4
             out["compute_only"] = compute_only
-            recv = (world - 1) * blk
+            rows = 13.0
+            if native is not None and args.payload == "reward_done":
+                rows = 2.0
+            elif native is not None and args.payload == "full_every_k" and args.gather_every > 1:
+                rows = 2.0 + 11.0 / args.gather_every
+            elif args.payload != "full":
+                warnings.append("--payload %s needs the C-side step+gather path: the whole block was collated" % args.payload)
+            out["config"]["payload"] = {"mode": args.payload if native is not None else "full", "rows_per_step": rows,
+                                        "gather_every": args.gather_every if args.payload == "full_every_k" else None}
+            recv = (world - 1) * blk * rows / 13.0
             out["xgmi_roofline"] = {"bound": "xgmi", "bytes_received_per_step_per_gpu": recv,
                                     "achieved": finite(recv / (elapsed / args.steps) / 1e9), "peak": 7 * 76.5, "unit": "GB/s",
                                     "frac": finite(recv / (elapsed / args.steps) / (7 * 76.5e9)),
@@ -781,9 +815,8 @@ def main():
         return launch_ranks(max(1, args.gpus), sys.argv[1:])
     if not in_group and args.gpus > 1:
         # outside torchrun: start the ranks ourselves -- BEFORE this process makes any GPU call
-        import torch
-        have = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
-        if have < args.gpus:
+        have = visible_gpu_count()                  # from the environment / KFD sysfs: no HIP call in this process
+        if 0 <= have < args.gpus:
             print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
             return 2
         from gym_PVDER_amd import _native

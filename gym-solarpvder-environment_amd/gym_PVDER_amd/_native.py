@@ -28,7 +28,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients", "pvder_lin_set_floats", "pvder_lin_max_sets",
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
-           "pvder_plan_rollout_gather", "pvder_plan_rollout_fused"]
+           "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows"]
 AGENT_SYMBOLS = ["pvder_qagent_step_f32"]            # include/pvder_agent.h
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
@@ -168,6 +168,9 @@ def lib() -> C.CDLL:
     L.pvder_gather_drain.argtypes = [vp, vp]
     L.pvder_plan_rollout_gather.restype = i32
     L.pvder_plan_rollout_gather.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32]
+    L.pvder_plan_rollout_gather_rows.restype = i32
+    L.pvder_plan_rollout_gather_rows.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+                                                 C.c_longlong]
     _lib = L
     return L
 

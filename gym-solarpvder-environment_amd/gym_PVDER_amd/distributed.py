@@ -39,6 +39,33 @@ def gather_outputs(out_local: torch.Tensor, buf: Optional[torch.Tensor] = None, 
     return buf
 
 
+# What a step collates (DESIGN.md "Multi-GPU"): the whole [13, N_local] block is what the north_star asks for and what
+# the default does; at 65 536 envs per GPU it is 3.4 MB per peer and step -- 44 us on one xGMI link against an 8 us step
+# kernel -- so a consumer that evaluates its policy where the env lives can ask for less:
+#   "full"         rows 0..12 every step
+#   "reward_done"  rows 11, 12 (reward, done) every step: 0.5 MB per peer
+#   "full_every_k" (reward, done) every step, the whole block every k-th step
+PAYLOADS = ("full", "reward_done", "full_every_k")
+REWARD_ROW = 11
+
+
+def payload_rows(payload: str, step_index: int, every: int = 1) -> Tuple[int, int]:
+    """(first row, number of rows) of the [13, N] output block that step number ``step_index`` (0-based) collates."""
+    if payload not in PAYLOADS:
+        raise ValueError("payload must be one of %s" % (PAYLOADS,))
+    if payload == "full" or (payload == "full_every_k" and every > 1 and (step_index + 1) % every == 0):
+        return 0, 13
+    if payload == "full_every_k" and every <= 1:
+        return 0, 13
+    return REWARD_ROW, 2
+
+
+def gather_payload(out_local: torch.Tensor, step_index: int, payload: str = "full", every: int = 1, group=None):
+    """One step's collective with a payload choice: returns (gathered [world, rows, N_local], first row, rows)."""
+    r0, nr = payload_rows(payload, step_index, every)
+    return gather_outputs(out_local[r0:r0 + nr], None, group), r0, nr
+
+
 def global_view(gathered: torch.Tensor) -> torch.Tensor:
     """[world, R, N_local] -> [N_total, R] (a strided view, no copy): row g = global env g."""
     w, r, n = gathered.shape
@@ -52,8 +79,13 @@ class ShardedPVDERVec:
     GLOBAL (obs[N_total, 11], reward[N_total], done[N_total]) collated by one all-gather.
     """
 
-    def __init__(self, total_envs: int, device, group=None, **env_kwargs):
+    def __init__(self, total_envs: int, device, group=None, payload: str = "full", gather_every: int = 1, **env_kwargs):
+        """``payload`` / ``gather_every``: what a step collates (PAYLOADS).  With "reward_done" / "full_every_k" a step
+        returns the GLOBAL reward and done and, on the steps without the whole block, ``None`` for the observation
+        (the local shard's is ``self.env.obs``)."""
         from .vec_env import PVDERVec
+        payload_rows(payload, 0, gather_every)          # validates
+        self.payload, self.gather_every, self._step_index = payload, int(gather_every), 0
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.first, self.n_local = shard_range(total_envs, self.rank, self.world)
@@ -71,7 +103,13 @@ class ShardedPVDERVec:
 
     def step(self, local_actions: torch.Tensor):
         self.env.step(local_actions, return_tensors=False)
-        return self._collate() + ({},)
+        k = self._step_index
+        self._step_index += 1
+        r0, nr = payload_rows(self.payload, k, self.gather_every)
+        if nr == 13:
+            return self._collate() + ({},)
+        g = global_view(gather_outputs(self.env.out[r0:r0 + nr], None, self.group))       # [N_total, 2]
+        return None, g[:, 0], g[:, 1] != 0, {}
 
 
 class RcclAllGather:
@@ -166,20 +204,25 @@ class NativeStepGather:
         self.recv = [torch.empty((self.world * 13, n), dtype=torch.float32, device=env.device) for _ in range(2)]
         self._k = 0
 
+    payload, gather_every = "full", 1        # what a step collates (PAYLOADS); set before the first rollout
+
     def rollout(self, actions: torch.Tensor, sync_each: bool = False):
         """``actions``: [K, N] uint8 device tensor.  After ``drain()`` the collated block of the last
-        step is ``self.recv[(steps_so_far - 1) & 1]``."""
+        step is ``self.recv[(steps_so_far - 1) & 1]`` (its first world * rows rows for a partial payload)."""
         from . import _native
         env = self.env
         assert actions.dtype == torch.uint8 and actions.is_contiguous() and actions.shape[1] == env.num_envs
         plan = env._plan or env._make_plan()
         K = int(actions.shape[0])
         with env._device_ctx():
-            rc = self._lib.pvder_plan_rollout_gather(plan, self._h, env.fstate.data_ptr(), env.istate.data_ptr(),
-                                                     env.ev_vg.data_ptr(), env.ev_si.data_ptr(), actions.data_ptr(), K,
-                                                     self.out[0].data_ptr(), self.out[1].data_ptr(),
-                                                     self.recv[0].data_ptr(), self.recv[1].data_ptr(),
-                                                     env.stats.data_ptr(), env._stream(), self._k & 1, 1 if sync_each else 0)
+            r0, nr = payload_rows(self.payload, 0, 0) if self.payload != "full_every_k" else (REWARD_ROW, 2)
+            rc = self._lib.pvder_plan_rollout_gather_rows(plan, self._h, env.fstate.data_ptr(), env.istate.data_ptr(),
+                                                          env.ev_vg.data_ptr(), env.ev_si.data_ptr(), actions.data_ptr(), K,
+                                                          self.out[0].data_ptr(), self.out[1].data_ptr(),
+                                                          self.recv[0].data_ptr(), self.recv[1].data_ptr(),
+                                                          env.stats.data_ptr(), env._stream(), self._k & 1, 1 if sync_each else 0,
+                                                          r0, nr, self.gather_every if self.payload == "full_every_k" else 0,
+                                                          self._k)
         _native.check(rc, "pvder_plan_rollout_gather")
         self._k += K
         if K:

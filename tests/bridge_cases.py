@@ -56,3 +56,26 @@ def load(name):
     assert np.array_equal(g["vgrid"], vg) and np.array_equal(g["sinsol"], si) and np.array_equal(g["actions"], acts), \
         "golden %s does not belong to its case definition any more: regenerate it" % name
     return g
+
+
+# ---- the returns of calc_returns' four policies (tests/test_gpu_golden.py::test_calc_returns_vs_oracle) -------------
+CALC_RETURNS = dict(seed=11, episodes=2, T=2.0, n=15, rand_seed=3,
+                    cells=(("voltage_regulation", False), ("Q_regulation", False), ("power_regulation", True)))
+
+
+def calc_returns_inputs():
+    c = CALC_RETURNS
+    K = int(c["T"] * 60 / c["n"])
+    rand = np.random.default_rng(c["rand_seed"]).integers(0, 5, size=(K + 1, c["episodes"]))
+    vg, si = counter_tables(c["episodes"], c["seed"], episode=1, env_id_base=0)
+    return K, rand, vg, si
+
+
+def load_calc_returns():
+    p = os.path.join(GOLD, "bridge_calc_returns.npz")
+    if not os.path.exists(p):
+        raise FileNotFoundError("%s missing: run python tests/golden/make_bridge_goldens.py calc_returns" % p)
+    g = dict(np.load(p))
+    K, rand, vg, si = calc_returns_inputs()
+    assert np.array_equal(g["rand"], rand) and np.array_equal(g["vgrid"], vg) and np.array_equal(g["sinsol"], si)
+    return g

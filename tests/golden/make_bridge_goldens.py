@@ -3,6 +3,7 @@
 tests/golden/bridge_<name>.npz (BUILD-ORACLE goldens: parity unpinned, see make_goldens.py).
 
     python tests/golden/make_bridge_goldens.py [case ...]        (default: every case without a file)
+    python tests/golden/make_bridge_goldens.py calc_returns      (the returns of calc_returns' policies)
 
 One process per env (the C bridge is single-threaded); ~25 s per env and 160-step episode."""
 import multiprocessing as mp
@@ -39,7 +40,32 @@ def run_env(job):
     return name, e, np.array(obs), np.array(rew), np.array(done), np.array(mabs), np.array(iabs)
 
 
+def make_calc_returns():
+    """bridge_calc_returns.npz: mean return and final refs of calc_returns' four policies (PVDER_env.py:458-497) for
+    the cells of bridge_cases.CALC_RETURNS, from the converged bridge with the reference's reward rules."""
+    ACTION_SPECS = {'random': None, 'inc': 0, 'dec': 1, 'no_change': 2}      # PVDER_env.py:462, :480-487
+    c = bridge_cases.CALC_RETURNS
+    K, rand, vg, si = bridge_cases.calc_returns_inputs()
+    out = dict(rand=rand, vgrid=vg, sinsol=si)
+    for goal, discrete in c["cells"]:
+        for name, fixed in ACTION_SPECS.items():
+            ref = BridgeVecEnv(c["episodes"], n=c["n"], max_sim_time=c["T"], discrete=discrete, goal=goal, method="rk45",
+                               rtol=1e-8, atol=1e-11)
+            ref.reset(vg, si)
+            total = np.zeros(c["episodes"])
+            for k in range(K):
+                a = np.full(c["episodes"], fixed) if fixed is not None else rand[k]
+                _, r, d = ref.step(a)
+                total += r
+            assert bool(d.all())
+            out["%s/%s" % (goal, name)] = np.array([total.mean(), ref.vdcref.mean(), ref.qref.mean()])
+    np.savez_compressed(os.path.join(HERE, "bridge_calc_returns.npz"), **out)
+    print("calc_returns: %d cells" % (len(out) - 3))
+
+
 def main():
+    if sys.argv[1:] == ["calc_returns"]:
+        return make_calc_returns()
     names = sys.argv[1:] or [n for n in bridge_cases.CASES if not os.path.exists(bridge_cases.path(n))]
     jobs = [(n, e) for n in names for e in range(bridge_cases.CASES[n]["N"])]
     t0 = time.time()

@@ -47,3 +47,28 @@ def bridge_episode(vg, si, ev_s0, ev_ds, actions, n=15, rtol=1e-8, atol=1e-11):
             obs.append(o.copy()); rew.append(np.array(r, copy=True)); done.append(np.array(d, copy=True))
         _BRIDGE_EPISODES[key] = (np.stack(obs), np.stack(rew), np.stack(done))
     return _BRIDGE_EPISODES[key]
+
+
+def assert_discrete_rewards(got_r, want_r, want_obs, goal="voltage_regulation", der_id="50", tol=2e-4, what=""):
+    """Discrete rewards must equal the oracle's -- except where the oracle's own observation puts the goal's error
+    within ``tol`` of a ladder threshold (PVDER_env.py:263-299: 1 % / 5 %, power 1 % / 3 %), where the 1e-4-level
+    difference between the two integrators may land on the other side.  Every mismatch is ASSERTED to sit there
+    (an allowance that does not check its excuse is not a test).  ``want_obs``: [..., 11] of the
+    oracle (balanced envs: Vrms = |v_a| / sqrt 2).  Returns the number of mismatches."""
+    from oracle.pvder_oracle_env import P_REF, Q_REF_TARGET
+    got_r, want_r, want_obs = np.asarray(got_r), np.asarray(want_r), np.asarray(want_obs, dtype=np.float64)
+    bad = got_r != want_r
+    if not bad.any():
+        return 0
+    m = pm.build_model(der_id)
+    o = want_obs[bad]
+    if goal == "voltage_regulation":
+        err, th = np.abs(np.hypot(o[..., 2], o[..., 3]) / np.sqrt(2.0) - m.Vrms_ref) / m.Vrms_ref, (0.01, 0.05)
+    elif goal == "power_regulation":
+        err, th = np.abs(o[..., 4] - P_REF / pm.SBASE) / (P_REF / pm.SBASE), (0.01, 0.03)
+    else:
+        err, th = np.abs(o[..., 5] - Q_REF_TARGET / pm.SBASE) / (Q_REF_TARGET / pm.SBASE), (0.01, 0.05)
+    dist = np.minimum(np.abs(err - th[0]), np.abs(err - th[1]))
+    assert dist.max() < tol, "%s: %d discrete reward(s) differ away from a threshold (distance %.2e, errors %s)" % (
+        what, int(bad.sum()), dist.max(), err[:5])
+    return int(bad.sum())

@@ -65,3 +65,23 @@ def test_pmc_summary_counts_only_for_the_sources_it_was_measured_on(tmp_path, mo
         {"kernel": "k", "envs": 8, "traffic_bytes_per_launch": 456.0, "kernel_src_sha": sha}))
     assert bench.pmc_traffic("k", 8) == (456.0, "r10_pmc_x_traffic.json")
     assert bench.pmc_traffic("k", 16) == (None, None)
+
+
+def test_visible_gpu_count_without_the_hip_runtime(tmp_path, monkeypatch):
+    """the parent that starts the ranks counts GPUs from the environment / the KFD topology, not
+    through torch.cuda (whatever that initialises)."""
+    import bench
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    for k, simd in enumerate((0, 0, 1024, 1024, 1024)):          # two CPU nodes, three GPUs
+        d = tmp_path / str(k)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) == -1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count(str(tmp_path)) == 0
+    src = open(bench.__file__).read()
+    assert "torch.cuda.device_count" not in src

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2
+from helpers import assert_discrete_rewards, rel_l2
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -45,9 +45,8 @@ def test_f32_kernels_vs_golden(gpu_device, name, integrator):
     assert err < FP32_TOL, "rel-L2 %.3e" % err
     assert np.array_equal(done[:, 0], g["done"])
     if bool(g["discrete"]):
-        # exact except when the golden sits within 1e-6 (relative) of a reward threshold
-        bad = rew[:, 0] != g["reward"]
-        assert bad.mean() <= 0.05, (name, np.nonzero(bad)[0])
+        # exact except where the golden sits on a reward threshold -- asserted
+        assert_discrete_rewards(rew[:, 0], g["reward"], g["obs"][1:], goal=str(g["goal"]), what=name)
     else:
         assert np.abs(rew[:, 0] - g["reward"]).max() < 1e-6
 
@@ -240,7 +239,9 @@ def test_single_phase_model_vs_bridge(gpu_device):
             obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
             o2, r2, d2 = ref.step(actions[t])
             got.append(obs.cpu().numpy().astype(np.float64)); want.append(o2)
-            assert (rew.cpu().numpy() != r2).mean() < 0.02 and np.array_equal(done.cpu().numpy(), d2)
+            assert np.array_equal(done.cpu().numpy(), d2)
+            # (single phase: Vrms is not in the observation's |v_a| / sqrt 2 form only for three phases; P_PCC is what counts here)
+            assert_discrete_rewards(rew.cpu().numpy(), r2, o2, goal="power_regulation", der_id="10", what=integrator)
         got, want = np.stack(got), np.stack(want)
         err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
         assert err.max() < tol, (integrator, err.max())
@@ -352,36 +353,27 @@ def test_calc_returns_vs_oracle(gpu_device):
     """SURVEY.md 8(f) rank 2 against the oracle: the returns of the reference's four fixed policies
     (PVDER_env.py:458-497) from the batched rollout == the fp64 bridge (converged RK45) stepping the same
     event tables (counter generator keyed by (seed, env id, episode)) and the same action sequences,
-    with the reference's reward rules (oracle/bridge_env.py)."""
+    with the reference's reward rules (oracle/bridge_env.py) -- the bridge's figures are the committed golden
+    tests/golden/bridge_calc_returns.npz (tests/golden/make_bridge_goldens.py calc_returns)."""
+    import bridge_cases
     from gym_PVDER_amd import der_model
     from gym_PVDER_amd.evaluate import ACTION_SPECS, calc_returns
-    from helpers import counter_tables
-    from oracle.bridge_env import BridgeVecEnv
-    seed, episodes, T = 11, 2, 2.0          # (the converged bridge integrates ~50 000 RK45 steps per env step)
-    K = int(T * 60 / 15)
-    rng = np.random.default_rng(3)
-    rand = rng.integers(0, 5, size=(K + 1, episodes))
-    vg, si = counter_tables(episodes, seed, episode=1, env_id_base=0)
-    for goal, discrete in (("voltage_regulation", False), ("Q_regulation", False), ("power_regulation", True)):
+    g = bridge_cases.load_calc_returns()
+    c = bridge_cases.CALC_RETURNS
+    seed, episodes, T = c["seed"], c["episodes"], c["T"]
+    rand = g["rand"]
+    for goal, discrete in c["cells"]:
         got = calc_returns(episodes=episodes, device=gpu_device, goals=[goal], seed=seed, max_sim_time=T,
                            DISCRETE_REWARD=discrete, random_actions=torch.as_tensor(rand))
         for name, fixed in ACTION_SPECS.items():
-            ref = BridgeVecEnv(episodes, n=15, max_sim_time=T, discrete=discrete, goal=goal, method="rk45",
-                               rtol=1e-8, atol=1e-11)
-            ref.reset(vg, si)
-            total = np.zeros(episodes)
-            for k in range(K):
-                a = np.full(episodes, fixed) if fixed is not None else rand[k]
-                _, r, d = ref.step(a)
-                total += r
-            assert bool(d.all())
-            want, have = float(total.mean()), got[goal][name]['return']
+            want, vdcref, qref = g["%s/%s" % (goal, name)]
+            have = got[goal][name]['return']
             if discrete:
                 assert abs(have - want) <= 4.0 / episodes + 1e-9, (goal, name, have, want)     # at most one threshold flip
             else:
                 assert abs(have - want) <= 1e-3 * abs(want) + 1e-9, (goal, name, have, want)
-            assert abs(got[goal][name]['ref'][0] - ref.vdcref.mean() * der_model.VBASE) < 1e-2
-            assert abs(got[goal][name]['ref'][1] - ref.qref.mean() * der_model.SBASE) < 1e-1
+            assert abs(got[goal][name]['ref'][0] - vdcref * der_model.VBASE) < 1e-2
+            assert abs(got[goal][name]['ref'][1] - qref * der_model.SBASE) < 1e-1
 
 
 def test_q_agent_update_vs_oracle(gpu_device):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import both_events_spec, bridge_episode, counter_tables, rel_l2
+from helpers import assert_discrete_rewards, both_events_spec, counter_tables, rel_l2
 from oracle import pvder_model as pm
 from oracle.bridge_env import BridgeVecEnv
 
@@ -68,8 +68,7 @@ def test_rk4_f32_trajectory_vs_fp64_bridge(gpu_device, n_sub, steps):
         want_obs.append(o2)
         # reward exact unless the oracle sits within 1e-6 of a threshold (discrete ladder)
         assert np.array_equal(done.cpu().numpy(), d2)
-        mism = rew.cpu().numpy() != r2
-        assert mism.mean() < 0.02, "reward mismatch on %.1f%% of envs" % (100 * mism.mean())
+        assert_discrete_rewards(rew.cpu().numpy(), r2, o2, what="step %d" % t)
     got, want = np.stack(got_obs), np.stack(want_obs)            # [T, N, 11]
     err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
     assert err.max() < FP32_TOL, "max rel-L2 over envs %.3e" % err.max()
@@ -120,7 +119,7 @@ def test_etdrk4_f32_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, mic
         got_obs.append(obs.cpu().numpy().astype(np.float64))
         want_obs.append(o2)
         assert np.array_equal(done.cpu().numpy(), d2)
-        assert (rew.cpu().numpy() != r2).mean() < 0.02
+        assert_discrete_rewards(rew.cpu().numpy(), r2, o2, what="step %d" % t)
     got, want = np.stack(got_obs), np.stack(want_obs)
     err = rel_l2(got.transpose(1, 0, 2).reshape(N, -1), want.transpose(1, 0, 2).reshape(N, -1), axis=1)
     assert err.max() < FP32_TOL, "max rel-L2 over envs %.3e" % err.max()
@@ -275,19 +274,22 @@ def test_current_limit_defers_to_23_state_path(gpu_device):
 
 def test_full_episode_drift_vs_converged_bridge(gpu_device):
     """A complete PVDER-v0 episode (160 env steps = 40 s, 38 voltage/insolation events, random
-    actions): the fp32 ETDRK4 kernel must not drift away from the converged fp64 solution."""
-    N, steps = 8, 160
-    rng = np.random.default_rng(2718)
-    actions = rng.integers(0, 5, size=(steps, N))
-    env = make_vec(N, gpu_device, integrator="etdrk4", seed=1234, events_spec=both_events_spec(), auto_reset=False)
+    actions): the fp32 ETDRK4 kernel must not drift away from the converged fp64 solution (the committed
+    golden tests/golden/bridge_episode_random.npz, shared with the etdlin test)."""
+    import bridge_cases
+    g = bridge_cases.load("episode_random")
+    c = bridge_cases.CASES["episode_random"]
+    N, steps, actions = c["N"], c["steps"], g["actions"]
+    env = make_vec(N, gpu_device, integrator="etdrk4", seed=c["seed"], events_spec=both_events_spec(), auto_reset=False)
     env.reset()
-    vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
-    want, want_r, want_d = bridge_episode(vg, si, env.ev_s0, env.ev_ds, actions)        # (shared with the etdlin test)
+    assert np.array_equal(env.ev_vg.cpu().numpy(), g["vgrid"].astype(np.float32)) and \
+        np.array_equal(env.ev_si.cpu().numpy(), g["sinsol"].astype(np.float32))
+    want, want_r, want_d = g["obs"], g["reward"], g["done"]
     got, rmis = [], 0
     for t in range(steps):
         obs, rew, done, _ = env.step(torch.as_tensor(actions[t], device=gpu_device))
         got.append(obs.cpu().numpy().astype(np.float64))
-        rmis += int((rew.cpu().numpy() != want_r[t]).sum())
+        rmis += assert_discrete_rewards(rew.cpu().numpy(), want_r[t], want[t], what="step %d" % t)
         assert np.array_equal(done.cpu().numpy(), want_d[t])
     assert bool(done.all()) and want_d[-1].all()         # 160 * 0.25 s = max_sim_time
     got = np.stack(got)
@@ -295,7 +297,7 @@ def test_full_episode_drift_vs_converged_bridge(gpu_device):
     assert err.max() < FP32_TOL, "whole-episode rel-L2 %.3e" % err.max()
     last = rel_l2(got[-20:].transpose(1, 0, 2).reshape(N, -1), want[-20:].transpose(1, 0, 2).reshape(N, -1), axis=1)
     assert last.max() < FP32_TOL, "last 5 s rel-L2 %.3e (drift)" % last.max()
-    assert rmis <= 0.01 * N * steps                      # discrete reward: only threshold ties may differ
+    assert rmis <= 0.01 * N * steps
 
 
 def test_step_is_graph_capturable(gpu_device):
