@@ -1,0 +1,109 @@
+// pvder_agent_dev.hpp -- device side of the tabular Q-learning step (include/pvder_agent.h), shared by the
+// stand-alone agent kernel (pvder_agent.hip: one launch behind each step launch) and by the closed-loop fused
+// rollout (pvder_kernels.hip: the agent step between two env steps of ONE launch, the env state still in
+// registers).  The body of the reference's QAgent.train loop, /root/reference/gym_PVDER/agents/qagent.py:56-105.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pvder_agent {
+
+constexpr int kObs = 11;
+
+struct AgentK {
+    int bins, n_act, first, choose;
+    float one_minus_lr, lr, gamma, epsilon, q_done;
+    double low, win;
+    uint64_t seed, counter;
+    long long env_id_base;
+};
+
+// counter-based generator of pvder_kernels.hip / oracle/pvder_model.py::counter_uniform (bit-identical)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float counter_uniform(uint64_t seed, uint64_t env, uint64_t episode, uint32_t k, uint32_t lane) {
+    uint64_t key = splitmix64(seed);
+    key = splitmix64(key ^ (env & 0xFFFFFFFFull) ^ ((episode & 0xFFFFFFFFull) << 32));
+    key = splitmix64(key ^ ((uint64_t)k << 8) ^ (uint64_t)(lane & 0xFF));
+    return (float)(key >> 40) * (1.0f / 16777216.0f);
+}
+
+// get_discrete_state (qagent.py:43-45): (state - low) / win in float64, truncated; the Box bound itself (+10)
+// falls into the last bin.  Returns the flat table row (first observation component most significant).
+__device__ __forceinline__ long long discretise(const AgentK &K, const float (&obs)[kObs]) {
+    long long s = 0;
+#pragma unroll
+    for (int k = 0; k < kObs; ++k) {
+        long long d = (long long)(((double)obs[k] - K.low) / K.win);
+        d = d < 0 ? 0 : (d > K.bins - 1 ? K.bins - 1 : d);
+        s = s * K.bins + d;
+    }
+    return s;
+}
+
+// One agent step of env `e` on the transition (state, action) -> obs with reward r / done: table update
+// (qagent.py:83-103), bookkeeping, next epsilon-greedy action (:63-68).  `counter`: exploration key of this call.
+// state / action / alive / ret are the env's agent-side registers (or its array slots).
+__device__ __forceinline__ void agent_step(const AgentK &K, float *__restrict__ q, const float (&obs)[kObs], float r, bool done,
+                                           long long gid, uint64_t counter, long long &state, int &action, bool &alive,
+                                           double &ret) {
+    const long long s2 = discretise(K, obs);
+    const float *row2 = q + (size_t)s2 * K.n_act;
+    if (K.first) {
+        alive = true;
+        ret = 0.0;
+    } else if (alive) {
+        float *entry = q + (size_t)state * K.n_act + action;
+        float nq = K.q_done;                                           // :100-103
+        if (!done) {                                                   // :83-95
+            float mx = row2[0];
+            for (int j = 1; j < K.n_act; ++j) mx = fmaxf(mx, row2[j]);
+            nq = K.one_minus_lr * *entry + K.lr * (r + K.gamma * mx);
+        }
+        *entry = nq;
+        ret += (double)r;
+        alive = !done;
+    }
+    state = s2;
+    if (K.choose) {                                                    // :63-68
+        int best = 0;
+        float bq = row2[0];
+        for (int j = 1; j < K.n_act; ++j) {                            // np.argmax: the first maximum
+            const float v = row2[j];
+            if (v > bq) { bq = v; best = j; }
+        }
+        const float u = counter_uniform(K.seed, (uint64_t)gid, counter, 0, 0);
+        if (u <= K.epsilon) {                                          // np.random.random() > epsilon -> greedy
+            int a = (int)(counter_uniform(K.seed, (uint64_t)gid, counter, 0, 1) * (float)K.n_act);
+            best = a > K.n_act - 1 ? K.n_act - 1 : a;
+        }
+        action = best;
+    }
+}
+
+// the same on array slots, observation / reward / done read from an output block [13][n_env]
+__device__ __forceinline__ void agent_step_block(const AgentK &K, float *__restrict__ q, const float *__restrict__ out, size_t N,
+                                                 int e, uint64_t counter, long long *__restrict__ state,
+                                                 uint8_t *__restrict__ action, uint8_t *__restrict__ alive,
+                                                 double *__restrict__ ep_reward) {
+    float obs[kObs];
+#pragma unroll
+    for (int k = 0; k < kObs; ++k) obs[k] = out[(size_t)k * N + e];
+    long long s = state[e];
+    int a = action[e];
+    bool al = alive[e] != 0;
+    double ret = ep_reward[e];
+    const float r = out[(size_t)11 * N + e];
+    const bool done = out[(size_t)12 * N + e] != 0.f;
+    agent_step(K, q, obs, r, done, K.env_id_base + e, counter, s, a, al, ret);
+    state[e] = s;
+    if (K.choose) action[e] = (uint8_t)a;
+    alive[e] = al ? 1 : 0;
+    ep_reward[e] = ret;
+}
+
+}  // namespace pvder_agent

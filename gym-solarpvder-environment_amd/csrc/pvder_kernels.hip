@@ -37,6 +37,8 @@
 #include "pvder_model.hpp"
 #include "pvder_model_pk.hpp"
 #include "pvder_etdlin.hpp"
+#include "pvder_agent.h"
+#include "pvder_agent_dev.hpp"
 
 namespace {
 // Debug-only in-kernel timeline (tools/trace_timeline.py builds a separate library with
@@ -1310,6 +1312,13 @@ struct RollK {
     int *progress;                   // [n_wg]: steps of the rollout the workgroup has behind it
     int resume;                      // fused kernel: 0 = start at step 0, 1 = start at progress[wg]
     int max_finish;                  // finish kernel: at most this many steps per workgroup
+    // closed loop (pvder_plan_rollout_fused_agent): the agent step between two env steps of the launch
+    pvder_agent::AgentK ag;          // ag.counter = exploration key of the agent call behind step 0 (+ k behind step k)
+    float *q;                        // the table
+    long long *ag_state;             // [n_env] table row of the observation the pending action was chosen in
+    uint8_t *ag_action;              // [n_env] the pending action (in: chosen behind the reset / the previous rollout)
+    uint8_t *ag_alive;               // [n_env]
+    double *ag_ret;                  // [n_env] return of the running episode
 };
 
 // first segment of an env step that starts at sim time step ksub: ONE integer division gives the event
@@ -1942,12 +1951,12 @@ __device__ __forceinline__ const RollArgs &roll_args() {
     return *(const RollArgs *)ka;
 }
 
-template <int PH>
-__global__ __launch_bounds__(kBlock)
-#ifndef PVDER_ROLLOUT_OCC2
-__attribute__((amdgpu_waves_per_eu(3)))      // 168 VGPRs: three waves per SIMD for batches beyond 131 072 envs
-#endif
-void step_etdlin_rollout_kernel(const RollArgs Q) {
+// AG = true: CLOSED LOOP -- the tabular Q-learning step of the reference's training loop (agents/qagent.py:56-105:
+// discretise the observation, update the table with the transition that just ended, choose the next action
+// epsilon-greedily; pvder_agent_dev.hpp) runs between env step k and k + 1 with the env state still in registers;
+// the action row of a step is what the agent chose behind the previous one.
+template <int PH, bool AG>
+__device__ __forceinline__ void rollout_body(const RollArgs &Q) {
     using namespace pvder;
     constexpr int NS = 6 * PH + 5;
     if (Q.Rk.resume && Q.Rk.progress[blockIdx.x] >= Q.Rk.n_steps) return;      // (workgroup-uniform) nothing left
@@ -1981,6 +1990,15 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
     float last_reward = 0.f, bad = 0.f;
     const int k_first = Q.Rk.resume ? Q.Rk.progress[blockIdx.x] : 0;
     int k = k_first;
+    // the agent's registers of this env (closed loop)
+    long long ag_s = 0;
+    int ag_a = 0;
+    bool ag_alive = false;
+    double ag_ret = 0.0;
+    if constexpr (AG) {
+        const int ec = e < Q.G.A.n_env ? e : Q.G.A.n_env - 1;
+        ag_s = Q.Rk.ag_state[ec]; ag_a = Q.Rk.ag_action[ec]; ag_alive = Q.Rk.ag_alive[ec] != 0; ag_ret = Q.Rk.ag_ret[ec];
+    }
     if (!__syncthreads_or((int)bail) && k < Q.Rk.n_steps) {
         // what a step reads from memory -- its action, the event inputs and the schedule row of its first
         // segment -- is requested ONE STEP AHEAD (the addresses only depend on the step counter): a lone wave
@@ -1991,7 +2009,8 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
             const EtdArgs &A = Q.G.A;
             const size_t N = (size_t)A.n_env;
             const int ec = e < A.n_env ? e : A.n_env - 1;
-            a_now = ld(&Q.Rk.actions[(size_t)k * N + ec]);
+            if constexpr (AG) a_now = ag_a;
+            else a_now = ld(&Q.Rk.actions[(size_t)k * N + ec]);
             sg = lin_first_segment(A.C, Q.G.Lk, ksub, A.ev_vg, A.ev_si, N, ec);
         }
         for (;; ++k) {
@@ -2002,8 +2021,11 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
             const int ec = e < A.n_env ? e : A.n_env - 1;
             const bool traced = k == k_first + 3;       // (trace builds: timeline of the fourth step)
             if (traced) PVDER_TRACE_AT(0);
-            const int k_next = k + 1 < Q1.Rk.n_steps ? k + 1 : k;
-            const int a_next = ld(&Q1.Rk.actions[(size_t)k_next * N + ec]);
+            int a_next = 0;
+            if constexpr (!AG) {
+                const int k_next = k + 1 < Q1.Rk.n_steps ? k + 1 : k;
+                a_next = ld(&Q1.Rk.actions[(size_t)k_next * N + ec]);
+            }
             // (the row in force at the end of this step is the one the next step starts with: its inputs
             // also serve the observation at tStop)
             const LinSeg sg_next = lin_first_segment(A.C, Q1.G.Lk, ksub + A.C.n_sub, A.ev_vg, A.ev_si, N, ec);
@@ -2056,6 +2078,15 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
                 st(&o[PVDER_O_DONE * N + e], 0.f);
             }
             if (traced) PVDER_TRACE_AT(21);
+            if constexpr (AG) {
+                // the agent step behind env step k (never an episode-ending one here: done = false)
+                const float obs[pvder_agent::kObs] = {iaR, iaI, vaR, vaI, Ppcc, Qpcc, ys[6 * PH], ppv, vdcref, qref,
+                                                      (float)ksub * (float)(1.0 / 60.0) * B.C.inv_tmax};
+                if (e < B.n_env)
+                    pvder_agent::agent_step(Q2.Rk.ag, Q2.Rk.q, obs, last_reward, false, Q2.Rk.ag.env_id_base + e,
+                                            Q2.Rk.ag.counter + (uint64_t)k, ag_s, ag_a, ag_alive, ag_ret);
+                a_next = ag_a;
+            }
             a_now = a_next;
             sg = sg_next;
         }
@@ -2083,12 +2114,27 @@ void step_etdlin_rollout_kernel(const RollArgs Q) {
             *slot = v4{r, 0.f, 0.f, ba};
         }
     }
+    if constexpr (AG) {
+        if (live) {
+            Q3.Rk.ag_state[e] = ag_s; Q3.Rk.ag_action[e] = (uint8_t)ag_a; Q3.Rk.ag_alive[e] = ag_alive ? 1 : 0; Q3.Rk.ag_ret[e] = ag_ret;
+        }
+    }
     if (threadIdx.x == 0) Q3.Rk.progress[blockIdx.x] = k;
 }
 
+template <int PH>
+__global__ __launch_bounds__(kBlock)
+#ifndef PVDER_ROLLOUT_OCC2
+__attribute__((amdgpu_waves_per_eu(3)))      // 168 VGPRs: three waves per SIMD for batches beyond 131 072 envs
+#endif
+void step_etdlin_rollout_kernel(const RollArgs Q) { rollout_body<PH, false>(Q); }
+
+template <int PH>
+__global__ __launch_bounds__(kBlock) void step_etdlin_rollout_agent_kernel(const RollArgs Q) { rollout_body<PH, true>(Q); }
+
 // the steps the fused kernel left to a workgroup, one at a time through memory (usually: the step that
 // ends an episode, once per episode)
-template <int PH>
+template <int PH, bool AG = false>
 __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollArgs Q) {
     using namespace pvder;
     const LinArgs &G = Q.G;
@@ -2112,8 +2158,18 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
         lin_load_mat(G.Lk.lcoef, lane, At);
         lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
         int cur = 1;
-        lin_step_body<PH, 0>(G, lane, At, Ac, cur, Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1, G.A.fstate,
-                             G.A.istate, G.A.n_env);
+        lin_step_body<PH, 0>(G, lane, At, Ac, cur, AG ? Rk.ag_action : Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1,
+                             G.A.fstate, G.A.istate, G.A.n_env);
+        if constexpr (AG) {
+            // the agent step behind this env step, from the output block the step has just written (this lane's own
+            // rows); the transition that ENDS an episode is among the steps taken here
+            const RollArgs &Qa = roll_args();
+            const int e = blockIdx.x * kBlock + threadIdx.x;
+            if (e < Qa.G.A.n_env)
+                pvder_agent::agent_step_block(Qa.Rk.ag, Qa.Rk.q, Qa.G.A.out + k * Qa.Rk.out_stride, (size_t)Qa.G.A.n_env, e,
+                                              Qa.Rk.ag.counter + (uint64_t)k, Qa.Rk.ag_state, Qa.Rk.ag_action, Qa.Rk.ag_alive,
+                                              Qa.Rk.ag_ret);
+        }
         __threadfence();                 // the next step of this workgroup reads what this one wrote
         __syncthreads();
     }
@@ -2830,6 +2886,7 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
     A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
     Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
+    Rk.ag = pvder_agent::AgentK{}; Rk.q = nullptr; Rk.ag_state = nullptr; Rk.ag_action = nullptr; Rk.ag_alive = nullptr; Rk.ag_ret = nullptr;
     // (fused kernel, finish kernel for ONE step) once per episode end a workgroup can meet inside the rollout,
     // then the finish kernel for whatever is left (workgroups with deferred / finished envs)
     const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
@@ -2839,6 +2896,47 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
         Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
         hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
         hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    }
+    return hip_rc(hipGetLastError());
+}
+
+// Closed-loop training episode in a handful of launches: n_steps x (env step, agent step) with the env state AND the
+// agent's registers on the chip from step to step (step_etdlin_rollout_agent_kernel); the steps a workgroup cannot carry
+// -- the one that ends the episode, an env off balance / at a limit -- are taken, env step and agent step, by the
+// finish kernel.  Same results as n_steps x (pvder_plan_step, pvder_qagent_step_f32) wherever that sequence is itself
+// deterministic (envs that do not race for the same table entries; one wave of envs always).
+int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                                   int n_steps, float *out, float *stats, int32_t *progress, const pvder_qagent_cfg *cfg,
+                                   float *q_table, int64_t *state, uint8_t *action, uint8_t *alive, double *ep_reward,
+                                   void *stream) {
+    if (!plan || n_steps < 0 || !out || !progress || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
+    if (!cfg || !q_table || !state || !action || !alive || !ep_reward) return PVDER_EINVAL;
+    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->R.enabled) return PVDER_EINVAL;   // (episodes are the caller's)
+    if (cfg->bins < 1 || cfg->n_act < 1 || cfg->n_act > 5 || !(cfg->win > 0.0) || cfg->first || !cfg->choose) return PVDER_EINVAL;
+    if (n_steps == 0) return 0;
+    const int n_env = plan->n_env;
+    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    RollArgs Q;
+    Q.G = plan->lin;
+    EtdArgs &A = Q.G.A;
+    RollK &Rk = Q.Rk;
+    A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
+    A.action = action; A.out = out; A.stats = stats; A.stats_fresh = 1;
+    Rk.actions = nullptr; Rk.n_steps = n_steps; Rk.out_stride = 0; Rk.progress = progress;
+    pvder_agent::AgentK &K = Rk.ag;
+    K.bins = cfg->bins; K.n_act = cfg->n_act; K.first = 0; K.choose = 1;
+    K.one_minus_lr = (float)(1.0 - (double)cfg->lr); K.lr = cfg->lr; K.gamma = cfg->gamma;
+    K.epsilon = cfg->epsilon; K.q_done = cfg->q_done; K.low = cfg->low; K.win = cfg->win;
+    K.seed = cfg->seed; K.counter = cfg->counter; K.env_id_base = cfg->env_id_base;
+    Rk.q = q_table; Rk.ag_state = (long long *)state; Rk.ag_action = action; Rk.ag_alive = alive; Rk.ag_ret = ep_reward;
+    const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
+    const int pairs = n_steps / ep + 2;
+    for (int r = 0; r < pairs; ++r) {
+        Rk.resume = r > 0 ? 1 : 0;
+        Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
+        hipLaunchKernelGGL(step_etdlin_rollout_agent_kernel<3>, grid, block, 0, st, Q);
+        hipLaunchKernelGGL((step_etdlin_finish_kernel<3, true>), grid, block, 0, st, Q);
     }
     return hip_rc(hipGetLastError());
 }

@@ -29,7 +29,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows"]
-AGENT_SYMBOLS = ["pvder_qagent_step_f32"]            # include/pvder_agent.h
+AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3}       # enum pvder_integrator
 LIN_MAX_SETS = 12
@@ -160,6 +160,8 @@ def lib() -> C.CDLL:
     L.pvder_plan_rollout_fused.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp]
     L.pvder_qagent_step_f32.restype = i32
     L.pvder_qagent_step_f32.argtypes = [C.POINTER(QAgentCfg), vp, vp, vp, vp, vp, vp, i32, vp]
+    L.pvder_plan_rollout_fused_agent.restype = i32
+    L.pvder_plan_rollout_fused_agent.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(QAgentCfg), vp, vp, vp, vp, vp, vp]
     L.pvder_gather_create.restype = i32
     L.pvder_gather_create.argtypes = [C.POINTER(vp), vp, vp]
     L.pvder_gather_destroy.restype = None

@@ -135,11 +135,32 @@ class BatchedQAgent:
                                             env._stream())
         _native.check(rc, "pvder_qagent_step_f32")
 
-    def train_fused(self, episodes: Optional[int] = None) -> Dict[str, List[float]]:
+    def closed_loop_episode(self, state, action, alive, ep_reward, steps: int, counter: int):
+        """``steps`` x (env step, agent step) in a handful of launches (pvder_plan_rollout_fused_agent, include/
+        pvder_agent.h): the env state and the agent's per-env registers stay on the chip from step to step.  Same
+        arguments as ``fused_step``; ``action`` holds the action chosen behind the reset."""
+        env = self.env
+        if env._plan is None:
+            env._make_plan()
+        if env._plan_integrator != "etdlin" or env.ns != 23 or env.auto_reset:
+            raise ValueError("closed-loop fused episodes: integrator='etdlin', three-phase model, auto_reset=False")
+        cfg = self._agent_cfg(False, True, counter)
+        with env._device_ctx():
+            rc = env._lib.pvder_plan_rollout_fused_agent(env._plan, env.fstate.data_ptr(), env.istate.data_ptr(),
+                                                         env.ev_vg.data_ptr(), env.ev_si.data_ptr(), int(steps),
+                                                         env.out.data_ptr(), env.stats.data_ptr(), env._progress.data_ptr(),
+                                                         C.byref(cfg), self.q_table.data_ptr(), state.data_ptr(),
+                                                         action.data_ptr(), alive.data_ptr(), ep_reward.data_ptr(), env._stream())
+        _native.check(rc, "pvder_plan_rollout_fused_agent")
+
+    def train_fused(self, episodes: Optional[int] = None, closed_loop: bool = False) -> Dict[str, List[float]]:
         """``train`` with TWO launches per env step (the env step + the agent step) and no host
         synchronisation inside an episode: the episode length is known (max_sim_time / TimeLimit), envs that
         end early simply stop learning (``alive``).  Exploration draws come from the counter generator of the
-        event tables, keyed (seed, global env id, step count): runs are reproducible."""
+        event tables, keyed (seed, global env id, step count): runs are reproducible.
+        ``closed_loop=True``: the whole episode -- every env step AND the agent step between two of them -- in a
+        handful of launches (``closed_loop_episode``); the same table wherever the two-launch sequence is itself
+        deterministic (envs that do not race for the same table entries)."""
         env = self.env
         assert not env.auto_reset, "construct the PVDERVec with auto_reset=False: episodes are reset here"
         assert env.fdtype == torch.float32, "the agent step reads the fp32 output block"
@@ -158,10 +179,14 @@ class BatchedQAgent:
             env.reset()
             self.fused_step(state, action, alive, ep_reward, first=True, counter=self._counter)
             self._counter += 1
-            for _ in range(steps):
-                env.step(action, return_tensors=False)
-                self.fused_step(state, action, alive, ep_reward, first=False, counter=self._counter)
-                self._counter += 1
+            if closed_loop:
+                self.closed_loop_episode(state, action, alive, ep_reward, steps, self._counter)
+                self._counter += steps
+            else:
+                for _ in range(steps):
+                    env.step(action, return_tensors=False)
+                    self.fused_step(state, action, alive, ep_reward, first=False, counter=self._counter)
+                    self._counter += 1
             self.update_epsilon()
             recent.append(ep_reward.clone())
             if episode % self.train_spec['STATS_EVERY'] == 0:                                           # :113-120

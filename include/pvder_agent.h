@@ -48,6 +48,22 @@ typedef struct pvder_qagent_cfg {
 int pvder_qagent_step_f32(const pvder_qagent_cfg *cfg, float *q_table, const float *out, int64_t *state,
                           uint8_t *action, uint8_t *alive, double *ep_reward, int n_env, void *stream);
 
+/* The closed loop without the host in it: n_steps x (env step, agent step) of a training episode -- qagent.py:56-105 --
+ * in a handful of launches, the env state and the agent's per-env registers on the chip from step to step (the fused
+ * rollout of pvder_hip.h, pvder_plan_rollout_fused, with the agent step between two env steps).  `plan`: a
+ * PVDER_INT_ETDLIN three-phase plan WITHOUT auto-reset (struct pvder_plan of pvder_hip.h); fstate .. progress as for
+ * pvder_plan_rollout_fused, `out` ONE [13][n_env] block (every step overwrites it: the agent consumes it on the chip).
+ * `action` holds, on entry, the action chosen behind the reset (a pvder_qagent_step_f32 call with cfg->first = 1);
+ * on return state / action / alive / ep_reward are what n_steps two-launch steps would have left.  cfg: first = 0,
+ * choose = 1; cfg->counter keys the agent call behind env step 0, + k behind step k.  Results equal those of the
+ * two-launch sequence wherever that sequence is deterministic (envs that do not race for the same table entries;
+ * the envs of one wave always). */
+struct pvder_plan;
+int pvder_plan_rollout_fused_agent(const struct pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                                   int n_steps, float *out, float *stats, int32_t *progress, const pvder_qagent_cfg *cfg,
+                                   float *q_table, int64_t *state, uint8_t *action, uint8_t *alive, double *ep_reward,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -533,3 +533,34 @@ def test_reference_helper_surface_of_the_single_env(gpu_device, capsys):
     # 'dec' sends action 1 (+Q_ref, the reference's labels :482-487): 8 steps x 375 VAR
     assert table['voltage_regulation']['dec']['ref'][1] == pytest.approx(8 * 375.0, rel=1e-5)
     assert "'return'" in capsys.readouterr().out                                    # show_env_returns printed the table
+
+
+@pytest.mark.parametrize("N,bins", [(1, 6), (8, 6), (64, 4)])
+def test_closed_loop_fused_episode_equals_the_two_launch_loop(gpu_device, N, bins):
+    """the agent step INSIDE the fused rollout (pvder_plan_rollout_fused_agent: env step, discretise,
+    table update, epsilon-greedy choice, next env step -- the env state and the agent's registers in registers, the
+    episode-ending step by the finish kernel) against train_fused's two launches per env step: the same table, bit
+    for bit, the same returns, states, actions, env state -- for one env, and for the envs of one wave (which step
+    in lockstep in both forms; across waves the two-launch form itself is a race for shared table entries)."""
+    from gym_PVDER_amd.agents import BatchedQAgent
+    from gym_PVDER_amd.vec_env import PVDERVec
+    res = []
+    for closed in (False, True):
+        env = PVDERVec(N, device=gpu_device, n_sim_time_steps_per_env_step=15, max_sim_time=6.0, auto_reset=False, seed=4,
+                       events_spec=both_events_spec_())
+        agent = BatchedQAgent(env, bins=bins, seed=21)
+        agent.explore_spec = dict(agent.explore_spec, EPSILON_DECAY=0.5)        # exploration -> mixed -> mostly greedy
+        stats = agent.train_fused(episodes=4, closed_loop=closed)
+        torch.cuda.synchronize()
+        res.append((agent.q_table, env.fstate.clone(), env.istate.clone(), env.out.clone(), stats, agent._counter))
+    a, b = res
+    assert a[5] == b[5] == 4 * (24 + 1)
+    assert torch.equal(a[0], b[0])                                   # the whole table
+    assert int((a[0] != -2.0).any(dim=1).sum()) >= 2                 # ... which has learnt something
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert a[4] == b[4]                                              # episode statistics (returns)
+
+
+def both_events_spec_():
+    from helpers import both_events_spec
+    return both_events_spec()
