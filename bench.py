@@ -275,6 +275,32 @@ def fixed_policy_leg(torch, dev, N, n_sub):
     return out
 
 
+def etdlin64_leg(torch, dev, N, n_sub, steps=40):
+    """BASELINE configs[4] on the tolerance-match path that is not stability-bound: fp64 etdlin with step doubling on a
+    dyadic menu as its error control (rtol 1e-6, atol 1e-8 in the RK45 kernel's norm), the RK45 kernel behind it."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, integrator="etdlin64", seed=2024,
+                   events_spec=events_on_spec(), auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(78)
+    acts = torch.randint(0, 5, (steps + 4, N), generator=gen, device=dev, dtype=torch.uint8)
+    for i in range(4):
+        env.step(acts[i], return_tensors=False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(4, steps + 4):
+        env.step(acts[i], return_tensors=False)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "dtype": "f64", "rtol": env.rtol, "atol": env.atol,
+            "workload": "BASELINE configs[4]: %d envs, fp64 etdlin with step doubling (tolerance-match), same events and random actions" % N,
+            "kernel": "step_etdlin64_kernel (+ step_rk45_kernel<double,3> for envs handed over: none in this run)",
+            "ms_per_step": 1e3 * el / steps, "hbm_frac": BYTES_PER_ENV_STEP["f64"] * N / (el / steps) / HBM_PEAK,
+            "n_nonfinite": env.step_stats()["n_nonfinite"],
+            "parity": "tests/test_gpu_fullsize.py::test_configs4_fp64_etdlin64_full_size_vs_converged_bridge (< 2e-6)"}
+
+
 def rk45_leg(torch, dev, N, n_sub, steps=2):
     """BASELINE configs[4]: the same batch through the fp64 adaptive Dormand-Prince kernel (rtol 1e-6, atol 1e-8) --
     the tolerance-match path; stability-bound at h ~ 4 us."""
@@ -791,6 +817,8 @@ def run_rank(args):
                     out["fixed_policy"] = fixed_policy_leg(torch, dev, N, args.n_sub)
                 if args.rk45_steps > 0:
                     out["rk45"] = rk45_leg(torch, dev, N, args.n_sub, args.rk45_steps)
+                    out["etdlin64"] = etdlin64_leg(torch, dev, N, args.n_sub)
+                    out["etdlin64"]["speedup_over_rk45"] = out["etdlin64"]["value"] / out["rk45"]["value"]
             except Exception as exc:                 # side legs: never lose the headline over them
                 warnings.append("side leg failed: %r" % (exc,))
         out.update(cpu)

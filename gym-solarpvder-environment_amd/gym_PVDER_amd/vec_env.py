@@ -29,7 +29,7 @@ SIM_TIME_STEP = 1.0 / 60.0               # env_sim_spec['sim_time_step'], PVDER_
 MAX_EPISODE_STEPS = 500                  # gym_PVDER/__init__.py:10
 # integrator steps per 1/60 s sim time step (DESIGN.md "Kernels"): classic RK4 is stability-bound
 # by the current loop (h <= ~4.5 us); ETDRK4 propagates that loop exactly and is accuracy-bound
-DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1}
+DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1, "etdlin64": 32}
 # ETDRK4 step schedule: a sim time step that starts at an input jump (new action / event) takes a first
 # step of 1/(60*micro) s and one more over the remainder (graded), every other one DEFAULT_MICRO_COARSE
 DEFAULT_MICRO_COARSE = 1
@@ -132,7 +132,10 @@ class PVDERVec(EnvSpecMixin):
                     the whole linear response sits in the matrix exponential; two steps per env step),
                     'etdrk4' (fp32 exponential RK of stiff order 4 with only the stiff current loop in
                     the exponential; 16 steps per env step), 'rk4' (fp32 fixed-step classic RK4
-                    micro-stepping) or 'rk45' (fp64 adaptive Dormand-Prince)
+                    micro-stepping), 'rk45' (fp64 adaptive Dormand-Prince: the literal tolerance-match path,
+                    stability-bound at 0.5 s per batched step) or 'etdlin64' (fp64 etdlin with step doubling on a dyadic
+                    menu as its error control -- rtol / atol in the RK45 kernel's norm --, the RK45 kernel behind it
+                    for the envs the balanced reduction does not cover: the tolerance-match path at ~10^4 x the rate)
         micro_steps: classic RK4: steps per 1/60 s sim time step (default 4096); ETDRK4 / etdlin: the
                     first step behind an input jump is 1/(60*micro_steps) s (default 32)
         micro_coarse: ETDRK4 only -- steps per sim time step that does not start at an input jump
@@ -219,7 +222,7 @@ class PVDERVec(EnvSpecMixin):
         self._lib = _native.lib()
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.fdtype = torch.float64 if integrator == "rk45" else torch.float32
+        self.fdtype = torch.float64 if integrator in ("rk45", "etdlin64") else torch.float32
         N = num_envs
         self._alloc_event_tables()
         self.fstate = torch.zeros((self.ns + 2, N), dtype=self.fdtype, device=self.device)
@@ -230,7 +233,7 @@ class PVDERVec(EnvSpecMixin):
         self.stats = torch.zeros((n_wg * (self._lib.pvder_block_size() // 64), 4), dtype=torch.float32,
                                  device=self.device)           # one slot per wave (include/pvder_hip.h)
         self._progress = torch.zeros(n_wg, dtype=torch.int32, device=self.device)     # scratch of the fused rollouts
-        self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator == "rk45" else None
+        self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator in ("rk45", "etdlin64") else None
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
         self._needs_reset = True
@@ -477,6 +480,24 @@ class PVDERVec(EnvSpecMixin):
 
     est_guard = etd_linear.EST_GUARD
 
+    def _lin64_coef(self, cfg) -> _native.LinCoef:
+        """``struct pvder_lin_coef`` of the etdlin64 path: the fp64 f-form matrices of the tick and of the dyadic menu
+        (etd_linear.pack_block64) on the device."""
+        key = (self.der_id if not self.der_config else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, "f64")
+        if getattr(self, "_lin64_key", None) != key:
+            host = PVDERVec._lin_cache.get(key)
+            if host is None:
+                L, _ = etd_linear.jacobian(self.par, self.der_id)
+                host = etd_linear.pack_block64(L, cfg.n_sub, cfg.micro)
+                PVDERVec._lin_cache[key] = host
+            self._lin64_dev = torch.from_numpy(host).to(self.device)
+            self._lin64_key = key
+        lc = _native.LinCoef()
+        lc.sets = self._lin64_dev.data_ptr()
+        lc.n_sets = 1 + etd_linear.LIN64_LEVELS
+        lc.sched, lc.n_sched_rows, lc.est_guard = None, 0, 1.0
+        return lc
+
     def _make_plan(self):
         """Fold cfg / reset block / coefficients into a C-side plan (include/pvder_hip.h "plans")."""
         cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
@@ -490,6 +511,20 @@ class PVDERVec(EnvSpecMixin):
                 # (env steps of more than ~1000 sim time steps: the schedule table cannot list their segments)
                 logger.warning("etdlin cannot tile this step schedule (%s): this env steps with integrator='etdrk4'", e)
                 integrator = "etdrk4"
+        if integrator == "etdlin64":
+            try:
+                if self.ns != 23:
+                    raise ValueError("three-phase model only")
+                lin = C.byref(self._lin64_coef(cfg))
+                h = C.c_void_p()
+                _native.check(self._lib.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS["etdlin64"], self._par_c,
+                                                          C.byref(cfg), C.byref(ar), None, lin, self.num_envs), "pvder_plan_create")
+                self._plan_integrator, self._plan = "etdlin64", h
+                return h
+            except ValueError as e:
+                # (single phase, or an event grid that cuts env steps: one segment per env step is what the kernel takes)
+                logger.warning("etdlin64 does not cover this configuration (%s): this env steps with integrator='rk45'", e)
+                integrator, lin = "rk45", None
         self._plan_integrator = integrator
         h = C.c_void_p()
         _native.check(self._lib.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS[integrator], self._par_c,

@@ -281,7 +281,14 @@ int pvder_step_etdlin_f32(const double *par, const pvder_step_cfg *cfg, const pv
  * elements (0: every step overwrites the same block).  A finished env (status != 0 on entry, no
  * auto-reset) returns the stale tuple: the step kernels leave its rows alone, and block k > 0 receives
  * them from block k-1; block 0 must hold them on entry (copy the block of the preceding step there). */
-enum pvder_integrator { PVDER_INT_ETDLIN = 0, PVDER_INT_ETDRK4 = 1, PVDER_INT_RK4 = 2, PVDER_INT_RK45 = 3 };
+/* PVDER_INT_ETDLIN64 (plans only): the tolerance-match path of BASELINE configs[4] that is not stability-bound -- the
+ * etdlin scheme in fp64 on the balanced reduction with step doubling on a dyadic menu as its error control (cfg->rtol /
+ * cfg->atol in the RK45 kernel's norm), the adaptive RK45 kernel behind it for the envs the reduction does not cover
+ * (fstate / out double, hstep as for RK45).  `lin->sets`: device DOUBLES, (1 + levels) sets of 6 x [11 columns][12] f-form
+ * matrices (column by column) -- set 0 for the tick, set 1 + j for (n_sub / 60 - tick) / 2^(j+1) s (gym_PVDER_amd/etd_linear.py::
+ * pack_block64); lin->n_sets = 1 + levels (3 .. 10); sched / len_ticks / est_guard unused.  Three-phase model, events on
+ * env-step boundaries (PVDER_EINVAL otherwise). */
+enum pvder_integrator { PVDER_INT_ETDLIN = 0, PVDER_INT_ETDRK4 = 1, PVDER_INT_RK4 = 2, PVDER_INT_RK45 = 3, PVDER_INT_ETDLIN64 = 4 };
 typedef struct pvder_plan pvder_plan;
 int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, const pvder_step_cfg *cfg,
                       const pvder_autoreset *ar, const float *coef, const pvder_lin_coef *lin, int n_env);

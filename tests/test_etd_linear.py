@@ -228,3 +228,43 @@ def test_fp32_emulation_of_the_kernel_arithmetic_vs_golden(lin50, name):
     got, want = np.array(out), g["obs"][:len(out), :10]
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-6
     assert est < el.EST_GUARD / 10                   # these cases stay far from the hand-over guard
+
+
+def test_etdlin64_step_doubling_reference_vs_golden(lin50):
+    """The tolerance-match scheme of the etdlin64 kernel in numpy fp64 (el.lin64_reference_step: ETD3RK tick + 2^(j+1)
+    equal ETD3RK steps, accepted when two consecutive levels agree to the tolerance) against a converged golden:
+    below 2e-6 on the observation trajectory with rtol 1e-6 / atol 1e-8 -- what BASELINE configs[4] asks of the fp64
+    path --, PVDER-v0 steps resolved at levels 1-2 (tick + 4 / tick + 8 steps), the step behind the reset (the PLL swings
+    a quarter turn into lock) near the top of the menu."""
+    par, c, L, _ = lin50
+    g = np.load(os.path.join(GOLD, "traj_random_both_n15.npz"))
+    n, acts, vgt, sit = int(g["n"]), g["actions"][:16], g["vgrid"], g["sinsol"]
+    K = len(vgt) - 1
+    s0, ds = int(round(float(g["ev_t0"]) * 60)), int(round(float(g["ev_dt"]) * 60))
+    y0f = der_model.steady_state(par, "50")
+    y = np.concatenate([y0f[:6], y0f[18:]]).astype(np.float64)
+    q, v = 0.0, par[der_model.IDX["VDC_REF0"]]
+    dq, dv = 25.0 * n / 50e3, 0.02 * n / 500.0
+
+    def observe(y, vg, si, q, v):
+        i = complex(y[0], y[1]); va = complex(c["GR"], c["GI"]) * vg + complex(c["kviR"], c["kviI"]) * i
+        S = 0.5 * c["PH"] * va * i.conjugate()
+        ppv = max(0.0, y[6] * (c["pvA"] * si + c["pvB"] - c["pvB"] * np.exp(c["pvK"] * y[6])))
+        return np.array([i.real, i.imag, va.real, va.imag, S.real, S.imag, y[6], ppv, v, q])
+    rowof = lambda gk: 0 if gk < s0 else min((gk - s0) // ds + 1, K)
+    out, ksub, levels, cache = [observe(y, vgt[0], sit[0], q, v)], 0, [], {}
+    for a in acts:
+        q += dq * (int(a == 1) - int(a == 2)); v += dv * (int(a == 3) - int(a == 4))
+        row = rowof(ksub)
+        y, lvl = el.lin64_reference_step(c, L, y, (vgt[row], sit[row], q, v), n, 32, 1e-6, 1e-8, cache=cache)
+        levels.append(lvl)
+        ksub += n
+        out.append(observe(y, vgt[rowof(ksub)], sit[rowof(ksub)], q, v))
+    got, want = np.array(out), g["obs"][:len(out), :10]
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-6
+    assert levels[0] >= 6 and all(1 <= lv <= 4 for lv in levels[1:]), levels
+    blk = el.pack_block64(L, n, 32)
+    assert blk.shape == ((1 + el.LIN64_LEVELS) * el.LIN64_SET,) and blk.dtype == np.float64
+    M43 = el.etd3rk_f_matrices(L, (n / 60.0 - 2 / 1920.0) / 4)[5]           # level 1, last matrix: stored column by column
+    got43 = blk[2 * el.LIN64_SET + 5 * 132: 2 * el.LIN64_SET + 6 * 132].reshape(11, 12)[:, :11]
+    assert np.array_equal(got43, M43.T)

@@ -192,8 +192,11 @@ def test_no_step_kernel_reads_the_dispatch_packet(tmp_path):
         assert props & 0x8, (name, "descriptor layout self-check: every kernel here takes kernel arguments")
         # no real scratch use: hipcc sometimes leaves a dead 20-byte frame object behind SGPR spills that it
         # turned into VGPR lanes (no scratch instruction in the kernel; measured: no effect on throughput)
-        if "rollout_kernel" in name or "finish_kernel" in name:
+        if "rollout_kernel" in name or "finish_kernel" in name or "rollout_agent_kernel" in name:
             continue            # the fused rollouts: one launch per K env steps, a few spilled loop-carried values
+        if "etdlin64" in name:
+            assert not props & 0x2, (name, "ENABLE_SGPR_DISPATCH_PTR")
+            continue            # the fp64 tolerance-match kernel calls its step as a real function (0.5 ms kernel: not latency-bound)
         assert private_seg <= 32, (name, "uses scratch", private_seg)
         assert not props & 0x2, (name, "ENABLE_SGPR_DISPATCH_PTR")
 
