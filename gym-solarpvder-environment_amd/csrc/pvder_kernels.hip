@@ -43,6 +43,13 @@
 namespace {
 // Debug-only in-kernel timeline (tools/trace_timeline.py builds a separate library with
 // -DPVDER_TRACE; the shipped library compiles these to nothing).  Slot = 100 MHz wall clock of wave 0.
+#ifdef PVDER_DEBUG_COUNTERS
+// debug build only (tools/diag_counters.py): why envs leave the standard path -- lanes counted per reason
+__device__ unsigned long long g_dbg[16];
+#define PVDER_DBG_COUNT(slot, cond) do { if (cond) atomicAdd(&g_dbg[slot], 1ull); } while (0)
+#else
+#define PVDER_DBG_COUNT(slot, cond) do { } while (0)
+#endif
 #ifdef PVDER_TRACE
 __device__ unsigned long long g_trace[4096 * 32];
 #define PVDER_TRACE_AT(slot)                                                                   \
@@ -1299,6 +1306,10 @@ struct LinK {
                                      // to the 23-state path
     float ir2_careful;               // |iref_a|^2 at the start of a step above which the env takes the careful pass
                                      // (current limit: hybrid steps with the outer loops' anti-windup, finer schedule)
+    float sat2_hard;                 // |m|^2 beyond which an env leaves the balanced reduction for the 23-state path.  Between
+                                     // the smooth-step guard (0.998 m_limit: what two samples per 0.125 s step can vouch
+                                     // for) and this one (0.9995: what the careful pass's 24 samples can) it takes the
+                                     // careful pass -- the anti-windup does not engage below m_limit, the reduction is exact
 };
 struct LinArgs {
     EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
@@ -1391,7 +1402,8 @@ __device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys)
 
 // One ETD3RK step of every lane from Y with the coefficient set in Ac: Yn = y+, returns whether the lane
 // must be handed to the 23-state path (|m| guard at the start, the middle -- stage a --, the end of the step;
-// embedded error indicator); near_ilim: |iref| at the start of the step is within 10 % of the current limit
+// embedded error indicator, |m| beyond the hard guard); near_ilim: |iref| at the start of the step is within 10 % of the
+// current limit, or |m| beyond the smooth-step guard at the start, middle or end (careful pass)
 template <int PH>
 __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
                                            const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
@@ -1432,25 +1444,26 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
     const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
-    near_ilim = ir2a > irg;          // the current reference comes near its limit: the careful pass redoes the env step
-    return mmax > Ec.sat2_smooth || est > G.Lk.est_guard;
+    // the current reference or the duty cycle comes near its limit: the careful pass redoes the env step
+    near_ilim = ir2a > irg || mmax > Ec.sat2_smooth;
+    return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
 // Does the duty cycle stay clear of its limit over the TICK behind an input jump (Y -> acc)?  The jump kicks the
 // under-damped current loop (poles -1.0e5 +- j5.8e5 1/s, zeta = 0.17): m = Kp_GCC u + x rings around its new value --
 // reached well inside the tick, 20 decay times -- with a first overshoot of exp(-pi zeta / sqrt(1 - zeta^2)) = 0.58
-// of the jump.  Peak = |m_new| + 0.6 |m_new - m_old| against the smooth-step guard: the clearance an env needs
+// of the jump.  Peak = |m_new| + 0.6 |m_new - m_old| against the guards (lin_integrate): the clearance an env needs
 // follows the jump it actually sees (an action alone: none; a 2 % grid-voltage event: 1.2 %) where a blanket 3 % sent
 // every env beyond |m| = 0.97 to the 23-state path at every event (among 65 536 envs on a Vdc_ref ramp: thousands).
-__device__ __forceinline__ bool lin_tick_trip(const ModelK<float> &P, const EtdK &Ec, const pvder::v4f (&Y)[3],
-                                              const pvder::v4f (&acc)[3], float m2a) {
+__device__ __forceinline__ float lin_tick_peak2(const ModelK<float> &P, const pvder::v4f (&Y)[3],
+                                                const pvder::v4f (&acc)[3], float m2a) {
     using namespace pvder;
     const v2 m0 = fma2(bc2(P.KpG), mk2(Y[1].x, Y[1].y), mk2(Y[0].z, Y[0].w));
     const v2 mn = fma2(bc2(P.KpG), mk2(acc[1].x, acc[1].y), mk2(acc[0].z, acc[0].w));
     const v2 dm = mn - m0;
     const float n2 = __builtin_fmaf(mn.y, mn.y, mn.x * mn.x), d2 = __builtin_fmaf(dm.y, dm.y, dm.x * dm.x);
     const float peak2 = n2 + 1.2f * __builtin_sqrtf(n2 * d2) + 0.36f * d2;          // (|m_new| + 0.6 |dm|)^2
-    return fmaxf(m2a, peak2) > Ec.sat2_smooth;
+    return fmaxf(m2a, peak2);
 }
 
 // next byte of a lane's schedule row; a byte with bit 7 set continues the row in another one (rows behind the
@@ -1508,9 +1521,11 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            bool trip = lin_tick_trip(P, Ec, Y, acc, m2a);
+            const float pk2 = lin_tick_peak2(P, Y, acc, m2a);
+            bool trip = pk2 > G.Lk.sat2_hard;
             if (run) {
-                if constexpr (SPLIT) { careful |= ir2a > irg; defer |= trip && !careful; } else defer |= trip || ir2a > irg;
+                if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
+                else defer |= pk2 > Ec.sat2_smooth || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
             }
             // (a wave whose envs all sit at the current limit -- a policy that holds one Q_ref action -- goes
@@ -1549,9 +1564,11 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const bool trip = lin_tick_trip(P, Ec, Y, acc, m2a);
+            const float pk2 = lin_tick_peak2(P, Y, acc, m2a);
+            const bool trip = pk2 > G.Lk.sat2_hard;
             if (start && !done) {
-                if constexpr (SPLIT) { careful |= ir2a > irg; defer |= trip && !careful; } else defer |= trip || ir2a > irg;
+                if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
+                else defer |= pk2 > Ec.sat2_smooth || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 start = false;
             }
@@ -1666,7 +1683,7 @@ __device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::Lin
                             fabsf(Yn[1].z - acc2[0][1].z));
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
-    return mmax > Ec.sat2_smooth || est > G.Lk.est_guard;
+    return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
 // where the quadratic through (0, s0), (1/2, sm), (1, s1) crosses zero, as a fraction of the step (s0, s1 of
@@ -1702,6 +1719,8 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
     bool trip = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a1, Yn, irm, ire);
     const float s1 = ire - lim;
     const bool need2 = act && (from_free ? s1 > 0.f : s1 < 0.f);
+    PVDER_DBG_COUNT(6, act);
+    PVDER_DBG_COUNT(7, need2);
     if (__builtin_amdgcn_readfirstlane(__any((int)need2))) {
         // the limit is crossed inside the step: the integrators run free for the fraction `tau` (1 - tau) of it
         const float tau = lin_cross_frac(s0, irm - lim, s1);
@@ -1711,6 +1730,7 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
         const float s2 = ire - lim;
         if (need2) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip2; }
         const bool need3 = need2 && (from_free ? s2 < 0.f : s2 > 0.f);
+        PVDER_DBG_COUNT(8, need3);
         if (__builtin_amdgcn_readfirstlane(__any((int)need3))) {
             // it does not stay on the far side: sliding along the limit -- the step ends on s = 0 (secant between
             // the two evaluations that bracket it)
@@ -1756,7 +1776,8 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
             bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a, -1.f);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const bool trip = lin_tick_trip(P, Ec, Y, acc, m2a);
+            const bool trip = lin_tick_peak2(P, Y, acc, m2a) > G.Lk.sat2_hard;
+            PVDER_DBG_COUNT(4, start && !done && !defer && trip);
             if (start && !done) {
                 defer |= trip;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
@@ -1776,6 +1797,7 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
             v4f Yn[3];
             const bool mine = todo && sidx == s_now;
             const bool trip = lin_hybrid_step<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, mine, Yn);
+            PVDER_DBG_COUNT(5, mine && trip);
             if (mine) {
                 defer |= trip;
                 Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -1842,8 +1864,17 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         lin_from_rows<PH>(ys, Y);
         PVDER_TRACE_AT(2);
         bool careful;
+        const bool defer0 = defer;          // (off balance / forced: the 23-state path whatever the standard pass finds)
         defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, careful, 0);
-        careful = careful && L.run && !defer;
+        PVDER_DBG_COUNT(0, L.run);
+        PVDER_DBG_COUNT(1, L.run && defer && !careful);
+        PVDER_DBG_COUNT(9, L.run && defer && careful);
+        // an env the standard pass gave up on in one step AND flagged for the careful pass in a later one (it crossed the
+        // 0.9 |iref| / 0.998 |m| threshold inside the env step: what tripped was the standard pass's own coarse, limit-blind
+        // step) belongs to the careful pass, which decides with its own guards
+        careful = careful && L.run && !defer0;
+        defer = defer0 || (defer && !careful);
+        PVDER_DBG_COUNT(2, careful);
         if (__builtin_amdgcn_readfirstlane(__any((int)careful))) {
             // envs at the current limit: their env step again, from the state it started with, by the careful pass
             v4f Yc[3];
@@ -1851,6 +1882,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             if (careful) { Y[0] = Yc[0]; Y[1] = Yc[1]; Y[2] = Yc[2]; }
             const bool dc = lin_integrate_careful<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, careful, false);
             defer |= careful && dc;
+            PVDER_DBG_COUNT(3, careful && dc);
         }
         if (L.run && !defer) {
             lin_to_rows<PH>(Y, ys);
@@ -1876,7 +1908,9 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     if constexpr (PH == 3) {
         // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state
         // path right here -- no second launch
+        PVDER_DBG_COUNT(10, defer);
         if (__syncthreads_or((int)defer)) {
+            PVDER_DBG_COUNT(11, threadIdx.x == 0);
             KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
             asm volatile("" : "+s"(kb));
             etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
@@ -2941,6 +2975,7 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         K.est_guard = lin->est_guard;
         // the careful pass takes over where |iref| comes within 10 % of the current limit
         K.ir2_careful = (float)(0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]);
+        K.sat2_hard = (float)(0.9995 * 0.9995 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
     }
     return 0;
 }
@@ -3318,6 +3353,16 @@ int pvder_plan_rollout_gather_rows(const pvder_plan *plan, pvder_gather *g, void
     return 0;
 }
 
+#ifdef PVDER_DEBUG_COUNTERS
+int pvder_debug_counters(unsigned long long *host, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && clear) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
+    }
+    return -(int)e;
+}
+#endif
 #ifdef PVDER_TRACE
 int pvder_debug_trace(unsigned long long *host, int n_words) {
     return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * (size_t)n_words);
