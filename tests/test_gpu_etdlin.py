@@ -349,6 +349,21 @@ def test_native_step_gather_world1(gpu_device):
         a.step(acts[k], return_tensors=False)
     torch.cuda.synchronize()
     assert torch.equal(nat.last(), a.out) and torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate)
+    # payload choices: (reward, done) only; the whole block every third step
+    for payload, every in (("reward_done", 1), ("full_every_k", 3)):
+        nat.payload, nat.gather_every = payload, every
+        for k in range(6):
+            idx = nat._k                                # number of this step within the gather object's life
+            a.step(acts[k], return_tensors=False)
+            nat.rollout(acts[k:k + 1])
+            nat.drain()
+            torch.cuda.synchronize()
+            full = payload == "full_every_k" and (idx + 1) % every == 0
+            if full:
+                assert torch.equal(nat.last()[:13], a.out), (payload, k)
+            else:
+                assert torch.equal(nat.last()[:2], a.out[11:13]), (payload, k)
+            assert torch.equal(b.out, a.out)
     nat.close()
     rc.close()
     dist.destroy_process_group()
