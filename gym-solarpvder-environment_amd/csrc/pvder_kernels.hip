@@ -2210,6 +2210,80 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
     if (threadIdx.x == 0) Rk.progress[blockIdx.x] = k1;
 }
 
+#ifdef PVDER_RK45_LAMBDA
+// REPRODUCER BUILD ONLY (tools/hipcc_rk45_lambda_repro.sh): one sim time step of the adaptive pair factored into a helper that
+// takes the right-hand side as a lambda -- the arithmetic of the written-out loop in step_rk45_kernel, line for line.
+// hipcc (ROCm 7.2) compiled the 23-state instance of this to code that returns NaN states in round 2.
+template <typename T, int NS, typename F>
+__device__ __forceinline__ void rk45_sim_step(F rhsf, T *y, T &hn, int max_it, T rtol, T atol) {
+    constexpr T c2 = 1. / 5, c3 = 3. / 10, c4 = 4. / 5, c5 = 8. / 9;
+    constexpr T a21 = 1. / 5, a31 = 3. / 40, a32 = 9. / 40, a41 = 44. / 45, a42 = -56. / 15, a43 = 32. / 9,
+                a51 = 19372. / 6561, a52 = -25360. / 2187, a53 = 64448. / 6561, a54 = -212. / 729,
+                a61 = 9017. / 3168, a62 = -355. / 33, a63 = 46732. / 5247, a64 = 49. / 176,
+                a65 = -5103. / 18656, b1 = 35. / 384, b3 = 500. / 1113, b4 = 125. / 192,
+                b5 = -2187. / 6784, b6 = 11. / 84;
+    constexpr T e1 = 71. / 57600, e3 = -71. / 16695, e4 = 71. / 1920, e5 = -17253. / 339200,
+                e6 = 22. / 525, e7 = -1. / 40;
+    const T Tend = (T)(1.0 / 60.0);
+    const T tq = (T)120;
+    T t = (T)0;
+    T k1[NS];
+    rhsf(y, (T)0, k1);
+    // bounded: every lane leaves after at most 2e7 attempts per 1/60 s (h >= ~1e-9 s)
+    for (int it = 0; it < max_it && t < Tend * (T)(1.0 - 1e-14); ++it) {
+        T h = hn;
+        bool last = false;
+        if (t + h >= Tend) { h = Tend - t; last = true; }
+        T k2[NS], k3[NS], k4[NS], k5[NS], k6[NS], yt[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) yt[q] = y[q] + h * (a21 * k1[q]);
+        rhsf(yt, (t + c2 * h) * tq, k2);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) yt[q] = y[q] + h * (a31 * k1[q] + a32 * k2[q]);
+        rhsf(yt, (t + c3 * h) * tq, k3);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) yt[q] = y[q] + h * (a41 * k1[q] + a42 * k2[q] + a43 * k3[q]);
+        rhsf(yt, (t + c4 * h) * tq, k4);
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            yt[q] = y[q] + h * (a51 * k1[q] + a52 * k2[q] + a53 * k3[q] + a54 * k4[q]);
+        rhsf(yt, (t + c5 * h) * tq, k5);
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            yt[q] = y[q] + h * (a61 * k1[q] + a62 * k2[q] + a63 * k3[q] + a64 * k4[q] + a65 * k5[q]);
+        rhsf(yt, (t + h) * tq, k6);
+        T errv[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            yt[q] = y[q] + h * (b1 * k1[q] + b3 * k3[q] + b4 * k4[q] + b5 * k5[q] + b6 * k6[q]);
+            errv[q] = e1 * k1[q] + e3 * k3[q] + e4 * k4[q] + e5 * k5[q] + e6 * k6[q];
+        }
+        rhsf(yt, (t + h) * tq, k2);   // k7 (reuses k2)
+        T err = (T)0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const T ek = h * (errv[q] + e7 * k2[q]);
+            const T ay = fmax(fabs(y[q]), fabs(yt[q]));
+            const T sc = atol + rtol * ay;
+            const T r = ek / sc;
+            err += r * r;
+        }
+        err = sqrt(err * (T)(1.0 / NS));
+        const bool ok = !(err > (T)1) || h < (T)1e-12;   // NaN err: accept, caught by the epilogue
+        if (ok) {
+            t += h;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { y[q] = yt[q]; k1[q] = k2[q]; }   // FSAL
+        }
+        T fac = (T)0.9 * pow(fmax(err, (T)1e-30), (T)-0.2);
+        fac = fmin((T)5, fmax((T)0.2, fac));
+        if (!ok) hn = h * fac;
+        else if (!last || h * fac < hn) hn = h * fac;
+        if (ok && last) break;
+    }
+}
+#endif
+
 // =============================================================================================
 // adaptive Dormand-Prince RK45 (per-lane step size; fp64 tolerance-match path)
 // =============================================================================================
@@ -2243,6 +2317,10 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
         for (int s = 0; s < C.n_sub; ++s) {
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + L.ec], (T)ev_si[(size_t)row * N + L.ec], S);
+#ifdef PVDER_RK45_LAMBDA
+            rk45_sim_step<T, NS>([&](const T *yy, T tau, T *dy) { pvder::rhs<T, PH>(P, S, yy, tau, L.qref, L.vdcref, dy); },
+                                 y, hn, C.max_it, C.rtol, C.atol);
+#else
             T t = (T)0;
             T k1[NS];
             pvder::rhs<T, PH>(P, S, y, (T)0, L.qref, L.vdcref, k1);
@@ -2298,6 +2376,7 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
                 else if (!last || h * fac < hn) hn = h * fac;
                 if (ok && last) break;
             }
+#endif
         }
         L.ksub += C.n_sub;
         L.steps += 1;
