@@ -1310,6 +1310,8 @@ struct LinK {
                                      // the smooth-step guard (0.998 m_limit: what two samples per 0.125 s step can vouch
                                      // for) and this one (0.9995: what the careful pass's 24 samples can) it takes the
                                      // careful pass -- the anti-windup does not engage below m_limit, the reduction is exact
+    float seqE[18];                  // exp(A0 T): what an env step does to a negative- / zero-sequence component (i, x, u) of an
+                                     // env slightly off balance (lin_seq_split); complex 3x3, row-major (re, im)
 };
 struct LinArgs {
     EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
@@ -1373,6 +1375,84 @@ __device__ __forceinline__ bool lin_unbalanced(const float *ys) {
     return ei > 4e-10f * (i2.x + i2.y) + 1e-20f || ex > 4e-10f * (x2.x + x2.y) + 1e-20f || eu > 4e-18f;
 }
 
+// ---- envs slightly OFF BALANCE stay on the matrix-core path: symmetrical components -----------------------------------
+// z+ = (z_a + a z_b + a^2 z_c)/3, z- = (z_a + a^2 z_b + a z_c)/3, z0 = (z_a + z_b + z_c)/3 of z = i, x, u (a = e^{+j120}).
+// Below the duty-cycle limit the phase equations are complex-linear in (i_p, x_p, u_p) given the shared states, and the
+// forcing (grid voltage, current reference) is positive-sequence: z+ with the shared states obeys the BALANCED model --
+// up to terms quadratic in z-, z0 in the power sums and a 2wt ripple K_vi i- in the PLL input --, z- and z0 decay by
+// themselves, z(T) = exp(A0 T) z(0) (LinK::seqE; host: gym_PVDER_amd/etd_linear.py::seq_propagator).  What survives an
+// anti-windup episode for seconds is the integrator of the current controller (x' = -(Ki/Kp) x, 1/3 per second): a
+// 1e-3 imbalance that kept an env on the 23-state path for ~50 env steps and its whole workgroup waiting for it.
+// An off-balance env whose z-, z0 are small (the neglected terms below 1e-5 relative, at the start and at the end of the
+// env step) runs the standard / careful pass on z+; its duty-cycle guards are tightened by (1 + r)^2, r = 1.6 x the
+// share of |m-| + |m0| in |m+| (each PHASE must stay clear of the limit; 1.6: the ringing of the fast modes).
+__device__ __forceinline__ v2 seq_rot(v2 z, float sgn) {            // z e^{sgn j120}
+    using namespace pvder;
+    return bc2(-0.5f) * z + swp(z) * mk2(-sgn * kHalfSqrt3, sgn * kHalfSqrt3);
+}
+// (z-, z0) of one quantity from its three phase values; zp: the positive-sequence component
+__device__ __forceinline__ void seq_of(v2 za, v2 zb, v2 zc, v2 &zp, v2 &zn, v2 &z0) {
+    using namespace pvder;
+    const v2 third = bc2(1.f / 3.f);
+    zp = third * (za + seq_rot(zb, 1.f) + seq_rot(zc, -1.f));
+    zn = third * (za + seq_rot(zb, -1.f) + seq_rot(zc, 1.f));
+    z0 = third * (za + zb + zc);
+}
+__device__ __forceinline__ v2 cmul(float er, float ei, v2 z) { return pvder::mk2(er * z.x - ei * z.y, er * z.y + ei * z.x); }
+__device__ __forceinline__ float abs2(v2 z) { return __builtin_fmaf(z.y, z.y, z.x * z.x); }
+// the components an env step later: zo = E z
+__device__ __forceinline__ void seq_advance(const float (&E)[18], const v2 (&z)[3], v2 (&zo)[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        zo[r] = cmul(E[6 * r], E[6 * r + 1], z[0]) + cmul(E[6 * r + 2], E[6 * r + 3], z[1]) + cmul(E[6 * r + 4], E[6 * r + 5], z[2]);
+}
+constexpr float kSeqI2Max = 1e-5f, kSeqMI2Max = 1e-10f, kSeqRMax = 0.05f;
+// Split the 18 phase rows in ys: returns whether the env qualifies; then ys[0..5] hold z+ (the rows lin_from_rows reads)
+// and msc = (1 + r)^2.  ys[6..17] are left alone (dead: lin_seq_merge re-reads the rows it needs from memory, so that no
+// register stays live across the integration for the sake of an env in ten thousand).
+__device__ __forceinline__ bool lin_seq_split(const ModelK<float> &P, const LinK &Lk, float *ys, float &msc) {
+    using namespace pvder;
+    v2 zp[3], zn[3], z0[3], en[3], e0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        seq_of(mk2(ys[2 * k], ys[2 * k + 1]), mk2(ys[6 + 2 * k], ys[7 + 2 * k]), mk2(ys[12 + 2 * k], ys[13 + 2 * k]), zp[k], zn[k], z0[k]);
+    seq_advance(Lk.seqE, zn, en);
+    seq_advance(Lk.seqE, z0, e0);
+    const v2 kp = bc2(P.KpG);
+    const float ip2 = abs2(zp[0]), mp2 = abs2(fma2(kp, zp[2], zp[1]));
+    const float i2 = abs2(zn[0]) + abs2(z0[0]), m2 = abs2(fma2(kp, zn[2], zn[1])) + abs2(fma2(kp, z0[2], z0[1]));
+    const float j2 = abs2(en[0]) + abs2(e0[0]), n2 = abs2(fma2(kp, en[2], en[1])) + abs2(fma2(kp, e0[2], e0[1]));
+    const float r = 1.6f * __builtin_sqrtf(2.f * fmaxf(m2, n2) / mp2);
+    const bool ok = i2 <= kSeqI2Max * ip2 && m2 * i2 <= kSeqMI2Max * mp2 * ip2 && j2 <= kSeqI2Max * ip2 &&
+                    n2 * j2 <= kSeqMI2Max * mp2 * ip2 && r <= kSeqRMax;      // (NaN: not ok)
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ys[2 * k] = zp[k].x; ys[2 * k + 1] = zp[k].y; }
+        msc = (1.f + r) * (1.f + r);
+    }
+    return ok;
+}
+// ys: the 23 rows lin_to_rows wrote from z+ (phases b, c = rotations); adds the negative- and zero-sequence components
+// the env step leaves of the ones the env STARTED with (rows 0..17 of fstate, still the state before the step)
+__device__ __forceinline__ void lin_seq_merge(const LinK &Lk, const float *__restrict__ fstate, size_t N, int e, float *ys) {
+    using namespace pvder;
+    v2 zp, zn[3], z0[3], en[3], e0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *p = fstate + (size_t)(2 * k) * N + e;
+        seq_of(mk2(p[0], p[N]), mk2(p[6 * N], p[7 * N]), mk2(p[12 * N], p[13 * N]), zp, zn[k], z0[k]);
+    }
+    seq_advance(Lk.seqE, zn, en);
+    seq_advance(Lk.seqE, z0, e0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const v2 da = en[k] + e0[k], db = seq_rot(en[k], 1.f) + e0[k], dc = seq_rot(en[k], -1.f) + e0[k];
+        ys[2 * k] += da.x; ys[2 * k + 1] += da.y;
+        ys[6 + 2 * k] += db.x; ys[7 + 2 * k] += db.y;
+        ys[12 + 2 * k] += dc.x; ys[13 + 2 * k] += dc.y;
+    }
+}
+
 // 23-state rows <-> the accumulator layout of the 11-state reduction (rows 0-3, 4-7, 8-11)
 template <int PH>
 __device__ __forceinline__ void lin_from_rows(const float *ys, pvder::v4f (&Y)[3]) {
@@ -1407,7 +1487,7 @@ __device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys)
 template <int PH>
 __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
                                            const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
-                                           pvder::v4f (&Yn)[3], bool traced, bool &near_ilim) {
+                                           float msc, pvder::v4f (&Yn)[3], bool traced, bool &near_ilim) {
     using namespace pvder;
     const ModelK<float> &P = G.A.P;
     const EtdK &Ec = G.A.Ec;
@@ -1443,7 +1523,8 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
                             fabsf(Yn[1].z - acc2[0][1].z));
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     // |m| at the start, the middle (stage a), the end (stage b and y+) of the step
-    const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+    // (msc: 1, or the (1 + r)^2 of an env carried by its positive-sequence component, lin_seq_split)
+    const float mmax = msc * fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
     // the current reference or the duty cycle comes near its limit: the careful pass redoes the env step
     near_ilim = ir2a > irg || mmax > Ec.sat2_smooth;
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
@@ -1484,7 +1565,7 @@ __device__ __forceinline__ unsigned long long lin_sched_next(const LinArgs &G, u
 template <int PH, bool SPLIT = true>
 __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
                                               int &cur, pvder::v4f (&Y)[3], float qref, float vdcref, int ec, LinSeg sg,
-                                              bool run, bool defer, bool &careful, int trace_step) {
+                                              bool run, bool defer, bool &careful, int trace_step, float msc = 1.f) {
     using namespace pvder;
     constexpr int kBig = 0x3fffffff;
     const ModelK<float> &P = G.A.P;
@@ -1521,7 +1602,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const float pk2 = lin_tick_peak2(P, Y, acc, m2a);
+            const float pk2 = msc * lin_tick_peak2(P, Y, acc, m2a);
             bool trip = pk2 > G.Lk.sat2_hard;
             if (run) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
@@ -1538,7 +1619,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
                 if (trace_step == 0 && st == 1) PVDER_TRACE_AT(4);
                 v4f Yn[3];
                 bool near;
-                trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, Yn, trace_step == 0 && st == 1, near);
+                trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, trace_step == 0 && st == 1, near);
                 if (run) {
                     if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                     Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -1564,7 +1645,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const float pk2 = lin_tick_peak2(P, Y, acc, m2a);
+            const float pk2 = msc * lin_tick_peak2(P, Y, acc, m2a);
             const bool trip = pk2 > G.Lk.sat2_hard;
             if (start && !done) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
@@ -1583,7 +1664,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
         if (__builtin_amdgcn_readfirstlane(__any((int)(todo && sidx != cur))) == 0) {
             v4f Yn[3];
             bool near;
-            const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, Yn, trace_step == 0 && it == 1, near);
+            const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, trace_step == 0 && it == 1, near);
             if (todo) {
                 if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                 Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -1600,7 +1681,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
                 }
                 v4f Yn[3];
                 bool near;
-                const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, Yn, false, near);
+                const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, false, near);
                 if (todo && sidx == s_now) {
                     if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                     Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -1653,7 +1734,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
 template <int PH>
 __device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
                                               const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float alpha,
-                                              pvder::v4f (&Yn)[3], float &ir2_mid, float &ir2_end) {
+                                              float msc, pvder::v4f (&Yn)[3], float &ir2_mid, float &ir2_end) {
     using namespace pvder;
     const ModelK<float> &P = G.A.P;
     const EtdK &Ec = G.A.Ec;
@@ -1682,7 +1763,7 @@ __device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::Lin
     const float est = fmaxf(fmaxf(fabsf(Yn[0].x - acc2[0][0].x), fabsf(Yn[0].y - acc2[0][0].y)),
                             fabsf(Yn[1].z - acc2[0][1].z));
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
-    const float mmax = fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+    const float mmax = msc * fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -1708,7 +1789,7 @@ __device__ __forceinline__ float lin_cross_frac(float s0, float sm, float s1) {
 template <int PH>
 __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
                                                 const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, bool act,
-                                                pvder::v4f (&Yn)[3]) {
+                                                float msc, pvder::v4f (&Yn)[3]) {
     using namespace pvder;
     const float lim = G.A.P.ilim2;
     const PkConst K = make_pkconst(G.A.P);
@@ -1716,7 +1797,7 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
     const bool from_free = s0 <= 0.f;
     const float a1 = from_free ? 1.f : 0.f;
     float irm, ire;
-    bool trip = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a1, Yn, irm, ire);
+    bool trip = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a1, msc, Yn, irm, ire);
     const float s1 = ire - lim;
     const bool need2 = act && (from_free ? s1 > 0.f : s1 < 0.f);
     PVDER_DBG_COUNT(6, act);
@@ -1726,7 +1807,7 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
         const float tau = lin_cross_frac(s0, irm - lim, s1);
         const float a2 = need2 ? (from_free ? tau : 1.f - tau) : a1;
         v4f Y2[3];
-        const bool trip2 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a2, Y2, irm, ire);
+        const bool trip2 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a2, msc, Y2, irm, ire);
         const float s2 = ire - lim;
         if (need2) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip2; }
         const bool need3 = need2 && (from_free ? s2 < 0.f : s2 > 0.f);
@@ -1735,7 +1816,7 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
             // it does not stay on the far side: sliding along the limit -- the step ends on s = 0 (secant between
             // the two evaluations that bracket it)
             const float a3 = need3 ? (from_free ? a2 - s2 * (1.f - a2) / (s1 - s2) : a2 * s1 / (s1 - s2)) : a2;
-            const bool trip3 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a3, Y2, irm, ire);
+            const bool trip3 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a3, msc, Y2, irm, ire);
             if (need3) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip3; }
         }
     }
@@ -1748,7 +1829,7 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
 template <int PH>
 __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane, const pvder::LinMatRegs &At,
                                                       pvder::LinSetRegs &Ac, int &cur, pvder::v4f (&Y)[3], float qref,
-                                                      float vdcref, int ec, LinSeg sg, bool run, bool defer) {
+                                                      float vdcref, int ec, LinSeg sg, bool run, bool defer, float msc) {
     using namespace pvder;
     constexpr int kBig = 0x3fffffff;
     const ModelK<float> &P = G.A.P;
@@ -1776,7 +1857,7 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
             bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a, -1.f);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
-            const bool trip = lin_tick_peak2(P, Y, acc, m2a) > G.Lk.sat2_hard;
+            const bool trip = msc * lin_tick_peak2(P, Y, acc, m2a) > G.Lk.sat2_hard;
             PVDER_DBG_COUNT(4, start && !done && !defer && trip);
             if (start && !done) {
                 defer |= trip;
@@ -1796,7 +1877,7 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
             }
             v4f Yn[3];
             const bool mine = todo && sidx == s_now;
-            const bool trip = lin_hybrid_step<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, mine, Yn);
+            const bool trip = lin_hybrid_step<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, mine, msc, Yn);
             PVDER_DBG_COUNT(5, mine && trip);
             if (mine) {
                 defer |= trip;
@@ -1842,6 +1923,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     const EtdArgs &A = G.A;
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
+    typedef __attribute__((address_space(4))) const char *KernargBytes;
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
@@ -1856,7 +1938,18 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
     PVDER_TRACE_AT(1);
     bool defer = PH == 3 && A.force_full != 0;
-    if constexpr (PH == 3) defer |= L.run && lin_unbalanced(ys);
+    bool seq = false;                   // off balance, carried by its positive-sequence component (lin_seq_split)
+    float msc = 1.f;
+    if constexpr (PH == 3) {
+        const bool unb = L.run && !defer && lin_unbalanced(ys);
+        if (__builtin_amdgcn_readfirstlane(__any((int)unb))) {
+            // (rare: the propagator is read from the kernel-argument segment right here, not kept in SGPRs for the launch)
+            KernargPtr kq = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
+            asm volatile("" : "+s"(kq));
+            if (unb) seq = lin_seq_split(A.P, ((const LinArgs *)kq)->Lk, ys, msc);
+            defer |= unb && !seq;
+        }
+    }
     {
         // every lane enters (a lane that does not run is `done` from the start): the coefficient registers are
         // packed ACROSS the lanes of the wave -- a set reloaded inside the loop must be loaded by all 64
@@ -1865,7 +1958,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         PVDER_TRACE_AT(2);
         bool careful;
         const bool defer0 = defer;          // (off balance / forced: the 23-state path whatever the standard pass finds)
-        defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, careful, 0);
+        defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, careful, 0, msc);
         PVDER_DBG_COUNT(0, L.run);
         PVDER_DBG_COUNT(1, L.run && defer && !careful);
         PVDER_DBG_COUNT(9, L.run && defer && careful);
@@ -1880,7 +1973,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             v4f Yc[3];
             lin_from_rows<PH>(ys, Yc);
             if (careful) { Y[0] = Yc[0]; Y[1] = Yc[1]; Y[2] = Yc[2]; }
-            const bool dc = lin_integrate_careful<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, careful, false);
+            const bool dc = lin_integrate_careful<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, careful, false, msc);
             defer |= careful && dc;
             PVDER_DBG_COUNT(3, careful && dc);
         }
@@ -1889,9 +1982,17 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             L.ksub += A.C.n_sub;
             L.steps += 1;
         }
+        if constexpr (PH == 3) {
+            seq = seq && L.run && !defer;
+            PVDER_DBG_COUNT(12, seq);
+            if (__builtin_amdgcn_readfirstlane(__any((int)seq))) {
+                KernargPtr kq = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
+                asm volatile("" : "+s"(kq));
+                if (seq) lin_seq_merge(((const LinArgs *)kq)->Lk, fstate, N, L.e, ys);
+            }
+        }
     }
     PVDER_TRACE_AT(20);
-    typedef __attribute__((address_space(4))) const char *KernargBytes;
     KernargPtr ka = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
     PVDER_LAUNDER_EPI(ka);
     const EtdArgs &E = *(const EtdArgs *)ka;
@@ -3055,6 +3156,7 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         // the careful pass takes over where |iref| comes within 10 % of the current limit
         K.ir2_careful = (float)(0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]);
         K.sat2_hard = (float)(0.9995 * 0.9995 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
+        for (int k = 0; k < 18; ++k) K.seqE[k] = lin->seq_prop[k];
     }
     return 0;
 }

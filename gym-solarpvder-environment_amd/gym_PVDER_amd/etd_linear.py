@@ -519,6 +519,70 @@ def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Envs slightly OFF BALANCE on the matrix-core path: symmetrical components
+# ---------------------------------------------------------------------------------------------------
+# With z_p = (i_p, x_p, u_p) the per-phase states of the three-phase model (csrc/pvder_model.hpp::rhs) and
+# a = e^{+j 120 deg}:   z+ = (z_a + a z_b + a^2 z_c)/3,   z- = (z_a + a^2 z_b + a z_c)/3,   z0 = (z_a + z_b + z_c)/3.
+# Away from the duty-cycle limit the phase equations are COMPLEX-LINEAR in z_p given the shared states (Vdc, the PLL
+# frequency) with a forcing (grid voltage, current reference) that is purely positive-sequence, so
+#   * z+ together with the shared states obeys the balanced 11-state model -- up to terms QUADRATIC in z-, z0 in the
+#     power sums (sum_p Re(m_p conj i_p) = 3 [Re(m+ conj i+) + Re(m- conj i-) + Re(m0 conj i0)]) and a 2 w t ripple
+#     K_vi i- in the PLL input;
+#   * z- and z0 obey  dz/dt = A(Vdc, w) z  with no forcing at all: over an env step of length T,  z(T) = exp(A0 T) z(0)
+#     with A0 at the nominal Vdc and w = wbase (the mode that lives longer than microseconds is the integrator of the
+#     current controller, x' = -(Ki_GCC / Kp_GCC) x: a third of a second^-1 whatever Vdc is).
+# The device carries an env whose z-, z0 are small (SEQ_* bounds: the neglected terms stay below 1e-5 relative) on the
+# matrix-core path this way instead of handing it to the 23-state path for the ~50 env steps the slow mode needs to die
+# (csrc lin_seq_split / lin_seq_merge).
+SEQ_I2_MAX = 1e-5         # (|i-|^2 + |i0|^2) / |i+|^2
+SEQ_MI2_MAX = 1e-10       # (|m-|^2 + |m0|^2)(|i-|^2 + |i0|^2) / (|m+|^2 |i+|^2)
+SEQ_R_MAX = 0.05          # guard margin r = 1.6 sqrt(2 (|m-|^2 + |m0|^2)) / |m+| beyond which the env takes the 23-state path
+_ROT = complex(-0.5, math.sqrt(3.0) / 2)
+
+
+def seq_operator(par: np.ndarray, der_id: str) -> np.ndarray:
+    """A0: complex 3x3 operator of a negative- / zero-sequence component (i, x, u) at the nominal operating point."""
+    c = folded(par)
+    hV = 0.5 * operating_point(par, der_id)[6]
+    Z = c["iLf"] * (complex(c["kviR"], c["kviI"]) + c["Rf"]) + 1j
+    return np.array([[-Z, c["iLf"] * hV, c["iLf"] * hV * c["KpG"]],
+                     [0.0, 0.0, c["KiG"]],
+                     [-c["wp"], 0.0, -c["wp"]]], dtype=np.complex128)
+
+
+def seq_propagator(par: np.ndarray, der_id: str, n_sub: int) -> np.ndarray:
+    """E = exp(A0 n_sub / 60), complex 3x3 (eigen-decomposition: three well-separated eigenvalues)."""
+    lam, V = np.linalg.eig(seq_operator(par, der_id))
+    return (V * np.exp(lam * (n_sub / 60.0))) @ np.linalg.inv(V)
+
+
+def seq_split(y23: np.ndarray):
+    """(z+, z-, z0), each complex [3] = (i, x, u), of a 23-state vector."""
+    z = [np.array([complex(y23[6 * p + 2 * k], y23[6 * p + 2 * k + 1]) for k in range(3)]) for p in range(3)]
+    a, a2 = _ROT, _ROT.conjugate()
+    return (z[0] + a * z[1] + a2 * z[2]) / 3, (z[0] + a2 * z[1] + a * z[2]) / 3, (z[0] + z[1] + z[2]) / 3
+
+
+def seq_merge(zp, zn, z0) -> np.ndarray:
+    """the 18 phase rows (a, b, c) x (iR, iI, xR, xI, uR, uI) of the three components"""
+    a, a2 = _ROT, _ROT.conjugate()
+    ph = [zp + zn + z0, a2 * zp + a * zn + z0, a * zp + a2 * zn + z0]
+    return np.array([[v.real, v.imag] for z in ph for v in z]).reshape(-1)
+
+
+def seq_accept(c, zp, zn, z0):
+    """(accepted, guard scale (1 + r)^2) of an off-balance state -- the test the device applies at the start AND to the
+    propagated components at the end of the env step"""
+    m = lambda z: c["KpG"] * z[2] + z[1]
+    i2 = abs(zn[0]) ** 2 + abs(z0[0]) ** 2
+    m2 = abs(m(zn)) ** 2 + abs(m(z0)) ** 2
+    ip2, mp2 = abs(zp[0]) ** 2, abs(m(zp)) ** 2
+    r = 1.6 * math.sqrt(2.0 * m2 / mp2) if mp2 > 0 else 1.0
+    ok = i2 <= SEQ_I2_MAX * ip2 and m2 * i2 <= SEQ_MI2_MAX * mp2 * ip2 and r <= SEQ_R_MAX
+    return ok, (1.0 + r) ** 2
+
+
+# ---------------------------------------------------------------------------------------------------
 # etdlin64: the fp64 tolerance-match form (BASELINE configs[4]) -- step doubling on a dyadic menu
 # ---------------------------------------------------------------------------------------------------
 LIN64_LEVELS = 9          # level j: tick + 2^(j+1) equal ETD3RK steps per env step (2, 4, ..., 512)

@@ -476,6 +476,11 @@ class PVDERVec(EnvSpecMixin):
         for k, t in enumerate(lens):
             lc.len_ticks[k] = int(math.ceil(t))      # (informational: the careful pass's set may end on a fraction of a tick)
         lc.est_guard = self.est_guard
+        if self.phases == 3:
+            E = etd_linear.seq_propagator(self.par, self.der_id, cfg.n_sub)
+            for r in range(3):
+                for k in range(3):
+                    lc.seq_prop[6 * r + 2 * k], lc.seq_prop[6 * r + 2 * k + 1] = float(E[r, k].real), float(E[r, k].imag)
         return lc
 
     est_guard = etd_linear.EST_GUARD

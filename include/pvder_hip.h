@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 10
+#define PVDER_ABI_VERSION 11
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -261,6 +261,10 @@ typedef struct pvder_lin_coef {
     const uint8_t *sched;    /* device, 8 * n_sched_rows bytes */
     float est_guard;
     int32_t n_sched_rows;    /* >= 2 * cfg->n_sub (regular rows, careful rows, continuation rows) */
+    float seq_prop[18];      /* exp(A0 n_sub / 60): complex 3x3, row-major (re, im) -- what an env step leaves of a negative- /
+                              * zero-sequence component (i, x, u) of an env slightly off balance, which the kernel carries on
+                              * the matrix-core path by its positive-sequence component (etd_linear.py::seq_propagator);
+                              * all zero: such components are dropped at the end of the step -- do not */
 } pvder_lin_coef;
 int pvder_lin_set_floats(void);
 int pvder_lin_max_sets(void);

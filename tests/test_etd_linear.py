@@ -268,3 +268,73 @@ def test_etdlin64_step_doubling_reference_vs_golden(lin50):
     M43 = el.etd3rk_f_matrices(L, (n / 60.0 - 2 / 1920.0) / 4)[5]           # level 1, last matrix: stored column by column
     got43 = blk[2 * el.LIN64_SET + 5 * 132: 2 * el.LIN64_SET + 6 * 132].reshape(11, 12)[:, :11]
     assert np.array_equal(got43, M43.T)
+
+
+def test_symmetrical_components_of_an_off_balance_env_vs_the_oracle_rhs(lin50):
+    """The claims behind lin_seq_split / lin_seq_merge (an env slightly off balance stays on the matrix-core path),
+    against the oracle's 23-state right-hand side away from the limits:
+    (1) split / merge are inverse; (2) with a negative- and a zero-sequence component of relative size eps on top of a
+    balanced state, the POSITIVE-sequence part of dy/dt and the shared derivatives are those of the balanced state up
+    to O(eps^2) -- the PLL rows see K_vi i- at first order (the 2wt ripple the device neglects: its size is asserted);
+    (3) the negative- / zero-sequence parts of dy/dt are A0 z (complex-linear, operator of seq_operator) up to the
+    variation of Vdc and w; (4) the propagator is a semigroup whose only surviving mode is x' = -(Ki/Kp) x."""
+    par, c, L, ystar = lin50
+    m = pm.build_model("50")
+    rng = np.random.default_rng(5)
+    A0 = el.seq_operator(par, "50")
+    y11 = ystar.copy()
+    y23 = expand(y11)
+    zp, zn, z0 = el.seq_split(y23)
+    assert np.abs(zn).max() < 1e-12 and np.abs(z0).max() < 1e-12 and np.allclose(zp, [complex(y11[0], y11[1]), complex(y11[2], y11[3]), complex(y11[4], y11[5])])
+    args = (1.0, par[der_model.IDX["SINSOL0"]], 0.0, par[der_model.IDX["VDC_REF0"]])
+    f0 = np.array(pm.rhs(m, y23, 0.0, *args))
+    scale = np.array([abs(zp[0]), abs(zp[1]), 1e-6])                  # sizes of i, x, u (u ~ 0 at the operating point)
+    for eps in (1e-3, 1e-4):
+        dn = eps * scale * (rng.standard_normal(3) + 1j * rng.standard_normal(3))
+        d0 = eps * scale * (rng.standard_normal(3) + 1j * rng.standard_normal(3))
+        y = y23.copy()
+        y[:18] = el.seq_merge(zp, dn, d0)
+        assert np.allclose(np.concatenate(el.seq_split(y)), np.concatenate([zp, dn, d0]), atol=1e-15)       # (1)
+        f = np.array(pm.rhs(m, y, 0.0, *args))
+        fp, fn, fz = el.seq_split(f)
+        fp0, _, _ = el.seq_split(f0)
+        # (2) positive sequence + shared states: second order in eps, except the PLL's first-order ripple term
+        big = np.abs(A0).max(axis=1) * scale.max()                  # scale of a derivative row
+        assert np.all(np.abs(fp - fp0) < 30 * eps ** 2 * big + 1e-9), (eps, np.abs(fp - fp0))
+        dsh = np.abs(f[18:] - f0[18:])
+        assert dsh[0] < 5 * eps ** 2 * 60 and dsh[1] < 1e-9 and dsh[2] < 50 * eps ** 2      # Vdc, xDC, xQ
+        ripple = abs(complex(c["kviR"], c["kviI"])) * abs(dn[0])
+        assert dsh[3] <= c["KiP"] * ripple * 1.01 + 1e-12 and dsh[4] <= c["KpP"] * ripple * 1.01 + c["KiP"] * 0 + 1e-12
+        # (3) the two components obey dz/dt = A0 z
+        assert np.allclose(fn, A0 @ dn, rtol=1e-6, atol=1e-9 * big.max()) and np.allclose(fz, A0 @ d0, rtol=1e-6, atol=1e-9 * big.max())
+        ok, msc = el.seq_accept(c, zp, dn, d0)
+        assert ok == (eps <= 1e-3 and abs(dn[0]) ** 2 + abs(d0[0]) ** 2 <= el.SEQ_I2_MAX * abs(zp[0]) ** 2) and msc >= 1.0
+    E1, E2 = el.seq_propagator(par, "50", 15), el.seq_propagator(par, "50", 30)
+    assert np.abs(E1 @ E1 - E2).max() < 1e-12                                                                # (4)
+    lam = np.sort(np.abs(np.linalg.eigvals(E1)))
+    assert lam[1] < 1e-20 and abs(lam[2] - np.exp(-0.25 * c["KiG"] / c["KpG"])) < 1e-6
+
+
+def test_sequence_propagator_vs_the_bridge_without_actions(lin50):
+    """exp(A0 T) against the converged 23-state bridge over env steps with events (voltage +2 %, insolation -20 %) but no
+    actions: the negative- / zero-sequence components of an off-balance env after each of four env steps, to 1e-6 of
+    their size (measured 2e-8) although Vdc swings by 5 % -- the slow mode does not depend on the shared states."""
+    from oracle.bridge_env import BridgeVecEnv
+    par = lin50[0]
+    N = 3
+    ref = BridgeVecEnv(N, n=15, method="rk45", rtol=1e-9, atol=1e-12)
+    vg = np.ones((3, N)); si = np.full((3, N), 100.0)
+    vg[1:, 1] = 1.02; si[1:, 2] = 80.0
+    ref.reset(vg, si, ev_s0=15, ev_ds=60)
+    ref.Y[:, 8:10] *= 1.003
+    E = el.seq_propagator(par, "50", 15)
+    prev = [el.seq_split(ref.Y[e]) for e in range(N)]
+    for t in range(4):
+        ref.step(np.zeros(N, dtype=np.int64))
+        now = [el.seq_split(ref.Y[e]) for e in range(N)]
+        for e in range(N):
+            for k in (1, 2):                      # z-, z0
+                want, got = now[e][k], E @ prev[e][k]
+                assert abs(want[1]) > 1e-4 and abs(got[1] - want[1]) < 1e-6 * abs(want[1]), (t, e, k)
+                assert abs(got[0] - want[0]) < 1e-6 * abs(want[1]) and abs(got[2] - want[2]) < 1e-6 * abs(want[1])
+        prev = now

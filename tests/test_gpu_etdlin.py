@@ -138,7 +138,7 @@ def test_etdlin_defers_envs_near_limits_and_off_balance(gpu_device):
                        auto_reset=True, max_sim_time=1.0)
         env._debug_knob = knob
         env.reset()
-        env.fstate[6, 1::2] *= 1.001              # unbalanced current
+        env.fstate[6, 1::2] *= 1.02               # unbalanced current (2 %: beyond what the fast path carries by itself)
         env.fstate[18, 3::4] = 0.985              # low DC-link voltage -> duty cycle at its limit
         env.fstate[24, 3::4] = 0.985
         gen = torch.Generator(device=gpu_device); gen.manual_seed(3)
@@ -163,6 +163,72 @@ def test_etdlin_defers_envs_near_limits_and_off_balance(gpu_device):
     f = lambda r, m: r[:, :11, m].cpu().numpy().astype(np.float64).reshape(-1)
     assert 0 < rel_l2(f(runs[0], ~odd), f(runs[1], ~odd)) < 2e-5          # fast path: another integrator, same answer
     assert rel_l2(f(runs[0], odd & ~sat), f(runs[1], odd & ~sat)) < 2e-5
+
+
+def test_slightly_off_balance_envs_stay_on_the_matrix_core_path(gpu_device):
+    """What an anti-windup episode leaves behind -- a 1e-3 imbalance in the integrators of the current controller that
+    takes ~50 env steps to die (x' = -(Ki/Kp) x) -- does not keep an env on the 23-state path: the step kernel
+    carries it by its positive-sequence component and propagates the negative- / zero-sequence components by
+    exp(A0 T) (csrc lin_seq_split / lin_seq_merge).  Against the converged bridge started from the SAME fp32 state:
+    observations and the full 23-state vector; the perturbed envs must not have run the 23-state code (their results
+    differ from a run that forces it), a 5 % imbalance must (bit-identical to forcing it)."""
+    N, n_sub, steps = 256, 15, 8
+    spec = both_events_spec()
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(8)
+    acts = torch.randint(0, 5, (steps, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    small = torch.zeros(N, dtype=torch.bool, device=gpu_device); small[1::4] = True
+    mixed = torch.zeros(N, dtype=torch.bool, device=gpu_device); mixed[2::4] = True
+    large = torch.zeros(N, dtype=torch.bool, device=gpu_device); large[3::4] = True
+    runs, states = {}, {}
+    for knob in (0, 1):
+        env = make_vec(N, gpu_device, n_sim_time_steps_per_env_step=n_sub, seed=23, events_spec=spec, auto_reset=False)
+        env._debug_knob = knob
+        env.reset()
+        env.fstate[8:10, small] *= 1.003             # x_b: the slow mode
+        env.fstate[14, mixed] *= 0.998               # x_c, and a little current: fast modes too
+        env.fstate[6, mixed] *= 1.0008
+        env.fstate[6:12, large] *= 1.05              # phase b 5 % off: the 23-state path
+        if knob == 0:
+            ref = BridgeVecEnv(N, n=n_sub, method="rk45", rtol=1e-8, atol=1e-11)
+            ref.reset(env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64),
+                      ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+            ref.Y[:, :18] = env.fstate[:18].t().cpu().numpy().astype(np.float64)
+            want, wstate = [], []
+            a_np = acts.cpu().numpy().astype(np.int64)
+            for t in range(steps):
+                want.append(ref.step(a_np[t])[0][:, :10].copy()); wstate.append(ref.Y[:, :21].copy())
+            want, wstate = np.stack(want), np.stack(wstate)
+        outs, sts = [], []
+        for t in range(steps):
+            env.step(acts[t], return_tensors=False)
+            outs.append(env.out.clone()); sts.append(env.fstate[:21].t().clone())      # (i, x, u) x 3, Vdc, xDC, xQ
+        runs[knob], states[knob] = torch.stack(outs), torch.stack(sts)
+    got = runs[0][:, :10].permute(0, 2, 1).cpu().numpy().astype(np.float64)
+    gst = states[0].cpu().numpy().astype(np.float64)
+    for name, mask in (("balanced", ~(small | mixed | large)), ("slow mode", small), ("mixed", mixed), ("5 %", large)):
+        k = mask.cpu().numpy()
+        per_step = max(rel_l2(got[t][k], want[t][k]) for t in range(steps))
+        st_err = max(rel_l2(gst[t][k], wstate[t][k]) for t in range(steps))
+        bound = 3e-4 if name == "5 %" else 1e-5            # (5 %: the 23-state path's own accuracy behind such a kick, 1.4e-4)
+        assert per_step < bound and st_err < bound, (name, per_step, st_err)
+    # the imbalance itself (x_b - x_a rotated) follows the bridge to 1 % of its own size.  (Not closer: in the model every
+    # Q_ref / Vdc_ref action rings the duty cycle across its limit for microseconds -- K_p,GCC = 6000 on the jump of the
+    # current reference -- and the component-wise anti-windup leaves 4e-7 of imbalance per action step, 2e-8 per Vdc_ref
+    # step, in BALANCED envs too; the converged bridge has it, the fast path does not: 1e-6 of the state, far below the
+    # parity bar.  Without actions the propagator is exact to 1e-8: tests/test_etd_linear.py.)
+    rot = np.exp(-2j * np.pi / 3)
+    k = small.cpu().numpy()
+    for t in (0, steps - 1):
+        d_got = (gst[t][k, 8] + 1j * gst[t][k, 9]) - rot * (gst[t][k, 2] + 1j * gst[t][k, 3])
+        d_want = (wstate[t][k, 8] + 1j * wstate[t][k, 9]) - rot * (wstate[t][k, 2] + 1j * wstate[t][k, 3])
+        assert np.abs(d_want).min() > 1e-4 and np.abs(d_got - d_want).max() < 1e-2 * np.abs(d_want).max(), t
+    # which code ran in the first step: the 5 % envs took the 23-state path in both runs (same bits; one step later what is
+    # left of their imbalance is small enough for the fast path), the others did not
+    assert torch.equal(runs[0][0][:, large], runs[1][0][:, large])
+    for mask in (small, mixed):
+        differs = (runs[0][0][:11, mask] != runs[1][0][:11, mask]).any(dim=0)
+        assert bool(differs.all())
+    assert rel_l2(runs[0][:, :11].cpu().numpy().astype(np.float64).reshape(-1), runs[1][:, :11].cpu().numpy().astype(np.float64).reshape(-1)) < 2e-5
 
 
 def test_etdlin_far_from_the_operating_point_and_hand_over_guard(gpu_device):
