@@ -389,7 +389,9 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
         const float d = (float)__popcll(__ballot((int)(done_f != 0.f)));
         const float nf = (float)__popcll(__ballot((int)(nonfinite != 0.f)));
         const float ba = (float)__popcll(__ballot((int)(L.live && L.bad_action != 0.f)));
-        if ((threadIdx.x & 63) == 63) {
+        // (lane id from mbcnt, not threadIdx.x & 63: a value the compiler would otherwise keep -- or spill -- from the first
+        // instruction of the kernel, where the coefficient loads use it, to this last one)
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 63u) {
             v4 *slot = (v4 *)stats + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
             v4 t = {r, d, nf, ba};
             if (!stats_fresh) t += *slot;
@@ -732,7 +734,7 @@ __device__ __forceinline__ void matvec16(const Mat16 &M, v2 ni, v2 nu, v2 &oi, v
     ou = fma2(mk2(M.d.x, M.d.y), bc2(nu.x), ou); ou = fma2(mk2(M.d.z, M.d.w), bc2(nu.y), ou);
 }
 // the model's sign tests on dx_p/dt at a stage state yt (ns[0..2] = dx_p), and the frozen rows of N_u
-__device__ __forceinline__ void sw_mask(const ModelK<float> &P, const v2 *__restrict__ yt, const int (&mode)[3],
+__device__ __forceinline__ void sw_mask(const ModelK<float> &P, const v2 *__restrict__ yt, int modes /* 2 bits per phase */,
                                         v2 *__restrict__ nf, v2 *__restrict__ ns) {
     using namespace pvder;
 #pragma unroll
@@ -742,13 +744,13 @@ __device__ __forceinline__ void sw_mask(const ModelK<float> &P, const v2 *__rest
             ns[p].x = ns[p].x * x.x > 0.f ? 0.f : ns[p].x;
             ns[p].y = ns[p].y * x.y > 0.f ? 0.f : ns[p].y;
         }
-        if (mode[p] & 1) nf[2 * p + 1].x = 0.f;
-        if (mode[p] & 2) nf[2 * p + 1].y = 0.f;
+        if (modes & (1 << (2 * p))) nf[2 * p + 1].x = 0.f;
+        if (modes & (2 << (2 * p))) nf[2 * p + 1].y = 0.f;
     }
 }
-__device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
-                                                  const pvder::SubPk &S, v2 *__restrict__ y, v2 *__restrict__ comp,
-                                                  const lds_v4 *Mset, float h, float t0, float tq, float qref, float vdcref) {
+__device__ __forceinline__ float etd_switched_step(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
+                                                   const pvder::SubPk &S, v2 *__restrict__ y, v2 *__restrict__ comp,
+                                                   const lds_v4 *Mset, float h, float t0, float tq, float qref, float vdcref) {
     using namespace pvder;
     constexpr int SL[6] = {1, 4, 7, 9, 10, 11};
     const v2 h2 = bc2(0.5f * h), h4 = bc2(0.25f * h), h8 = bc2(0.125f * h), h6 = bc2(h * (float)(1.0 / 6.0)),
@@ -756,15 +758,15 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
     const float t1 = t0 + 0.5f * tq, t2 = t0 + tq;
     v2 n1f[6], nf[6], ns1[6], nsl[6], s23[6], k14[6], yt[NP], n23[6];
     v2 u3[6], u4[6], u5[6], zn[6];
-    etd_eval(P, K, Ec, S, y, t0, qref, vdcref, n1f, ns1);                                  // N1
-    int mode[3];
-    const lds_v4 *Mp[3];
+    const float m2a = etd_eval(P, K, Ec, S, y, t0, qref, vdcref, n1f, ns1);                // N1
+    int mode = 0;        // 2 bits per phase
+    // (the operator set of a pair is addressed from its mode wherever it is read: three pointers less to keep)
+#define PVDER_MP(p) (Mset + ((mode >> (2 * (p))) & 3) * (kMatCount * 4))
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const v2 u = y[3 * p + 2], m = fma2(bc2(P.KpG), u, y[3 * p + 1]);
         const v2 du = fma2(bc2(-P.wp), y[3 * p] + u, n1f[2 * p + 1]);                      // wp (iref_p - i_p - u_p)
-        mode[p] = __builtin_fmaf(m.y, m.y, m.x * m.x) > P.mlim2 ? ((du.x * u.x > 0.f ? 1 : 0) | (du.y * u.y > 0.f ? 2 : 0)) : 0;
-        Mp[p] = Mset + mode[p] * (kMatCount * 4);
+        mode |= (__builtin_fmaf(m.y, m.y, m.x * m.x) > P.mlim2 ? ((du.x * u.x > 0.f ? 1 : 0) | (du.y * u.y > 0.f ? 2 : 0)) : 0) << (2 * p);
     }
     sw_mask(P, y, mode, n1f, ns1);
 #pragma unroll
@@ -772,19 +774,19 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
         const v2 zi = y[3 * p], zu = y[3 * p + 2];
         const v2 n1i = n1f[2 * p], n1u = n1f[2 * p + 1];
         v2 e2i = bc2(0.f), e2u = bc2(0.f), ei = bc2(0.f), eu = bc2(0.f);
-        matvec16(load_mat16(Mp[p], EM_E2), zi, zu, e2i, e2u);
-        matvec16(load_mat16(Mp[p], EM_E), zi, zu, ei, eu);
+        matvec16(load_mat16(PVDER_MP(p), EM_E2), zi, zu, e2i, e2u);
+        matvec16(load_mat16(PVDER_MP(p), EM_E), zi, zu, ei, eu);
         v2 ai = e2i, au = e2u;
-        matvec16(load_mat16(Mp[p], EM_A21), n1i, n1u, ai, au);                             // U2
+        matvec16(load_mat16(PVDER_MP(p), EM_A21), n1i, n1u, ai, au);                             // U2
         yt[3 * p] = ai; yt[3 * p + 2] = au;
         u3[2 * p] = e2i; u3[2 * p + 1] = e2u;
-        matvec16(load_mat16(Mp[p], EM_A31), n1i, n1u, u3[2 * p], u3[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_A31), n1i, n1u, u3[2 * p], u3[2 * p + 1]);
         u4[2 * p] = ei; u4[2 * p + 1] = eu;
-        matvec16(load_mat16(Mp[p], EM_A41), n1i, n1u, u4[2 * p], u4[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_A41), n1i, n1u, u4[2 * p], u4[2 * p + 1]);
         u5[2 * p] = e2i; u5[2 * p + 1] = e2u;
-        matvec16(load_mat16(Mp[p], EM_A51), n1i, n1u, u5[2 * p], u5[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_A51), n1i, n1u, u5[2 * p], u5[2 * p + 1]);
         zn[2 * p] = ei; zn[2 * p + 1] = eu;
-        matvec16(load_mat16(Mp[p], EM_B1), n1i, n1u, zn[2 * p], zn[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_B1), n1i, n1u, zn[2 * p], zn[2 * p + 1]);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) yt[SL[q]] = fma2(h2, ns1[q], y[SL[q]]);
@@ -793,7 +795,7 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         n23[2 * p] = nf[2 * p]; n23[2 * p + 1] = nf[2 * p + 1];
-        matvec16(load_mat16(Mp[p], EM_A32), nf[2 * p], nf[2 * p + 1], u3[2 * p], u3[2 * p + 1]);       // U3
+        matvec16(load_mat16(PVDER_MP(p), EM_A32), nf[2 * p], nf[2 * p + 1], u3[2 * p], u3[2 * p + 1]);       // U3
         yt[3 * p] = u3[2 * p]; yt[3 * p + 2] = u3[2 * p + 1];
     }
 #pragma unroll
@@ -803,8 +805,8 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         n23[2 * p] += nf[2 * p]; n23[2 * p + 1] += nf[2 * p + 1];
-        matvec16(load_mat16(Mp[p], EM_A42), n23[2 * p], n23[2 * p + 1], u4[2 * p], u4[2 * p + 1]);     // U4
-        matvec16(load_mat16(Mp[p], EM_A52), n23[2 * p], n23[2 * p + 1], u5[2 * p], u5[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_A42), n23[2 * p], n23[2 * p + 1], u4[2 * p], u4[2 * p + 1]);     // U4
+        matvec16(load_mat16(PVDER_MP(p), EM_A52), n23[2 * p], n23[2 * p + 1], u5[2 * p], u5[2 * p + 1]);
         yt[3 * p] = u4[2 * p]; yt[3 * p + 2] = u4[2 * p + 1];
     }
 #pragma unroll
@@ -813,8 +815,8 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
     sw_mask(P, yt, mode, nf, nsl);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        matvec16(load_mat16(Mp[p], EM_A54), nf[2 * p], nf[2 * p + 1], u5[2 * p], u5[2 * p + 1]);       // U5
-        matvec16(load_mat16(Mp[p], EM_B4), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_A54), nf[2 * p], nf[2 * p + 1], u5[2 * p], u5[2 * p + 1]);       // U5
+        matvec16(load_mat16(PVDER_MP(p), EM_B4), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
         yt[3 * p] = u5[2 * p]; yt[3 * p + 2] = u5[2 * p + 1];
     }
 #pragma unroll
@@ -826,7 +828,7 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
     sw_mask(P, yt, mode, nf, nsl);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-        matvec16(load_mat16(Mp[p], EM_B5), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
+        matvec16(load_mat16(PVDER_MP(p), EM_B5), nf[2 * p], nf[2 * p + 1], zn[2 * p], zn[2 * p + 1]);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int g = SL[q];
@@ -837,6 +839,8 @@ __device__ __forceinline__ void etd_switched_step(const ModelK<float> &P, const 
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) { y[3 * p] = zn[2 * p]; y[3 * p + 2] = zn[2 * p + 1]; }
+    return fmaxf(m2a, max_m2(P, y));          // |m|^2 at the start and at the end of the step
+#undef PVDER_MP
 }
 
 // The 23-state ETDRK4 path, the tail of step_etdrk4_bal_kernel<3>: its workgroups run it for the lanes
@@ -869,9 +873,11 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     // model constants (they would be spilled to VGPR lanes and read back with v_readlane in the
     // hot loop): stage the block once in LDS and read it with broadcast ds_read (every lane reads
     // the same address: conflict-free, no VALU issue slot).
+#ifdef PVDER_RK4_FALLBACK
     __shared__ __attribute__((aligned(16))) float Mlds[kCoefFloats];
-    __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // the switched block (steps at the duty-cycle limit)
     for (int k = threadIdx.x; k < kCoefFloats; k += kBlock) Mlds[k] = coef[k];
+#endif
+    __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // the operator sets per anti-windup mode (mode 0: the complex block)
     for (int k = threadIdx.x; k < kSwFloats; k += kBlock) Msw[k] = coef[kCoefFloats + k];
     __syncthreads();
     Lane<float> L;
@@ -912,6 +918,19 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                          h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
                 const float tq = 120.f * h;                   // 2*theta advances 2 turns per 1/60 s
                 const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
+#ifndef PVDER_RK4_FALLBACK
+                // ONE step function for every lane of this path: the (i_p, u_p) pairs on the real 4x4 operator set of the
+                // anti-windup mode each is in at the start of the step -- mode 0 (below the limit: every pair of an env that
+                // is merely off balance) is the complex 2x2 system itself.  (Until round 3 a step was first taken on the
+                // complex block and, if the duty cycle met the guard, taken AGAIN on the switched sets: an env at the limit
+                // -- what this path mostly serves since slightly off-balance envs stay on the matrix-core path -- paid
+                // for every step twice.)
+                const lds_v4 *Ms = (const lds_v4 *)Msw + (kSwModes * kMatCount * 4) * set;
+                asm volatile("" : "+v"(Ms));
+                const float t2 = t0 + tq;
+                const float mm2 = etd_switched_step(P, K, Ec, S, y, comp, Ms, h, t0, tq, L.qref, L.vdcref);
+                if (mm2 > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) L.fail = true;     // the episode ends here (epilogue)
+#else
                 // opaque per-iteration copy of the LDS base: the 160 coefficients are re-read from
                 // LDS every step (40 ds_read_b128) instead of being hoisted into 160 registers
                 const lds_v4 *Mq = (const lds_v4 *)Mlds + 2 * kMatCount * set;
@@ -1012,6 +1031,7 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                         y[g] = tsum;
                     }
                 }
+#endif
                 t0 = t2;
             }
             }
@@ -1086,7 +1106,7 @@ __device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
 }
 
 template <int PH>
-__global__ __launch_bounds__(kBlock) void step_etdrk4_bal_kernel(const EtdArgs A) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdrk4_bal_kernel(const EtdArgs A) {
     const ModelK<float> &P = A.P;
     const StepK<float> &C = A.C;
     const ResetK &R = A.R;
@@ -2038,7 +2058,7 @@ static_assert(alignof(LinArgs) <= 8 && sizeof(LinHead) % alignof(LinArgs) == 0, 
 static_assert(offsetof(LinArgs, A) == 0, "the 23-state tail reads EtdArgs at the start of LinArgs");
 
 template <int PH>
-__global__ __launch_bounds__(kBlock) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
                                                              const float *lcoef, int n_env, int pad, const LinArgs G) {
     using namespace pvder;
     (void)pad;

@@ -22,6 +22,11 @@ def _ramp(action):
 
 CASES = {
     "ramp_a1": _ramp(1), "ramp_a2": _ramp(2), "ramp_a3": _ramp(3), "ramp_a4": _ramp(4),
+    # four envs of the 65 536-env action-1 ramp (seed 3) in which the +2 % voltage event of env step 121 takes the duty
+    # cycle -- |m| = 0.97 by then -- across its limit for a moment: one env step on the 23-state path (switched operator
+    # sets), a 1e-3 imbalance in the current controller's integrators behind it that takes the rest of the episode to die
+    # (carried on the matrix-core path by symmetrical components), the current limit from step ~125
+    "ramp_a1_touch": dict(N=4, seed=3, spec="both", n=15, steps=160, actions=("const", 1), env_ids=(17360, 20888, 45096, 63022)),
     # a complete PVDER-v0 episode, random actions (tests of drift: etdlin and ETDRK4 replay it)
     "episode_random": dict(N=8, seed=1234, spec="both", n=15, steps=160, actions=("random", 2718)),
 }
@@ -31,7 +36,11 @@ def case_inputs(name):
     """(event tables [K+1, N] x 2, actions [steps, N], case dict) of a case, from its definition alone."""
     c = CASES[name]
     spec = both_events_spec() if c["spec"] == "both" else {k: dict(v) for k, v in DEFAULT_EVENTS_SPEC.items()}
-    vg, si = counter_tables(c["N"], c["seed"], episode=1, spec=spec)
+    if "env_ids" in c:              # named envs of a larger batch: the tables the device generator gives THOSE env ids
+        cols = [counter_tables(1, c["seed"], episode=1, env_id_base=i, spec=spec) for i in c["env_ids"]]
+        vg, si = np.concatenate([v for v, _ in cols], axis=1), np.concatenate([s_ for _, s_ in cols], axis=1)
+    else:
+        vg, si = counter_tables(c["N"], c["seed"], episode=1, spec=spec)
     kind, arg = c["actions"]
     if kind == "const":
         acts = np.full((c["steps"], c["N"]), arg, dtype=np.int64)

@@ -23,15 +23,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=65536)
     ap.add_argument("--actions", type=int, nargs="*", default=[1, 2, 3, 4])
+    ap.add_argument("--cases", nargs="*", default=None, help="case names of tests/bridge_cases.py instead of --actions (e.g. ramp_a1_touch)")
     ap.add_argument("--off-range", default="integrate")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    for act in a.actions:
-        g = bridge_cases.load("ramp_a%d" % act)
-        c = bridge_cases.CASES["ramp_a%d" % act]
-        vg, si, acts, cc = bridge_cases.case_inputs("ramp_a%d" % act)
+    for name in (a.cases or ["ramp_a%d" % k for k in a.actions]):
+        g = bridge_cases.load(name)
+        c = bridge_cases.CASES[name]
+        act = c["actions"][1]
+        vg, si, acts, cc = bridge_cases.case_inputs(name)
         env = PVDERVec(c["N"], device=dev, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], off_range=a.off_range)
         env.reset()
+        if "env_ids" in c:           # named envs of a larger batch: their tables, set explicitly
+            env.set_event_tables(torch.from_numpy(vg.astype(np.float32)).to(dev), torch.from_numpy(si.astype(np.float32)).to(dev))
+            env.reset()
         assert np.array_equal(env.ev_vg.cpu().numpy(), vg.astype(np.float32)) and np.array_equal(env.ev_si.cpu().numpy(), si.astype(np.float32))
         at = torch.full((c["N"],), act, dtype=torch.uint8, device=dev)
         got = []
@@ -44,8 +49,11 @@ def main():
         ok = g["m_abs"].max(axis=1) < 0.999
         last = int(np.argmin(ok)) if not ok.all() else c["steps"]
         traj = np.linalg.norm((got - want)[:last]) / np.linalg.norm(want[:last])
-        print("action %d: steps compared %d (|m| < 0.999 in the bridge), trajectory rel-L2 %.2e, worst env step %.2e at step %d"
-              % (act, last, traj, per[:last].max(), int(per[:last].max(axis=1).argmax())))
+        print("%s, action %d: steps compared %d (|m| < 0.999 in the bridge), trajectory rel-L2 %.2e, worst env step %.2e at step %d"
+              % (name, act, last, traj, per[:last].max(), int(per[:last].max(axis=1).argmax())))
+        if "env_ids" in c:
+            print("   env steps 118..128, per env: " + " | ".join(" ".join("%.1e" % v for v in per[t]) for t in range(118, 129)))
+            continue
         print("   worst env step by 20-step block: " + " ".join("%.1e" % per[k:k + 20].max() for k in range(0, c["steps"], 20)))
         print("   |iref| / limit at block ends:    " + " ".join("%.3f" % (g["iref_abs"][min(k + 19, c["steps"] - 1)].max() / 1.7316) for k in range(0, c["steps"], 20)))
         print("   |m_a| at block ends:             " + " ".join("%.3f" % g["m_abs"][min(k + 19, c["steps"] - 1)].max() for k in range(0, c["steps"], 20)))
