@@ -348,6 +348,8 @@ def test_fused_rollout_with_desynchronised_and_deferred_envs(gpu_device):
         mask[256:512:2] = 1                          # every second env of one workgroup restarts: off the event grid
         env.reset(mask)
         env.fstate[6:12, 1024:1030] *= 1.01          # phase b of six envs: unbalanced -> 23-state path
+        env.fstate[8:10, 1100:1104] *= 1.003         # x_b of four envs: slightly off balance -> symmetrical components, for the
+                                                     # whole rollout (per-step body: the fused kernel holds 11 states per env)
         env.fstate[24, 1536:1540] = 1.1 * 0.93       # Vdc_ref -7 %: |m| at its limit -> deferred for good
     a, b = envs
     singles = []
@@ -360,6 +362,9 @@ def test_fused_rollout_with_desynchronised_and_deferred_envs(gpu_device):
     assert _same_env_state(a, b)
     assert bool((a.istate[3] != 0).any())            # some envs finished inside the rollout (max_sim_time) and stayed so
     assert a.step_stats() == b.step_stats()
+    xa, xb = torch.complex(a.fstate[2], a.fstate[3]), torch.complex(a.fstate[8], a.fstate[9])
+    off = (xb - xa * complex(-0.5, -np.sqrt(0.75))).abs()
+    assert float(off[1100:1104].min()) > 5e-4 and float(off[:1024].max()) < 1e-6      # still off balance / never were
 
 
 def test_single_phase_etdlin_vs_bridge(gpu_device):
