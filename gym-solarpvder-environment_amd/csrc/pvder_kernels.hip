@@ -579,8 +579,9 @@ enum { EM_E2 = 0, EM_E, EM_A21, EM_A31, EM_A41, EM_A51, EM_B1, EM_A32, EM_A42, E
 // (iR, iI, uR, uI), once per anti-windup MODE of the pair.  While |m_p| > m_limit the reference model freezes the
 // components of du_p/dt (and dx_p/dt) that point outward (pvder_model.hpp::rhs, the `mlim2` branch): component-wise,
 // so the pair no longer obeys a complex 2x2 system but one of four real LINEAR ones -- mode bit 0: uR frozen (its row
-// of Lz zeroed), bit 1: uI frozen.  An ETDRK4 step that meets the limit is taken with the operator set of the mode
-// found at its start (etd_switched_step) where it used to be redone by 61 440 classic-RK4 steps per env step.
+// of Lz zeroed), bit 1: uI frozen; mode 0 is the complex system itself.  Every ETDRK4 step of the 23-state path is taken with,
+// per pair, the operator set of the mode found at its start (etd_switched_step) -- where a step that met the limit used
+// to be redone by 61 440 classic-RK4 steps per env step (round 2), then by a second, switched step (round 3).
 // Layout: [step size][mode][matrix][16 floats]; a matrix as column pairs (M0k, M1k) k = 0..3, then (M2k, M3k).
 constexpr int kSwModes = 4;
 constexpr int kSwMatFloats = 16;
@@ -710,7 +711,8 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
 }
 
 // ---- one ETDRK4 step of the 23-state model with the (i_p, u_p) pairs on the operator sets of their anti-windup
-// modes (see kSwModes).  Same tableau, same slow-state update as the step in etdrk4_full_tail; what differs:
+// modes (see kSwModes): THE step of etdrk4_full_tail.  Hochbruck-Ostermann's tableau, Kahan-compensated slow states;
+// returns the largest |m_p|^2 at the start and at the end of the step.  On top of the plain scheme:
 //   * per phase, the mode found at the START of the step (|m_p| > m_limit: the components of du_p/dt that point
 //     outward are frozen) selects the real 4x4 operator set of the pair and blanks the frozen rows of N_u;
 //   * dx_p/dt carries the model's sign tests at every stage.
@@ -3176,6 +3178,9 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         // the careful pass takes over where |iref| comes within 10 % of the current limit
         K.ir2_careful = (float)(0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]);
         K.sat2_hard = (float)(0.9995 * 0.9995 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
+        // the propagator of a small imbalance: its (x, x) entry is exp(-T Ki/Kp) -- an all-zero block (a caller written
+        // against ABI 10) would silently drop what an anti-windup episode leaves in the controller's integrators
+        if (p.ph == 3 && !(lin->seq_prop[8] > 0.f && lin->seq_prop[8] <= 1.f)) return PVDER_EINVAL;
         for (int k = 0; k < 18; ++k) K.seqE[k] = lin->seq_prop[k];
     }
     return 0;
