@@ -567,7 +567,7 @@ def test_momentary_duty_cycle_saturation_on_the_q_ref_ramp(gpu_device):
     got, want, unbalanced = np.stack(got), g["obs"], np.stack(unbalanced)
     per = rel_l2(got, want, axis=2)                                  # [steps, N]
     ev = 121
-    assert per[:ev].max() < TIGHT * 1.5, per[:ev].max()
+    assert per[:ev].max() < TIGHT * 2, per[:ev].max()               # (2.6e-5: the careful pass from step ~100)
     assert unbalanced[:ev].max() < 1e-6 and unbalanced[ev].max() > 2e-4          # the event knocks the envs off balance ...
     assert unbalanced[ev + 20].max() > 0.1 * unbalanced[ev].max()                 # ... for seconds
     assert per[ev:ev + 10].max() < 2.5e-3, per[ev:ev + 10].max()
