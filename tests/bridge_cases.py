@@ -20,6 +20,8 @@ def _ramp(action):
     return dict(N=4, seed=11, spec="both", n=15, steps=160, actions=("const", action))
 
 
+_SAMPLE_IDS = tuple(int(i) for i in np.sort(np.random.default_rng(77).choice(65536, size=48, replace=False)))
+
 CASES = {
     "ramp_a1": _ramp(1), "ramp_a2": _ramp(2), "ramp_a3": _ramp(3), "ramp_a4": _ramp(4),
     # four envs of the 65 536-env action-1 ramp (seed 3) in which the +2 % voltage event of env step 121 takes the duty
@@ -27,6 +29,10 @@ CASES = {
     # sets), a 1e-3 imbalance in the current controller's integrators behind it that takes the rest of the episode to die
     # (carried on the matrix-core path by symmetrical components), the current limit from step ~125
     "ramp_a1_touch": dict(N=4, seed=3, spec="both", n=15, steps=160, actions=("const", 1), env_ids=(17360, 20888, 45096, 63022)),
+    # 48 envs drawn from the 65 536-env batch of the 'dec' / 'no_change' episodes (seed 3): the distribution of the error along
+    # the Q_ref ramps over envs nobody picked -- current limit, momentary duty-cycle saturations and their aftermath included
+    "ramp_a1_sample": dict(N=48, seed=3, spec="both", n=15, steps=160, actions=("const", 1), env_ids=_SAMPLE_IDS),
+    "ramp_a2_sample": dict(N=48, seed=3, spec="both", n=15, steps=160, actions=("const", 2), env_ids=_SAMPLE_IDS),
     # a complete PVDER-v0 episode, random actions (tests of drift: etdlin and ETDRK4 replay it)
     "episode_random": dict(N=8, seed=1234, spec="both", n=15, steps=160, actions=("random", 2718)),
 }

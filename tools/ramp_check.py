@@ -52,7 +52,16 @@ def main():
         print("%s, action %d: steps compared %d (|m| < 0.999 in the bridge), trajectory rel-L2 %.2e, worst env step %.2e at step %d"
               % (name, act, last, traj, per[:last].max(), int(per[:last].max(axis=1).argmax())))
         if "env_ids" in c:
-            print("   env steps 118..128, per env: " + " | ".join(" ".join("%.1e" % v for v in per[t]) for t in range(118, 129)))
+            if c["N"] <= 8:
+                print("   env steps 118..128, per env: " + " | ".join(" ".join("%.1e" % v for v in per[t]) for t in range(118, 129)))
+            else:
+                w = per.max(axis=0)
+                tr = np.linalg.norm((got - want).transpose(1, 0, 2).reshape(c["N"], -1), axis=1) / np.linalg.norm(want.transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
+                print("   worst env step per env, sorted: " + " ".join("%.1e" % v for v in np.sort(w)))
+                print("   trajectory per env, sorted:     " + " ".join("%.1e" % v for v in np.sort(tr)))
+                print("   max |m_a| per env (bridge), in the order of the worst env step: " + " ".join("%.3f" % v for v in g["m_abs"].max(axis=0)[np.argsort(w)]))
+                print("   worst env step by 20-step block (all envs): " + " ".join("%.1e" % per[k:k + 20].max() for k in range(0, c["steps"], 20)))
+                print("   90 %% quantile over envs of the per-step error, by 20-step block: " + " ".join("%.1e" % np.quantile(per[k:k + 20].max(axis=0), 0.9) for k in range(0, c["steps"], 20)))
             continue
         print("   worst env step by 20-step block: " + " ".join("%.1e" % per[k:k + 20].max() for k in range(0, c["steps"], 20)))
         print("   |iref| / limit at block ends:    " + " ".join("%.3f" % (g["iref_abs"][min(k + 19, c["steps"] - 1)].max() / 1.7316) for k in range(0, c["steps"], 20)))
