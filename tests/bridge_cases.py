@@ -33,6 +33,8 @@ CASES = {
     # the Q_ref ramps over envs nobody picked -- current limit, momentary duty-cycle saturations and their aftermath included
     "ramp_a1_sample": dict(N=48, seed=3, spec="both", n=15, steps=160, actions=("const", 1), env_ids=_SAMPLE_IDS),
     "ramp_a2_sample": dict(N=48, seed=3, spec="both", n=15, steps=160, actions=("const", 2), env_ids=_SAMPLE_IDS),
+    # ... and the same 48 envs through a complete episode of RANDOM actions (the benchmark's workload)
+    "episode_random_sample": dict(N=48, seed=3, spec="both", n=15, steps=160, actions=("random", 4242), env_ids=_SAMPLE_IDS),
     # a complete PVDER-v0 episode, random actions (tests of drift: etdlin and ETDRK4 replay it)
     "episode_random": dict(N=8, seed=1234, spec="both", n=15, steps=160, actions=("random", 2718)),
 }

@@ -8,6 +8,9 @@ tests/golden/bridge_<name>.npz (BUILD-ORACLE goldens: parity unpinned, see make_
 One process per env (the C bridge is single-threaded); ~25 s per env and 160-step episode."""
 import multiprocessing as mp
 import os
+
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):     # one process per env: BLAS threads on top only fight
+    os.environ.setdefault(_v, "1")                                            # (48 envs: 109 s with, 14 min without)
 import sys
 import time
 

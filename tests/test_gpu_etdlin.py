@@ -93,6 +93,34 @@ def test_etdlin_full_episode_does_not_drift(gpu_device):
     assert bool(done.all())
 
 
+def test_random_action_episode_on_a_sample_of_the_batch(gpu_device):
+    """The benchmark's workload -- a complete episode of random actions, both kinds of events -- on 48 envs DRAWN from
+    the 65 536-env batch (tests/bridge_cases.py episode_random_sample, converged-bridge golden): every env step of
+    every env, the discrete rewards (mismatches only at a threshold), done flags."""
+    import bridge_cases
+    name = "episode_random_sample"
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    N, steps = c["N"], c["steps"]
+    env = make_vec(N, gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"])
+    env.reset()
+    env.set_event_tables(torch.from_numpy(vg.astype(np.float32)).to(gpu_device), torch.from_numpy(si.astype(np.float32)).to(gpu_device))
+    env.reset()
+    got, rews = [], []
+    for t in range(steps):
+        obs, rew, done, _ = env.step(torch.as_tensor(acts[t], device=gpu_device))
+        got.append(obs.cpu().numpy().astype(np.float64)); rews.append(rew.cpu().numpy().astype(np.float64))
+        assert np.array_equal(done.cpu().numpy(), g["done"][t])
+        assert env.step_stats()["n_nonfinite"] == 0
+    got, rews, want = np.stack(got), np.stack(rews), g["obs"]
+    per = rel_l2(got, want, axis=2)
+    assert per.max() < FP32_TOL / 2, (int(per.max(axis=1).argmax()), per.max())          # every env step of every env
+    flat = lambda a: a.transpose(1, 0, 2).reshape(N, -1)
+    assert rel_l2(flat(got), flat(want), axis=1).max() < TIGHT
+    assert_discrete_rewards(rews, g["reward"], want, goal="voltage_regulation", what=name)
+
+
 def test_etdlin_schedule_is_per_lane(gpu_device):
     """An env's trajectory must not depend on which envs share its wave (the ETDRK4
     schedule is wave-uniform).  Every second lane is reset mid-episode, off the event grid, so from
