@@ -1326,8 +1326,11 @@ struct LinK {
                                      // time steps takes behind its tick
     float est_guard;                 // a step whose indicator max |y+ - b| over (i_a, Vdc) exceeds this hands the env
                                      // to the 23-state path
-    float ir2_careful;               // |iref_a|^2 at the start of a step above which the env takes the careful pass
-                                     // (current limit: hybrid steps with the outer loops' anti-windup, finer schedule)
+    float ir2_careful;               // (0.95 iref_limit)^2: an env whose |iref_a|^2 exceeds it at the start of the tick or of an ETD3RK
+                                     // step takes the careful pass (current limit: hybrid steps with the outer loops' anti-windup,
+                                     // finer schedule).  Below the limit the standard pass IS the model; the 5 % cover what |iref|
+                                     // does between two samples 1/8 s apart and comes back from (the outer loops' overshoot behind an
+                                     // event: 2-3 %); an excursion that stays shows in the next sample.  (0.9 until late in round 3.)
     float sat2_hard;                 // |m|^2 beyond which an env leaves the balanced reduction for the 23-state path.  Between
                                      // the smooth-step guard (0.998 m_limit: what two samples per 0.125 s step can vouch
                                      // for) and this one (0.9995: what the careful pass's 24 samples can) it takes the
@@ -1504,7 +1507,7 @@ __device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys)
 
 // One ETD3RK step of every lane from Y with the coefficient set in Ac: Yn = y+, returns whether the lane
 // must be handed to the 23-state path (|m| guard at the start, the middle -- stage a --, the end of the step;
-// embedded error indicator, |m| beyond the hard guard); near_ilim: |iref| at the start of the step is within 10 % of the
+// embedded error indicator, |m| beyond the hard guard); near_ilim: |iref| at the start of the step is within 5 % of the
 // current limit, or |m| beyond the smooth-step guard at the start, middle or end (careful pass)
 template <int PH>
 __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
@@ -3175,8 +3178,8 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         K.lcoef = lin->sets;
         K.sched = (const unsigned long long *)lin->sched;
         K.est_guard = lin->est_guard;
-        // the careful pass takes over where |iref| comes within 10 % of the current limit
-        K.ir2_careful = (float)(0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]);
+        // the careful pass takes over where |iref| comes within 5 % of the current limit
+        K.ir2_careful = (float)(0.95 * 0.95 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]);
         K.sat2_hard = (float)(0.9995 * 0.9995 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
         // the propagator of a small imbalance: its (x, x) entry is exp(-T Ki/Kp) -- an all-zero block (a caller written
         // against ABI 10) would silently drop what an anti-windup episode leaves in the controller's integrators

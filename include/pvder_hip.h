@@ -247,7 +247,7 @@ int pvder_step_rk45_f64(const double *par, const pvder_step_cfg *cfg, const pvde
  *                  any ETD3RK step -- hopelessly far from the operating point L was taken at -- is
  *                  advanced by the 23-state ETDRK4 path instead (`coef`, as for
  *                  pvder_step_etdrk4_f32), like the envs that come near the duty-cycle limit or are not balanced.
- * The careful pass: an env whose current reference comes within 10 % of iref_limit (a policy that holds one
+ * The careful pass: an env whose current reference comes within 5 % of iref_limit (a policy that holds one
  * Q_ref action walks there, PVDER_env.py:214-217, :480-487) stays on this path; its env step is taken by hybrid
  * ETD3RK steps that carry the reference model's conditional integration of the outer PI loops -- free, frozen,
  * or sliding along |iref| = iref_limit, with the crossing located inside the step (csrc: lin_integrate_careful). */
