@@ -90,7 +90,7 @@ using pvder::v2;
 #define PVDER_BLOCK 256
 #endif
 constexpr int kBlock = PVDER_BLOCK;   // 4 waves: one per SIMD of a CU
-constexpr int kDeferred = -1; // transient istate status (single-phase ETDRK4 only): "advance me in the follow-up launch"
+constexpr int kDeferred = -1; // transient istate status (etdlin64 only): "advance me in the follow-up launch" (step_rk45_kernel)
 
 template <typename T>
 struct StepK {
@@ -403,28 +403,30 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
 // =============================================================================================
 // classic RK4 micro-stepping, generic template (single phase; A/B reference of the packed form)
 // =============================================================================================
+// The body of step_rk4_kernel; also the tail of the single-phase etdlin / ETDRK4 step kernels (only_mine: the lanes
+// the fast path handed over, `mine`; micro: classic RK4 steps per sim time step).
 template <typename T, int PH>
-__global__ __launch_bounds__(kBlock) void step_rk4_kernel(
-    const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
+__device__ __forceinline__ void rk4_body(
+    const ModelK<T> &P, const StepK<T> &C, int micro, const ResetK &R, T *__restrict__ fstate, int32_t *__restrict__ istate,
     float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
-    T *__restrict__ out, float *__restrict__ stats, int n_env, int stats_fresh,
-    int run_status) {
+    T *__restrict__ out, float *__restrict__ stats, int n_env, int stats_fresh, int run_status, bool only_mine, bool mine) {
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     Lane<T> L;
     T y[NS], comp[NS];
     prologue<T, NS>(C, fstate, istate, action, n_env, L, y, run_status);
+    if (only_mine) L.live = L.run = L.run && mine;
 #pragma unroll
     for (int k = 0; k < NS; ++k) comp[k] = (T)0;
-    const T h = (T)(1.0 / 60.0) / (T)C.micro;
+    const T h = (T)(1.0 / 60.0) / (T)micro;
     const T h2 = (T)0.5 * h, h6 = h * (T)(1.0 / 6.0);
-    const T tq = (T)2 / (T)C.micro;                // 2*theta advances 2 turns per 1/60 s
+    const T tq = (T)2 / (T)micro;                  // 2*theta advances 2 turns per 1/60 s
     if (L.run) {
         SubK<T, PH> S;
         for (int s = 0; s < C.n_sub; ++s) {
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
             pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + L.ec], (T)ev_si[(size_t)row * N + L.ec], S);
-            for (int j = 0; j < C.micro; ++j) {
+            for (int j = 0; j < micro; ++j) {
                 T k[NS], ks[NS], yt[NS];
                 const T t0 = (T)j * tq, t1 = ((T)j + (T)0.5) * tq, t2 = ((T)j + (T)1) * tq;
                 pvder::rhs<T, PH>(P, S, y, t0, L.qref, L.vdcref, k);
@@ -452,6 +454,14 @@ __global__ __launch_bounds__(kBlock) void step_rk4_kernel(
         L.steps += 1;
     }
     epilogue<T, PH>(P, C, R, L, y, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
+}
+template <typename T, int PH>
+__global__ __launch_bounds__(kBlock) void step_rk4_kernel(
+    const ModelK<T> P, const StepK<T> C, const ResetK R, T *__restrict__ fstate, int32_t *__restrict__ istate,
+    float *__restrict__ ev_vg, float *__restrict__ ev_si, const uint8_t *__restrict__ action,
+    T *__restrict__ out, float *__restrict__ stats, int n_env, int stats_fresh,
+    int run_status) {
+    rk4_body<T, PH>(P, C, C.micro, R, fstate, istate, ev_vg, ev_si, action, out, stats, n_env, stats_fresh, run_status, false, false);
 }
 
 // ---- packed pair layout <-> pvder state order
@@ -607,6 +617,8 @@ struct EtdArgs {
     int n_env;
     int force_full;          // A/B and tests: every env takes the 23-state path
     int rk4_fallback;        // A/B and tests: steps at the duty-cycle limit by classic RK4 micro-steps (round 2's way)
+    int ph1_micro;           // single phase: classic RK4 micro-steps per sim time step of the envs the fast path hands over
+                             // (8192: poles at 1.0e6 rad/s) -- the tail of the step kernel (rk4_tail_1ph)
 };
 
 typedef __attribute__((address_space(3))) v4 lds_v4;     // LDS-resident coefficient entries
@@ -1045,6 +1057,15 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
 }
 
+// Single phase: the envs the fast path hands over (estimate guard, duty cycle at its limit -- the single-phase inverter
+// never gets there in PVDER-v0: |m| <= 0.73 along all four fixed-action episodes) are redone by classic RK4 micro-steps
+// right here, by the workgroup that holds them, like the three-phase kernels run their 23-state path: no second
+// launch (until late in round 3 every single-phase step paid for one, 4 us of 13, to pick up envs that are never there).
+__device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const uint8_t *act = nullptr, long long out_off = 0) {
+    rk4_body<float, 1>(A.P, A.C, A.ph1_micro, A.R, A.fstate, A.istate, A.ev_vg, A.ev_si, act ? act : A.action, A.out + out_off,
+                       A.stats, A.n_env, 0, 0, true, defer);
+}
+
 // =============================================================================================
 // ETDRK4, balanced fast path.  PVDER-v0 feeds the 'ThreePhaseUnbalanced' model a balanced grid
 // (unbalance ratios 1.0) from a balanced steady state, and the ODE maps balanced states to balanced
@@ -1285,20 +1306,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         L.fail = L.run;     // single phase: the hand-over would be classic RK4 for the whole env step -- the episode ends instead
     } else if (defer) {
         // hand the env over untouched: nothing stored, nothing added to the stats
-        if constexpr (PH == 1) istate[PVDER_I_STATUS * N + L.e] = kDeferred;     // marker for the follow-up launch
         L.run = false;
         L.live = false;
     }
     epilogue<float, PH>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
     PVDER_TRACE_AT(21);
-    if constexpr (PH == 3) {
-        // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the
-        // 23-state path right here -- no second launch
-        if (__syncthreads_or((int)defer)) {
-            KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(ka));
-            etdrk4_full_tail(*(const EtdArgs *)ka, defer);
-        }
+    // the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state path (three-phase) / classic RK4
+    // micro-steps (single phase) right here -- no second launch
+    defer = defer && !L.fail;
+    if (__syncthreads_or((int)defer)) {
+        KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        if constexpr (PH == 3) etdrk4_full_tail(*(const EtdArgs *)ka, defer);
+        else rk4_tail_1ph(*(const EtdArgs *)ka, defer);
     }
 }
 
@@ -2024,22 +2044,23 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     if (PH == 1 && defer && E.C.off_range == PVDER_OFF_RANGE_TERMINATE) {
         L.fail = L.run;     // single phase: the hand-over would be classic RK4 for the whole env step -- the episode ends instead
     } else if (defer) {
-        if constexpr (PH == 1) E.istate[PVDER_I_STATUS * (size_t)E.n_env + L.e] = kDeferred;   // marker for the follow-up launch
         L.run = false;
         L.live = false;
     }
     epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out + out_off, E.stats, E.n_env,
                         stats_fresh, true, vg_stop, si_stop);
     PVDER_TRACE_AT(21);
-    if constexpr (PH == 3) {
-        // three-phase: the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state
-        // path right here -- no second launch
+    {
+        // the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state path (three-phase) / classic
+        // RK4 micro-steps (single phase) right here -- no second launch
+        defer = defer && !L.fail;
         PVDER_DBG_COUNT(10, defer);
         if (__syncthreads_or((int)defer)) {
             PVDER_DBG_COUNT(11, threadIdx.x == 0);
             KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
             asm volatile("" : "+s"(kb));
-            etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
+            if constexpr (PH == 3) etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
+            else rk4_tail_1ph(*(const EtdArgs *)kb, defer, act, out_off);
         }
     }
 }
@@ -3168,6 +3189,7 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
     A.rk4_fallback = (cfg->reserved & 2) ? 1 : 0;
+    A.ph1_micro = p.C4.micro;
     if (integrator == PVDER_INT_ETDLIN) {
         if (!lin || !lin->sets || !lin->sched || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
         if (lin->len_ticks[0] < 1 || !(lin->est_guard > 0.f)) return PVDER_EINVAL;
@@ -3209,10 +3231,9 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         EtdArgs &A = G.A;
         A.fstate = (float *)fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
         A.action = action; A.out = (float *)out; A.stats = stats; A.stats_fresh = fresh;
-        // Three-phase: ONE launch -- the balanced fast path, whose workgroups run the 23-state path
-        // themselves for the envs they must defer (none in PVDER-v0 rollouts).  Single phase: the
-        // "balanced" kernel IS the model; an env near a limit is redone by classic RK4 micro-steps
-        // (8192 per 1/60 s) in a follow-up launch.
+        // ONE launch -- the fast path, whose workgroups themselves run the 23-state path (three-phase) / classic RK4
+        // micro-steps, 8192 per 1/60 s (single phase: the "balanced" kernel IS the model) for the envs they must defer
+        // (none in PVDER-v0 rollouts).
         if (p.integrator == PVDER_INT_ETDLIN) {
             if (p.ph == 3)
                 hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, 0, G);
@@ -3222,9 +3243,6 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
         }
-        if (p.ph == 1)
-            hipLaunchKernelGGL((step_rk4_kernel<float, 1>), grid, block, 0, st, p.Pf, p.C4, p.R, (float *)fstate, istate,
-                               ev_vg, ev_si, action, (float *)out, stats, n_env, 0, (int)kDeferred);
         break;
     }
     case PVDER_INT_RK4: {

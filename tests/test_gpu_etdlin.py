@@ -121,6 +121,36 @@ def test_random_action_episode_on_a_sample_of_the_batch(gpu_device):
     assert_discrete_rewards(rews, g["reward"], want, goal="voltage_regulation", what=name)
 
 
+def test_single_phase_hand_over_is_classic_rk4_inside_the_same_launch(gpu_device):
+    """model_1: the envs the fast path hands over (here all of them: hand-over guard below every indicator value) are
+    redone by classic RK4 micro-steps, 8192 per sim time step, by the step kernel's own workgroups -- the same
+    arithmetic as integrator='rk4' with that step count (to fp32 rounding: hipcc contracts the multiply-adds of the model
+    differently in the two kernels), same counters and done flags, and no marker left in the status row."""
+    N, n_sub, steps = 64, 4, 3
+    kw = dict(model_type='model_1', n_sim_time_steps_per_env_step=n_sub, seed=5, events_spec=both_events_spec(), auto_reset=False)
+    a = make_vec(N, gpu_device, integrator="etdlin", **kw)
+    a.est_guard = 1e-9
+    a.reset()
+    b = make_vec(N, gpu_device, integrator="rk4", micro_steps=8192, **kw)
+    b.reset()
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(4)
+    for t in range(steps):
+        act = torch.randint(0, 5, (N,), generator=gen, device=gpu_device, dtype=torch.uint8)
+        a.step(act, return_tensors=False); b.step(act, return_tensors=False)
+        d_ab = rel_l2(a.out[:11].cpu().numpy().astype(np.float64).reshape(-1), b.out[:11].cpu().numpy().astype(np.float64).reshape(-1))
+        assert d_ab < 1e-6 and torch.equal(a.out[11:], b.out[11:]) and torch.equal(a.istate, b.istate), (t, d_ab)
+        sa, sb = a.step_stats(), b.step_stats()
+        assert sa["n_done"] == sb["n_done"] and sa["n_nonfinite"] == sb["n_nonfinite"] == 0 and abs(sa["reward_sum"] - sb["reward_sum"]) < 1e-3
+    assert int(a.istate[3].min()) == 0 and int(a.istate[3].max()) == 0
+    c = make_vec(N, gpu_device, integrator="etdlin", **kw)         # ... and with the default guard nobody is handed over:
+    c.reset()                                                      # the exponential integrator's answer, 1e-5 away
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(4)
+    for t in range(steps):
+        c.step(torch.randint(0, 5, (N,), generator=gen, device=gpu_device, dtype=torch.uint8), return_tensors=False)
+    d_ca = rel_l2(c.out[:11].cpu().numpy().astype(np.float64).reshape(-1), a.out[:11].cpu().numpy().astype(np.float64).reshape(-1))
+    assert 3 * d_ab < d_ca < FP32_TOL, (d_ab, d_ca)
+
+
 def test_etdlin_schedule_is_per_lane(gpu_device):
     """An env's trajectory must not depend on which envs share its wave (the ETDRK4
     schedule is wave-uniform).  Every second lane is reset mid-episode, off the event grid, so from
