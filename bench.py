@@ -76,6 +76,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--fixed-policy", type=int, default=1, help="1: time the four fixed-action ramps of calc_returns' kind (0 = skip)")
     ap.add_argument("--rk45-steps", type=int, default=2, help="fp64 RK45 steps (BASELINE configs[4]) timed beside the main run (0 = skip)")
+    ap.add_argument("--large-batch", type=int, default=1 << 20, help="envs of the large_batch leg (same kernel, one launch per env step; 0 = skip)")
+    ap.add_argument("--single-env-steps", type=int, default=1000, help="steps of the single_env leg: make('PVDER-v0'), random agent (0 = skip)")
     ap.add_argument("--time-every", type=int, default=64,
                     help="bracket every K-th step kernel with HIP events (clamped so that even a short run gets samples); 0 = none")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
@@ -165,6 +167,32 @@ def launch_ranks(n: int, argv) -> int:
     return rc
 
 
+def payload_rows_per_step(payload: str, gather_every: int) -> float:
+    """Rows of the [13, N_local] block a step collates on average."""
+    return {"full": 13.0, "reward_done": 2.0}.get(payload, 2.0 + 11.0 / max(gather_every, 2))
+
+
+def xgmi_roofline(world: int, n_local: int, rows: float, sec_per_step: float) -> dict:
+    """What the collective must move and the bound xGMI puts on it (MI355X_MICROARCH.md: 7 links x ~153 GB/s
+    bidirectional per GPU, i.e. ~77 GB/s into a GPU per link, all peers in parallel)."""
+    recv = (world - 1) * n_local * 4 * rows
+    return {"bound": "xgmi", "bytes_received_per_step_per_gpu": recv,
+            "achieved": finite(recv / sec_per_step / 1e9), "peak": 7 * 76.5, "unit": "GB/s",
+            "frac": finite(recv / sec_per_step / (7 * 76.5e9)),
+            "frac_of_the_links_in_use": finite(recv / sec_per_step / (max(world - 1, 1) * 76.5e9)),
+            "note": "bytes a GPU receives per step / step time, against 7 links x 76.5 GB/s into one GPU "
+                    "(MI355X_MICROARCH.md); with fewer than 8 ranks only world-1 links carry data"}
+
+
+def payload_leg(world: int, n_local: int, steps: int, seconds: float, payload: str, gather_every: int, host_s=None) -> dict:
+    rows = payload_rows_per_step(payload, gather_every)
+    d = {"value": world * n_local * steps / seconds, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * seconds / steps,
+         "rows_per_step": rows, "xgmi_roofline": xgmi_roofline(world, n_local, rows, seconds / steps)}
+    if host_s is not None:
+        d["host_enqueue_ms_per_step"] = 1e3 * host_s / steps
+    return d
+
+
 def selftest_rank():
     """--selftest-launcher: what a rank does, minus the GPU (gloo all-reduce of the rank ids)."""
     import torch
@@ -174,8 +202,25 @@ def selftest_rank():
     t = torch.zeros(world, dtype=torch.int64)
     t[rank] = 1
     dist.all_reduce(t)
+    # the N > 1 line's three legs -- no collation / the whole block / (reward, done) -- with a stand-in for the step launch
+    # (gloo on the CPU: the STRUCTURE of the line, not a rate)
+    from gym_PVDER_amd.distributed import gather_payload
+    n_local, steps = 256, 4
+    blk = torch.full((13, n_local), float(rank))
+    legs = {}
+    for name in ("compute_only", "full", "reward_done"):
+        dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            blk += 1.0                                   # "the step"
+            if name != "compute_only":
+                gather_payload(blk, k, name, 1)
+        dist.barrier()
+        el = time.perf_counter() - t0
+        legs[name] = ({"value": world * n_local * steps / el, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * el / steps}
+                      if name == "compute_only" else payload_leg(world, n_local, steps, el, name, 1))
     if rank == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.sum())}))
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.sum()), "payload_legs": legs}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -332,6 +377,55 @@ def rk45_leg(torch, dev, N, n_sub, steps=2):
             "hbm_frac": BYTES_PER_ENV_STEP["f64"] * N / avg / HBM_PEAK, "n_nonfinite": env.step_stats()["n_nonfinite"]}
 
 
+def single_env_leg(steps=1000):
+    """BASELINE configs[0] on the PRODUCT: ``gym_PVDER_amd.make('PVDER-v0')`` (the drop-in's own single env = a PVDERVec of one
+    env), random agent, `steps` steps with reset() at every episode end -- the loop of the reference's
+    examples/gym_PVDER_environment_import_test.py:23-31.  One launch + one host read-back per step: a latency figure."""
+    import gym_PVDER_amd as gp
+    env = gp.make('PVDER-v0')
+    env.reset()
+    for _ in range(20):
+        env.step(env.action_space.sample())
+    env.reset()
+    t0 = time.perf_counter()
+    episodes = 0
+    for _ in range(steps):
+        _, _, done, _ = env.step(env.action_space.sample())
+        if done:
+            env.reset()
+            episodes += 1
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "env-steps/s", "steps": steps, "episodes_finished": episodes, "us_per_step": 1e6 * el / steps,
+            "workload": "BASELINE configs[0]: 1 env, gym_PVDER_amd.make('PVDER-v0') defaults, random agent, reset() at every "
+                        "episode end; one launch and one host read-back (obs, reward, done as Python objects) per step"}
+
+
+def large_batch_leg(torch, dev, n_sub, N=1 << 20, steps=300, warm=60):
+    """The same workload, kernel and launch-per-env-step at 1 048 576 envs per GPU: sixteen waves per SIMD's worth of envs
+    instead of one -- the batch at which the step kernel's loads, arithmetic and stores overlap across waves."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2024, events_spec=events_on_spec(), auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(55)
+    acts = torch.randint(0, 5, (steps, N), generator=gen, device=dev, dtype=torch.uint8)
+    env.rollout(acts[:warm], fused=False)
+    r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    r0.record()
+    env.rollout(acts, fused=False)
+    r1.record()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    per = r0.elapsed_time(r1) * 1e-3 / steps
+    return {"value": N * steps / el, "unit": "env-steps/s", "envs": N, "steps": steps, "ms_per_step": 1e3 * el / steps,
+            "region_ms_per_step": per * 1e3, "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK,
+            "achieved_GBps": BYTES_PER_ENV_STEP["f32"] * N / per / 1e9, "kernel": KERNEL_NAME["etdlin"],
+            "n_nonfinite": env.step_stats()["n_nonfinite"],
+            "note": "one launch per env step, same events / random actions / auto-reset as the headline; NOT the headline (configs[2] is 65 536 envs)"}
+
+
 def kernel_source_hash() -> str:
     """sha256 over the kernel sources: a PMC summary under profiles/ is only valid for the code it
     was measured on."""
@@ -380,6 +474,8 @@ def sample_period(time_every: int, steps: int) -> int:
 # ---------------------------------------------------------------------------------------------------
 def run_rank(args):
     import torch
+    from gym_PVDER_amd.distributed import check_payload
+    check_payload(args.payload, args.gather_every)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -670,12 +766,24 @@ def run_rank(args):
                      "note": "same envs, events and random actions as the headline; results bit-identical to one launch per "
                              "step (tests/test_gpu_etdlin.py::test_fused_rollout_equals_single_steps); NOT the headline"}
     compute_only = None
+    payload_legs = {}
     if dist is not None:        # the same steps without the collective: what the gather costs
         el_c, host_c, k_c, region_c = timed(total, args.steps, every, gather=False)
         compute_only = {"value": world * N * args.steps / el_c, "unit": "env-steps/s", "steps": args.steps,
                         "ms_per_step": 1e3 * el_c / args.steps, "host_enqueue_ms_per_step": 1e3 * host_c / args.steps,
                         "kernel_avg_ms": finite(min(sum(k_c) / len(k_c), region_c)) if k_c else finite(region_c),
                         "kernel_samples": len(k_c)}
+        # ... and the same steps once per payload the consumer can choose (ONE run tells the whole story):
+        # `value` stays the payload of the command line (default "full": what BASELINE configs[3] names)
+        if native is not None:
+            main_payload = args.payload
+            for pl in ("full", "reward_done"):
+                if pl == main_payload:
+                    continue
+                native.payload = pl
+                el_p, host_p, _, _ = timed(total, args.steps, 0)
+                payload_legs[pl] = payload_leg(world, N, args.steps, el_p, pl, args.gather_every, host_p)
+            native.payload = main_payload
 
     if rank == 0:
         prec = "f64" if args.integrator == "rk45" else "f32"
@@ -783,26 +891,23 @@ def run_rank(args):
             "last_step_stats": st,
         }
         if dist is not None:
-            # what the collective must move and the bound xGMI puts on it (MI355X_MICROARCH.md: 7 links x
-            # ~153 GB/s bidirectional per GPU, i.e. ~77 GB/s into a GPU per link, all peers in parallel)
             blk = 13 * N * 4
             out["compute_only"] = compute_only
             rows = 13.0
-            if native is not None and args.payload == "reward_done":
-                rows = 2.0
-            elif native is not None and args.payload == "full_every_k" and args.gather_every > 1:
-                rows = 2.0 + 11.0 / args.gather_every
+            if native is not None:
+                rows = payload_rows_per_step(args.payload, args.gather_every)
             elif args.payload != "full":
-                warnings.append("--payload %s needs the C-side step+gather path: the whole block was collated" % args.payload)
+                warnings.append("--payload %s needs the C-side step+gather path (unavailable in this run: c10d fallback): "
+                                "the whole block was collated" % args.payload)
             out["config"]["payload"] = {"mode": args.payload if native is not None else "full", "rows_per_step": rows,
                                         "gather_every": args.gather_every if args.payload == "full_every_k" else None}
-            recv = (world - 1) * blk * rows / 13.0
-            out["xgmi_roofline"] = {"bound": "xgmi", "bytes_received_per_step_per_gpu": recv,
-                                    "achieved": finite(recv / (elapsed / args.steps) / 1e9), "peak": 7 * 76.5, "unit": "GB/s",
-                                    "frac": finite(recv / (elapsed / args.steps) / (7 * 76.5e9)),
-                                    "frac_of_the_links_in_use": finite(recv / (elapsed / args.steps) / (max(world - 1, 1) * 76.5e9)),
-                                    "note": "bytes a GPU receives per step / step time, against 7 links x 76.5 GB/s into one GPU "
-                                            "(MI355X_MICROARCH.md); with fewer than 8 ranks only world-1 links carry data"}
+            out["xgmi_roofline"] = xgmi_roofline(world, N, rows, elapsed / args.steps)
+            # the three legs side by side: no collation / the whole block / (reward, done) -- same process, same steps
+            main = {"value": value, "unit": "env-steps/s", "steps": args.steps, "ms_per_step": ms_per_step, "rows_per_step": rows,
+                    "xgmi_roofline": out["xgmi_roofline"]}
+            legs = dict(payload_legs)
+            legs[args.payload if native is not None else "full"] = main
+            out["payload_legs"] = {"compute_only": compute_only, **{k: legs[k] for k in sorted(legs)}}
             out["xgmi_bound"] = {"bytes_received_per_step_per_gpu": (world - 1) * blk,
                                  "link_GBps_one_direction": 76.5,
                                  "min_us_per_step": blk / 76.5e9 * 1e6 if world > 1 else 0.0,
@@ -813,6 +918,10 @@ def run_rank(args):
         if world == 1 and dist is None and args.integrator == "etdlin":
             del env, actions                         # (the side legs build their own envs)
             try:
+                if args.large_batch > 0:
+                    out["large_batch"] = large_batch_leg(torch, dev, args.n_sub, N=args.large_batch)
+                if args.single_env_steps > 0:
+                    out["single_env"] = single_env_leg(args.single_env_steps)
                 if args.fixed_policy:
                     out["fixed_policy"] = fixed_policy_leg(torch, dev, N, args.n_sub)
                 if args.rk45_steps > 0:

@@ -366,7 +366,12 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
             tfrac = (T)0;
         }
 #pragma unroll
-        for (int q = 0; q < NS; ++q) st(&fstate[(size_t)q * N + e], y[q]);
+        for (int q = 0; q < NS; ++q) {
+#ifdef PVDER_AB_SKIPBCST
+            if (PH == 3 && q >= 6 && q < 18) continue;      // A/B ONLY: what the store burst costs
+#endif
+            st(&fstate[(size_t)q * N + e], y[q]);
+        }
         st(&fstate[(size_t)NS * N + e], L.qref);
         st(&fstate[(size_t)(NS + 1) * N + e], L.vdcref);
         st(&istate[PVDER_I_KSUB * N + e], (int32_t)L.ksub);
@@ -1963,7 +1968,8 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
 template <int PH, int KOFF>
 __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
                                               int &cur, const uint8_t *__restrict__ act, long long out_off, int stats_fresh,
-                                              const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env) {
+                                              const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env,
+                                              bool only = true) {
     using namespace pvder;
     const EtdArgs &A = G.A;
     constexpr int NS = 6 * PH + 5;
@@ -1972,6 +1978,9 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
+    // `only`: the lanes this pass advances (step_etdlin_kernel: the envs its lean first pass, lin_step_lean, left alone;
+    // everyone else of the workgroup has stored its result -- and been counted -- already)
+    if (!only) { L.run = false; L.live = false; L.bad_action = 0.f; }
     // ksub is the first state word to arrive: the event inputs and the schedule row of the first segment
     // are requested while the other state rows are still in flight
     const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
@@ -2053,7 +2062,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     {
         // the deferred envs of this workgroup (none in PVDER-v0 rollouts) take the 23-state path (three-phase) / classic
         // RK4 micro-steps (single phase) right here -- no second launch
-        defer = defer && !L.fail;
+        defer = defer && !L.fail && only;
         PVDER_DBG_COUNT(10, defer);
         if (__syncthreads_or((int)defer)) {
             PVDER_DBG_COUNT(11, threadIdx.x == 0);
@@ -2083,6 +2092,86 @@ constexpr int kLinHeadBytes = (int)sizeof(LinHead);
 static_assert(alignof(LinArgs) <= 8 && sizeof(LinHead) % alignof(LinArgs) == 0, "LinArgs must start right behind LinHead");
 static_assert(offsetof(LinArgs, A) == 0, "the 23-state tail reads EtdArgs at the start of LinArgs");
 
+// The LEAN first pass of step_etdlin_kernel: the env transition of every env that stays on the standard path -- balanced,
+// clear of the current limit and of the duty-cycle guards: every env of a PVDER-v0 rollout under a random or a
+// learning policy -- with nothing else in its live ranges.  It is the step of the fused rollout kernel (lin_integrate
+// with ONE hand-over flag), through memory.  An env that needs anything more (off balance: symmetrical components; at
+// the current limit: the careful pass; at the duty-cycle limit: the 23-state path) is left untouched -- nothing of it is
+// stored or counted -- and the workgroup that holds one takes it through lin_step_body from the state still in memory
+// (round 3 ran that body for everyone: the careful flag, the guard scale of the symmetrical-component carry and the 23
+// state rows kept for the careful pass's restart rode along on the standard path -- 8.3 -> 8.8 us per step).  Same
+// arithmetic for the envs that stay (msc = 1 is exact), same body for the ones that leave: bit-identical results.
+template <int PH, int KOFF>
+__device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
+                                              int &cur, const uint8_t *__restrict__ act, int stats_fresh,
+                                              const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env) {
+    using namespace pvder;
+    const EtdArgs &A = G.A;
+    constexpr int NS = 6 * PH + 5;
+    const size_t N = (size_t)n_env;
+    typedef __attribute__((address_space(4))) const char *KernargBytes;
+    Lane<float> L;
+    float ys[NS];
+#ifdef PVDER_AB_SKIPBC
+    // A/B ONLY (not a product build): what the load burst costs -- phases b, c are not read (the balance check is skipped)
+    {
+        L.e = blockIdx.x * kBlock + threadIdx.x;
+        L.live = L.e < n_env;
+        L.ec = L.live ? L.e : n_env - 1;
+        L.ksub = ld(&istate[PVDER_I_KSUB * N + L.ec]);
+        L.steps = ld(&istate[PVDER_I_STEPS * N + L.ec]);
+        L.status = ld(&istate[PVDER_I_STATUS * N + L.ec]);
+        L.run = L.live && L.status == 0;
+        L.fail = false;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) ys[k] = (k < 6 || k >= 6 * PH) ? ld(&fstate[(size_t)k * N + L.ec]) : 0.f;
+        L.qref = ld(&fstate[(size_t)NS * N + L.ec]);
+        L.vdcref = ld(&fstate[(size_t)(NS + 1) * N + L.ec]);
+        const int a = ld(&act[L.ec]);
+        L.bad_action = 0.f;
+        if (a == 1) L.qref += A.C.dq;
+        else if (a == 2) L.qref -= A.C.dq;
+        else if (a == 3) L.vdcref += A.C.dv;
+        else if (a == 4) L.vdcref -= A.C.dv;
+        else if (a != 0) L.bad_action = 1.f;
+    }
+#else
+    prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
+#endif
+    const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
+    int row_stop = sg.row;                     // (the inputs in force at tStop: see lin_step_body)
+    if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
+    else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
+    const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
+    PVDER_TRACE_AT(1);
+    bool leave = PH == 3 && A.force_full != 0;
+#ifndef PVDER_AB_SKIPBC
+    if constexpr (PH == 3) leave |= lin_unbalanced(ys);
+#endif
+    leave = leave && L.run;
+    {
+        v4f Y[3];
+        lin_from_rows<PH>(ys, Y);
+        PVDER_TRACE_AT(2);
+        bool careful;
+        leave = lin_integrate<PH, false>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, leave, careful, 0) && L.run;
+        if (L.run && !leave) {
+            lin_to_rows<PH>(Y, ys);
+            L.ksub += A.C.n_sub;
+            L.steps += 1;
+        }
+    }
+    PVDER_TRACE_AT(20);
+    KernargPtr ka = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
+    PVDER_LAUNDER_EPI(ka);
+    const EtdArgs &E = *(const EtdArgs *)ka;
+    if (leave) { L.run = false; L.live = false; }
+    epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out, E.stats, E.n_env, stats_fresh, true,
+                        vg_stop, si_stop);
+    PVDER_TRACE_AT(21);
+    return leave;
+}
+
 template <int PH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
                                                              const float *lcoef, int n_env, int pad, const LinArgs G) {
@@ -2101,7 +2190,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     lin_load_set(lcoef + kLinMatFloats, lane, Ac);
     PVDER_TRACE_DEP(19, At[0] + Ac[5][2]);               // (... the coefficient registers are loaded)
     int cur = 1;
+#ifdef PVDER_NO_LEAN
     lin_step_body<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, 0, G.A.stats_fresh, fstate, istate, n_env);
+#else
+    const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, G.A.stats_fresh, fstate, istate, n_env);
+    if (__syncthreads_or((int)leave)) {
+        // (rare: every argument again through a laundered copy of the kernarg pointer -- nothing of this pass stays
+        // live across the lean one)
+        typedef __attribute__((address_space(4))) const char *KernargBytes;
+        typedef __attribute__((address_space(4))) const LinArgs *LinKernargPtr;
+        LinKernargPtr kc = (LinKernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + kLinHeadBytes);
+        asm volatile("" : "+s"(kc));
+        const LinArgs &Gc = *(const LinArgs *)kc;
+        lin_step_body<PH, kLinHeadBytes>(Gc, lane, At, Ac, cur, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
+    }
+#endif
 }
 
 // =============================================================================================

@@ -49,13 +49,20 @@ PAYLOADS = ("full", "reward_done", "full_every_k")
 REWARD_ROW = 11
 
 
-def payload_rows(payload: str, step_index: int, every: int = 1) -> Tuple[int, int]:
-    """(first row, number of rows) of the [13, N] output block that step number ``step_index`` (0-based) collates."""
+def check_payload(payload: str, every: int = 1) -> None:
+    """ONE validator for every layer (ShardedPVDERVec, NativeStepGather, bench.py): "full_every_k" needs a period of at
+    least 2 -- with 1 it IS "full", and the C path (full_every <= 1: never a whole block) and the Python path used to
+    disagree about it."""
     if payload not in PAYLOADS:
         raise ValueError("payload must be one of %s" % (PAYLOADS,))
-    if payload == "full" or (payload == "full_every_k" and every > 1 and (step_index + 1) % every == 0):
-        return 0, 13
-    if payload == "full_every_k" and every <= 1:
+    if payload == "full_every_k" and (not isinstance(every, int) or every < 2):
+        raise ValueError("payload 'full_every_k' needs gather_every >= 2 (got %r); use payload='full' for every step" % (every,))
+
+
+def payload_rows(payload: str, step_index: int, every: int = 1) -> Tuple[int, int]:
+    """(first row, number of rows) of the [13, N] output block that step number ``step_index`` (0-based) collates."""
+    check_payload(payload, every)
+    if payload == "full" or (payload == "full_every_k" and (step_index + 1) % every == 0):
         return 0, 13
     return REWARD_ROW, 2
 
@@ -84,7 +91,7 @@ class ShardedPVDERVec:
         returns the GLOBAL reward and done and, on the steps without the whole block, ``None`` for the observation
         (the local shard's is ``self.env.obs``)."""
         from .vec_env import PVDERVec
-        payload_rows(payload, 0, gather_every)          # validates
+        check_payload(payload, gather_every)
         self.payload, self.gather_every, self._step_index = payload, int(gather_every), 0
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
@@ -95,6 +102,7 @@ class ShardedPVDERVec:
 
     def reset(self):
         self.env.reset()
+        self._step_index = 0             # the whole-block cadence of "full_every_k" restarts with the episode
         return self._collate()[0]
 
     def _collate(self):
@@ -214,8 +222,9 @@ class NativeStepGather:
         assert actions.dtype == torch.uint8 and actions.is_contiguous() and actions.shape[1] == env.num_envs
         plan = env._plan or env._make_plan()
         K = int(actions.shape[0])
+        check_payload(self.payload, self.gather_every)
         with env._device_ctx():
-            r0, nr = payload_rows(self.payload, 0, 0) if self.payload != "full_every_k" else (REWARD_ROW, 2)
+            r0, nr = payload_rows(self.payload, 0, 1) if self.payload != "full_every_k" else (REWARD_ROW, 2)
             rc = self._lib.pvder_plan_rollout_gather_rows(plan, self._h, env.fstate.data_ptr(), env.istate.data_ptr(),
                                                           env.ev_vg.data_ptr(), env.ev_si.data_ptr(), actions.data_ptr(), K,
                                                           self.out[0].data_ptr(), self.out[1].data_ptr(),

@@ -135,7 +135,8 @@ class PVDERVec(EnvSpecMixin):
                     micro-stepping), 'rk45' (fp64 adaptive Dormand-Prince: the literal tolerance-match path,
                     stability-bound at 0.5 s per batched step) or 'etdlin64' (fp64 etdlin with step doubling on a dyadic
                     menu as its error control -- rtol / atol in the RK45 kernel's norm --, the RK45 kernel behind it
-                    for the envs the balanced reduction does not cover: the tolerance-match path at ~10^4 x the rate)
+                    for the envs the balanced reduction does not cover: the tolerance-match path at ~2e2 x the rate,
+                    bench.py legs `rk45` / `etdlin64`)
         micro_steps: classic RK4: steps per 1/60 s sim time step (default 4096); ETDRK4 / etdlin: the
                     first step behind an input jump is 1/(60*micro_steps) s (default 32)
         micro_coarse: ETDRK4 only -- steps per sim time step that does not start at an input jump
@@ -165,8 +166,11 @@ class PVDERVec(EnvSpecMixin):
         several parameter sets see gym_PVDER_amd.param_groups.PVDERVecGroups.
         ``off_range``: an env driven out of the range the fast fp32 integrators cover (duty cycle / current
         reference at their limits: e.g. Vdc_ref walked down 6 %) is ``"integrate"``d through as the reference
-        does -- classic RK4 micro-steps, ~50 ms per env step for the WHOLE batch while one env is there -- or its
-        episode ``"terminate"``s (done, reward -100, the reference's failure branch PVDER_env.py:169-172)."""
+        does -- on the 23-state path, its steps at the duty-cycle limit on the operator sets of the anti-windup modes:
+        ~0.1 ms per env step for the WHOLE batch while one env is there (a launch lasts as long as its slowest
+        workgroup; bench.py `fixed_policy`) -- or its episode ``"terminate"``s (done, reward -100, the reference's
+        failure branch PVDER_env.py:169-172).  Envs at the CURRENT limit are not off range: they stay on the
+        matrix-core path (careful pass) and are never terminated."""
         if off_range not in ("integrate", "terminate"):
             raise ValueError("off_range must be 'integrate' or 'terminate'")
         self.off_range = off_range

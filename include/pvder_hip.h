@@ -94,8 +94,9 @@ typedef struct pvder_step_cfg {
     int32_t ev_ds;        /* ksub between events      (t_events_step*60)  */
     int32_t ev_count;     /* K events; event tables have K+1 rows (row 0 = nominal) */
     int32_t reserved;     /* integrator-specific test knob, 0 in production: RK45 = cap on attempts per
-                             sim time step; ETDRK4 / etdlin bit 0 = run the full 23-state kernel only, bit 1 = steps
-                             at the duty-cycle limit by classic RK4 micro-steps instead of the switched operator sets */
+                             sim time step; ETDRK4 / etdlin bit 0 = run the full 23-state kernel only (bit 1 is read by
+                             A/B builds with -DPVDER_RK4_FALLBACK only -- steps at the duty-cycle limit by classic RK4
+                             micro-steps; the shipped library ignores it) */
     double del_qref;      /* _delQref/Sbase   per env step (:617, :225) */
     double del_vdcref;    /* _delVdcref/Vdcbase per env step (:618, :229) */
     double inv_max_sim_time; /* obs[10] = tStart/max_sim_time (:540) */
@@ -116,11 +117,13 @@ typedef struct pvder_step_cfg {
                              Qtarget = PV_model.Q_ref, :238 -- 1e-6 when it is 0 in the discrete branch, :266-267),
                              PVDER_REWARD_VOLTAGE_ERROR the voltage_error term (:276-287) under the other goals */
     int32_t off_range;    /* what happens to an env that leaves the range the fast fp32 integrators cover -- duty
-                             cycle |m| at its limit or current reference at the overload limit, where the
-                             reference model's component-wise anti-windup switches the stiff dynamics:
+                             cycle |m| at its limit, where the reference model's component-wise anti-windup switches
+                             the stiff dynamics (an env at the CURRENT limit is in range since round 3: etdlin keeps it on
+                             the matrix-core path, careful pass, and never terminates it):
                              PVDER_OFF_RANGE_INTEGRATE (0, default): it is integrated through, as the reference
-                             does -- the 23-state path on the operator sets of the anti-windup modes, ~0.1 ms per env
-                             step for the launch while an env is there;  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
+                             does -- the 23-state path on the operator sets of the anti-windup modes (the mode of a
+                             phase is found at the START of an integrator step and held over it, up to 1/60 s), ~0.1 ms
+                             per env step for the launch while an env is there;  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
                              (status 2, done, reward -100: the reference's failure branch, :169-172) -- for
                              training runs that must not stall on a saturated converter.  fp32 exponential
                              integrators only (etdlin, ETDRK4). */

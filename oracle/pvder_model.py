@@ -101,7 +101,9 @@ class ModelOptions:
     m_limit: float = 1.0              # U2: anti-windup threshold on |m_p|
     refs_external: bool = True        # U3: Q_ref / Vdc_ref persist (env intent, PVDER_env.py:225-229,394)
     event_inclusive: bool = True      # U4: event at T is active for t >= T
-    ppv_uses_vdc: bool = True         # U5: Ppv evaluated at the instantaneous Vdc
+    ppv_uses_vdc: bool = True         # U5: Ppv evaluated at the instantaneous Vdc (False: at the MPP voltage Vdcmpp0)
+    ratio_is_vbase: bool = False      # U7: False: transformer ratio a = Vgridrated/(sqrt(2) Vrmsrated) (the choice consistent
+    #                                   with Vdc = 550 V and |m| ~ 0.9); True: SURVEY Appendix A's Vgridrated/Vbase
     rtol: float = 1e-4                # U6: LSODA tolerances of the "reference-settings" run
     atol: float = 1e-4
     hmax: float = 1.0 / 120.0
@@ -157,7 +159,7 @@ def build_model(der_id: str = "50", opts: Optional[ModelOptions] = None, overrid
         c[k] = float(v)
     phases = int(c["phases"])
     Varated = c["Vrmsrated"] * math.sqrt(2.0)
-    a = VGRIDRATED / Varated
+    a = VGRIDRATED / (VBASE if opts.ratio_is_vbase else Varated)
     Z1 = complex(c["R1_actual"], c["X1_actual"]) / ZBASE
     Z2 = Z2_ACTUAL / ZBASE
     Zl = ZLOAD1_ACTUAL / ZBASE
@@ -227,7 +229,7 @@ def algebraic(m: DERModel, y: Sequence[float], t: float, vg_mag: float, Sinsol: 
     o.S = 0.5 * sum(o.vt[p] * o.i[p].conjugate() for p in range(P))
     o.S_PCC = 0.5 * sum(o.v[p] * o.i[p].conjugate() for p in range(P))
     o.Vrms = math.sqrt(sum(abs(v) ** 2 for v in o.v) / P) / math.sqrt(2.0)
-    o.Ppv = ppv_calc(m, o.Vdc, Sinsol)
+    o.Ppv = ppv_calc(m, o.Vdc if m.opts.ppv_uses_vdc else m.Vdc_ref0, Sinsol)
     ia_ref = (o.xDC + m.Kp_DC * (Vdc_ref - o.Vdc)) + 1j * (o.xQ - m.Kp_Q * (Q_ref - o.S_PCC.imag))
     o.iref = [ia_ref, ia_ref * A240, ia_ref * A120][:P]
     # SRF-PLL: phasor -> time domain -> Park transform at angle wte (pvder utility_functions)

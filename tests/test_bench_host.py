@@ -22,6 +22,15 @@ def test_launcher_starts_n_ranks_by_itself():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    # ONE N > 1 run carries the three legs -- no collation, the whole block, (reward, done) -- each payload
+    # with its own xGMI fraction (here: gloo on the CPU, the structure of the line)
+    legs = d["payload_legs"]
+    assert set(legs) == {"compute_only", "full", "reward_done"}
+    assert legs["full"]["rows_per_step"] == 13.0 and legs["reward_done"]["rows_per_step"] == 2.0
+    for k in ("full", "reward_done"):
+        x = legs[k]["xgmi_roofline"]
+        assert x["bound"] == "xgmi" and x["bytes_received_per_step_per_gpu"] == 256 * 4 * legs[k]["rows_per_step"] and x["frac"] > 0
+    assert all(v["value"] > 0 for v in legs.values())
 
 
 def test_launcher_propagates_a_failing_rank():

@@ -36,12 +36,17 @@ def _worker(rank, world, port, total, q):
     # k-th step -- collated values carry (row, GLOBAL env id)
     from gym_PVDER_amd.distributed import gather_payload, payload_rows
     for payload, every, want_rows in (("full", 1, [13, 13, 13, 13]), ("reward_done", 1, [2, 2, 2, 2]),
-                                      ("full_every_k", 3, [2, 2, 13, 2]), ("full_every_k", 1, [13, 13, 13, 13])):
+                                      ("full_every_k", 3, [2, 2, 13, 2]), ("full_every_k", 2, [2, 13, 2, 13])):
         for k in range(4):
             gp, r0, nr = gather_payload(out_local, k, payload, every)
             ok = ok and nr == want_rows[k] and (r0, nr) == payload_rows(payload, k, every) and gp.shape == (world, nr, n_local)
             gv = global_view(gp)                                           # [total, nr]
             ok = ok and torch.equal(gv, want[:, r0:r0 + nr])
+    try:                                        # ONE validator on every layer: a period below 2 is rejected, not reinterpreted
+        payload_rows("full_every_k", 0, 1)
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
