@@ -72,7 +72,8 @@ __device__ __forceinline__ void bal_f(const ModelK<float> &P, const PkConst &K, 
     F[1] = bc2(P.KiG) * ua;
     F[2] = bc2(P.wp) * (iar - ia - ua);
     // dVdc = (Ppv - Re S)/(Vdc C), Ppv = max(0, Vdc g(Vdc)), Re S = Vdc PH Pa/4  ->  no division
-    const float g = __builtin_fmaf(-P.pvB, Math<float>::exp_pv(P.pvK * Vdc), S.pv1);
+    float g = __builtin_fmaf(-P.pvB, Math<float>::exp_pv(P.pvK * Vdc), S.pv1);
+    if (P.pvK == 0.f) g = -S.pv1 * Math<float>::rcp(Vdc);      // (model option U5, wave-uniform: pv1 = -Ppv(Vdcmpp0), see ModelK)
     const float dVdc = __builtin_fmaf(-0.25f * PH * P.iC, Pa, P.iC * fmaxf(g, 0.f));
     F[3] = mk2(dVdc, dpi.x);
     F[4] = mk2(dpi.y, P.KiP * vd);

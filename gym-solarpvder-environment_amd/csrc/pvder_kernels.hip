@@ -366,12 +366,7 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
             tfrac = (T)0;
         }
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-#ifdef PVDER_AB_SKIPBCST
-            if (PH == 3 && q >= 6 && q < 18) continue;      // A/B ONLY: what the store burst costs
-#endif
-            st(&fstate[(size_t)q * N + e], y[q]);
-        }
+        for (int q = 0; q < NS; ++q) st(&fstate[(size_t)q * N + e], y[q]);
         st(&fstate[(size_t)NS * N + e], L.qref);
         st(&fstate[(size_t)(NS + 1) * N + e], L.vdcref);
         st(&istate[PVDER_I_KSUB * N + e], (int32_t)L.ksub);
@@ -1116,7 +1111,8 @@ __device__ __forceinline__ float bal_eval(const ModelK<float> &P, const pvder::P
     ns[0] = bc2(P.KiG) * ua;
     // dVdc = (Ppv - Re S)/(Vdc C) with Ppv = max(0, Vdc g(Vdc)), Re S = Vdc PH Pa/4  (Vdc > 0):
     //      = (max(0, g) - PH Pa/4)/C         -- no division
-    const float g = __builtin_fmaf(-P.pvB, Math<float>::exp_pv(P.pvK * Vdc), S.pv1);
+    float g = __builtin_fmaf(-P.pvB, Math<float>::exp_pv(P.pvK * Vdc), S.pv1);
+    if (P.pvK == 0.f) g = -S.pv1 * pvder::Math<float>::rcp(Vdc);       // (model option U5, wave-uniform: see ModelK)
     const float dVdc = __builtin_fmaf(-0.25f * PH * P.iC, Pa, P.iC * fmaxf(g, 0.f));
     ns[1] = dpi;
     ns[2] = mk2(dVdc, P.KiP * vd);
@@ -1793,6 +1789,7 @@ __device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::Lin
     float m2a, ir2a, m2x, m2b, ir2b;
     lin_pairs(Y, yp);
     bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a, alpha);
+    bool fz_dc = F[3].y == 0.f, fz_q = F[4].x == 0.f;        // (alpha = 0: the outward-moving integrators came out as +-0)
     v4f acc3[3][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
     {
         const int m3[3] = {LM21, LM31, LM41};
@@ -1800,6 +1797,7 @@ __device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::Lin
     }
     lin_pairs(acc3[0], yp);
     bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2x, ir2_mid, alpha);
+    fz_dc = fz_dc && F[3].y == 0.f; fz_q = fz_q && F[4].x == 0.f;
     v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
     {
         const int m2[2] = {LM32, LM42};
@@ -1807,8 +1805,20 @@ __device__ __forceinline__ bool lin_etd3rk_aw(const LinArgs &G, const pvder::Lin
     }
     lin_pairs(acc2[0], yp);
     bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2b, ir2b, alpha);
+    fz_dc = fz_dc && F[3].y == 0.f; fz_q = fz_q && F[4].x == 0.f;
     Yn[0] = acc2[1][0]; Yn[1] = acc2[1][1]; Yn[2] = acc2[1][2];
     lin_mfma1(Ac[LM43], F, Yn);
+    // A FROZEN outer integrator stays where it is -- exactly (round 4).  Its derivative is zero at the three stages, but the
+    // f-form matrices are dense functions of hL and L couples the integrators to the currents (d xQ'/d i != 0): what the
+    // currents do inside the step leaks into the "frozen" state at second order -- 1e-5 per env step along the reference's
+    // Q_ref ramps, most of it in the tick behind the action -- and an env stuck behind the current limit stays there for the
+    // rest of its episode: nothing ever pulls that back (x_Q 1.6e-4 off after 16 env steps, fp64 prototype; the converged
+    // bridge holds both integrators to the last bit).  Frozen at all three stages: an integrator whose sign test releases it
+    // inside the step moves, as the model says.  etd_linear.hybrid_step states the same.
+    if (alpha == 0.f) {
+        if (fz_dc) Yn[1].w = Y[1].w;
+        if (fz_q) Yn[2].x = Y[2].x;
+    }
     ir2_end = lin_iref2<PH>(K, S, Yn, qref, vdcref, kpo);
     const float est = fmaxf(fmaxf(fabsf(Yn[0].x - acc2[0][0].x), fabsf(Yn[0].y - acc2[0][0].y)),
                             fabsf(Yn[1].z - acc2[0][1].z));
@@ -1867,7 +1877,19 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
             // the two evaluations that bracket it)
             const float a3 = need3 ? (from_free ? a2 - s2 * (1.f - a2) / (s1 - s2) : a2 * s1 / (s1 - s2)) : a2;
             const bool trip3 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a3, msc, Y2, irm, ire);
-            if (need3) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip3; }
+            if (need3) {
+                // the third evaluation lands NEAR the limit (the secant between two evaluations far apart); sliding means ON
+                // it.  Between two close evaluations the state is all but linear in alpha: one more secant step through
+                // (a2, s2), (a3, s3), taken on the STATES -- no further evaluation (round 4: the converged bridge slides at
+                // |iref| = iref_limit to 1e-8, these steps used to end 1.6e-4 above it, 1.4e-4 in the observations of that
+                // env step; etd_linear.hybrid_step states the same)
+                const float s3 = ire - lim;
+                float w = -s3 / (s3 - s2);
+                w = (s3 != s2 && a3 != a2 && fabsf(w) <= 1.f) ? w : 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) Yn[g] = Y2[g] + w * (Y2[g] - Yn[g]);
+                trip = trip3;
+            }
         }
     }
     return trip;
@@ -1907,6 +1929,10 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
             bal_f<PH, true>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a, -1.f);
             v4f acc[3] = {Y[0], Y[1], Y[2]};
             lin_mfma1(At, F, acc);
+            if (ir2a > P.ilim2) {                  // frozen integrators are HELD over the tick too (see lin_etd3rk_aw):
+                if (F[3].y == 0.f) acc[1].w = Y[1].w;     // the jump kicks the current loop, and h phi1(hL) is dense
+                if (F[4].x == 0.f) acc[2].x = Y[2].x;
+            }
             const bool trip = msc * lin_tick_peak2(P, Y, acc, m2a) > G.Lk.sat2_hard;
             PVDER_DBG_COUNT(4, start && !done && !defer && trip);
             if (start && !done) {
@@ -2084,7 +2110,7 @@ struct LinHead {
     int32_t *istate;
     const uint8_t *action;
     const float *lcoef;
-    int n_env, pad;
+    int n_env, ksub_hint;
 };
 constexpr int kLinHeadBytes = (int)sizeof(LinHead);
 // lin_step_body / the 23-state tail re-read G (and G.A at its start) from the kernel-argument segment at this byte
@@ -2104,7 +2130,8 @@ static_assert(offsetof(LinArgs, A) == 0, "the 23-state tail reads EtdArgs at the
 template <int PH, int KOFF>
 __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
                                               int &cur, const uint8_t *__restrict__ act, int stats_fresh,
-                                              const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env) {
+                                              const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env,
+                                              int ksub_hint) {
     using namespace pvder;
     const EtdArgs &A = G.A;
     constexpr int NS = 6 * PH + 5;
@@ -2112,42 +2139,35 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const 
     typedef __attribute__((address_space(4))) const char *KernargBytes;
     Lane<float> L;
     float ys[NS];
-#ifdef PVDER_AB_SKIPBC
-    // A/B ONLY (not a product build): what the load burst costs -- phases b, c are not read (the balance check is skipped)
-    {
-        L.e = blockIdx.x * kBlock + threadIdx.x;
-        L.live = L.e < n_env;
-        L.ec = L.live ? L.e : n_env - 1;
-        L.ksub = ld(&istate[PVDER_I_KSUB * N + L.ec]);
-        L.steps = ld(&istate[PVDER_I_STEPS * N + L.ec]);
-        L.status = ld(&istate[PVDER_I_STATUS * N + L.ec]);
-        L.run = L.live && L.status == 0;
-        L.fail = false;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) ys[k] = (k < 6 || k >= 6 * PH) ? ld(&fstate[(size_t)k * N + L.ec]) : 0.f;
-        L.qref = ld(&fstate[(size_t)NS * N + L.ec]);
-        L.vdcref = ld(&fstate[(size_t)(NS + 1) * N + L.ec]);
-        const int a = ld(&act[L.ec]);
-        L.bad_action = 0.f;
-        if (a == 1) L.qref += A.C.dq;
-        else if (a == 2) L.qref -= A.C.dq;
-        else if (a == 3) L.vdcref += A.C.dv;
-        else if (a == 4) L.vdcref -= A.C.dv;
-        else if (a != 0) L.bad_action = 1.f;
+    // ---- the event inputs, SPECULATIVELY.  What a step reads from the event tables depends on the env's clock
+    // (ksub -> event row): a dependent fetch behind the state rows, one more memory round trip (0.6-0.8 us with 1024 waves
+    // asking at once) before the first flop.  The caller tells where the envs of the batch ARE (ksub_hint: a kernel
+    // argument, there with the wave; pvder_plan_hint -- envs stepped in lockstep since a common reset, the benchmark and
+    // every vectorised training loop), the rows that clock names are requested with the state rows, and a lane whose own
+    // clock says otherwise (an env reset on its own) falls back to the dependent fetch -- with its whole wave, same values:
+    // a wrong or missing hint (-1) costs time, never a result.
+    const int ec0 = min((int)(blockIdx.x * kBlock + threadIdx.x), n_env - 1);
+    LinSeg sg;
+    float vg_stop = 0.f, si_stop = 0.f;
+    const bool hinted = ksub_hint >= 0;
+    if (hinted) {
+        sg = lin_first_segment(A.C, G.Lk, ksub_hint, A.ev_vg, A.ev_si, N, ec0);
+        int row_stop = sg.row;                 // (the inputs in force at tStop: see lin_step_body)
+        if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
+        else if (sg.until < A.C.n_sub) row_stop = event_row(ksub_hint + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
+        vg_stop = A.ev_vg[(size_t)row_stop * N + ec0]; si_stop = A.ev_si[(size_t)row_stop * N + ec0];
     }
-#else
     prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
-#endif
-    const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
-    int row_stop = sg.row;                     // (the inputs in force at tStop: see lin_step_body)
-    if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
-    else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
-    const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
+    if (__builtin_amdgcn_readfirstlane(__any((int)(!hinted || (L.run && L.ksub != ksub_hint))))) {
+        sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
+        int row_stop = sg.row;
+        if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
+        else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
+        vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec]; si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
+    }
     PVDER_TRACE_AT(1);
     bool leave = PH == 3 && A.force_full != 0;
-#ifndef PVDER_AB_SKIPBC
     if constexpr (PH == 3) leave |= lin_unbalanced(ys);
-#endif
     leave = leave && L.run;
     {
         v4f Y[3];
@@ -2174,9 +2194,8 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const 
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
-                                                             const float *lcoef, int n_env, int pad, const LinArgs G) {
+                                                             const float *lcoef, int n_env, int ksub_hint, const LinArgs G) {
     using namespace pvder;
-    (void)pad;
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
     // first ETD3RK set stay in registers for the whole launch; another set replaces the latter only when
@@ -2193,7 +2212,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
 #ifdef PVDER_NO_LEAN
     lin_step_body<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, 0, G.A.stats_fresh, fstate, istate, n_env);
 #else
-    const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, G.A.stats_fresh, fstate, istate, n_env);
+    const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
     if (__syncthreads_or((int)leave)) {
         // (rare: every argument again through a laundered copy of the kernarg pointer -- nothing of this pass stays
         // live across the lean one)
@@ -2963,6 +2982,14 @@ ModelK<T> fold_params(const double *par, bool exp2_path) {
     P.vrms_ref = (T)par[PVDER_PAR_VRMS_REF];
     P.vdc_ref0 = (T)par[PVDER_PAR_VDC_REF0];
     P.sinsol0 = (T)par[PVDER_PAR_SINSOL0];
+    if (par[PVDER_PAR_PPV_AT_MPP] != 0.0) {
+        // model option U5: the array's power at the MPP voltage -- folded into (pvA, pvB, pvK), see ModelK
+        const double v0 = par[PVDER_PAR_VDC_REF0], e0 = exp(par[PVDER_PAR_PV_VT] * v0);
+        const double a = par[PVDER_PAR_NP] * par[PVDER_PAR_ISCR] * scale / 100.0, b = par[PVDER_PAR_NP] * par[PVDER_PAR_IRS] * scale;
+        P.pvA = (T)(-v0 * a);
+        P.pvB = (T)(-v0 * b * (1.0 - e0));
+        P.pvK = (T)0;
+    }
     return P;
 }
 
@@ -3238,6 +3265,9 @@ struct pvder_plan {
     StepK<double> Cd;
     Lin64K l64;                      // etdlin64
     ResetK R;
+    mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
+                                     // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
+    int n_sub;
 };
 
 namespace {
@@ -3252,6 +3282,8 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     p.n_env = n_env;
     p.episode_steps = (cfg->max_ksub + cfg->n_sub - 1) / cfg->n_sub;
     if (cfg->max_steps > 0 && cfg->max_steps < p.episode_steps) p.episode_steps = cfg->max_steps;
+    p.ksub_hint = -1;
+    p.n_sub = cfg->n_sub;
     rc = fold_reset(par, cfg, ar, p.R);
     if (rc) return rc;
     if (integrator == PVDER_INT_RK45 || integrator == PVDER_INT_ETDLIN64) {
@@ -3314,6 +3346,15 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     return 0;
 }
 
+// the hint `steps` env steps later: envs in lockstep finish together -- and restart together (same-step auto-reset)
+void advance_hint(const pvder_plan &p, int steps) {
+    if (p.ksub_hint < 0 || p.n_sub <= 0 || p.episode_steps <= 0) return;
+    long long k = (long long)(p.ksub_hint / p.n_sub) + steps;
+    if (p.R.enabled) k %= p.episode_steps;
+    else if (k > p.episode_steps) k = p.episode_steps;        // (finished, not running: whatever)
+    p.ksub_hint = (int)k * p.n_sub;
+}
+
 int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action,
                 void *out, double *hstep, float *stats, int zero_stats, void *stream, const void *out_prev = nullptr) {
     if (!fstate || !istate || !ev_vg || !ev_si || !action || !out) return PVDER_EINVAL;
@@ -3339,9 +3380,10 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         // (none in PVDER-v0 rollouts).
         if (p.integrator == PVDER_INT_ETDLIN) {
             if (p.ph == 3)
-                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, 0, G);
+                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, p.ksub_hint, G);
             else
-                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, 0, G);
+                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, p.ksub_hint, G);
+            advance_hint(p, 1);
         } else {
             if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
@@ -3472,6 +3514,12 @@ int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, cons
 
 void pvder_plan_destroy(pvder_plan *plan) { delete plan; }
 
+int pvder_plan_hint(pvder_plan *plan, int ksub) {
+    if (!plan) return -1;
+    if (ksub >= -1) plan->ksub_hint = ksub;
+    return plan->ksub_hint;
+}
+
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream) {
     if (!plan) return PVDER_EINVAL;
@@ -3525,6 +3573,7 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
         hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
         hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
     }
+    advance_hint(*plan, n_steps);
     return hip_rc(hipGetLastError());
 }
 
@@ -3566,6 +3615,7 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
         hipLaunchKernelGGL(step_etdlin_rollout_agent_kernel<3>, grid, block, 0, st, Q);
         hipLaunchKernelGGL((step_etdlin_finish_kernel<3, true>), grid, block, 0, st, Q);
     }
+    advance_hint(*plan, n_steps);
     return hip_rc(hipGetLastError());
 }
 

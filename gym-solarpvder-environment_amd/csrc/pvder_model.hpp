@@ -30,6 +30,10 @@ struct ModelK {
     T pvA;                    // Np*Iscr*Vdcbase/(100*Sbase): Iph term = pvA*Sinsol*Vdc
     T pvB;                    // Np*Irs*Vdcbase/Sbase
     T pvK;                    // q*Vdcbase/(k T A Ns)  [* log2(e) for the fp32 exp2 path]
+                              // MODEL OPTION U5 (Ppv at the MPP voltage Vdcmpp0, PVDER_PAR_PPV_AT_MPP) is folded into these three
+                              // on the host -- no further field, no further register: pvK = 0 flags it, and with
+                              // pvA = -vdc0 pvA, pvB = -vdc0 pvB (1 - exp(pvK vdc0))  make_sub's  pv1 = pvA*Sinsol + pvB  IS
+                              // -Ppv(Vdcmpp0, Sinsol), a constant per insolation level (ppv_of)
     T vrms_ref, vdc_ref0, sinsol0;
 };
 
@@ -81,7 +85,10 @@ template <typename T>
 __device__ __forceinline__ T ppv_of(const ModelK<T> &P, T pv1, T Vdc) {
 #pragma clang fp contract(off)       // (reported as an observation: see outputs())
     const T e = Math<T>::exp_pv(P.pvK * Vdc);
-    const T p = Vdc * (pv1 - P.pvB * e);
+    T p = Vdc * (pv1 - P.pvB * e);
+    // model option U5 (wave-uniform, pvK == 0: see ModelK): pv1 = -Ppv(Vdcmpp0, Sinsol).  A select on a kernel argument that
+    // is live here anyway -- the 23-state tail that calls this sits at the register limit
+    p = P.pvK == (T)0 ? -pv1 : p;
     return p > (T)0 ? p : (T)0;
 }
 

@@ -159,8 +159,11 @@ class BatchedQAgent:
         end early simply stop learning (``alive``).  Exploration draws come from the counter generator of the
         event tables, keyed (seed, global env id, step count): runs are reproducible.
         ``closed_loop=True``: the whole episode -- every env step AND the agent step between two of them -- in a
-        handful of launches (``closed_loop_episode``); the same table wherever the two-launch sequence is itself
-        deterministic (envs that do not race for the same table entries)."""
+        handful of launches (``closed_loop_episode``).  That form is ASYNCHRONOUS Q-learning across workgroups
+        (Hogwild-style: workgroups run through their env steps independently inside a launch, table updates of other
+        workgroups are seen late -- within the launch at the latest -- or lose a read-modify-write race; see
+        include/pvder_agent.h): bit-identical to the two-launch loop for batches of at most one workgroup's envs in
+        lockstep, statistically equivalent beyond (returns, visited entries)."""
         env = self.env
         assert not env.auto_reset, "construct the PVDERVec with auto_reset=False: episodes are reset here"
         assert env.fdtype == torch.float32, "the agent step reads the fp32 output block"

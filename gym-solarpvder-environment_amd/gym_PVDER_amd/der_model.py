@@ -52,7 +52,13 @@ WTE0 = 2.0 * math.pi
 # index names of the parameter vector -- MUST match include/pvder_hip.h `enum pvder_par`
 PAR = ["PHASES", "RF", "LF", "C", "KVG_RE", "KVG_IM", "KVI_RE", "KVI_IM", "KP_GCC", "KI_GCC",
        "KP_DC", "KI_DC", "KP_Q", "KI_Q", "WP", "KP_PLL", "KI_PLL", "M_LIMIT", "IREF_LIMIT", "WBASE",
-       "VG_SCALE", "VDCBASE", "SBASE", "NP", "ISCR", "IRS", "PV_VT", "VRMS_REF", "VDC_REF0", "SINSOL0"]
+       "VG_SCALE", "VDCBASE", "SBASE", "NP", "ISCR", "IRS", "PV_VT", "VRMS_REF", "VDC_REF0", "SINSOL0", "PPV_AT_MPP"]
+# model options: the questions about the pvder model that /root/reference cannot answer and that DO move the observations
+# (measured: profiles/r04_oracle_uncertainty.txt).  U5 "ppv_at_mpp": the PV array's power at the MPP
+# voltage Vdcmpp0 instead of the instantaneous DC-link voltage (1e-4 ... 7e-4 in the observations).  U1 (winv = grid
+# frequency) moves them by < 3e-6 and U7 (ratio Vgridrated / Vbase) has no steady state inside the duty-cycle limit: neither is
+# a switch of the device model.
+MODEL_OPTIONS = ("ppv_at_mpp",)
 IDX = {k: i for i, k in enumerate(PAR)}
 
 
@@ -72,8 +78,12 @@ def der_config(der_id: str = "50", overrides: Optional[Dict[str, float]] = None)
     return c
 
 
-def param_vector(der_id: str = "50", overrides: Optional[Dict[str, float]] = None) -> np.ndarray:
-    """Per-unit constants of one DER as the C ABI's ``double par[PVDER_PAR_COUNT]``."""
+def param_vector(der_id: str = "50", overrides: Optional[Dict[str, float]] = None,
+                 options: Optional[Dict[str, bool]] = None) -> np.ndarray:
+    """Per-unit constants of one DER as the C ABI's ``double par[PVDER_PAR_COUNT]``; ``options``: MODEL_OPTIONS."""
+    for k in (options or {}):
+        if k not in MODEL_OPTIONS:
+            raise ValueError("unknown model option %r (available: %s)" % (k, MODEL_OPTIONS))
     c = der_config(der_id, overrides)
     ph = int(c["phases"])
     a = VGRIDRATED / (c["Vrmsrated"] * math.sqrt(2.0))          # transformer turns ratio
@@ -92,7 +102,8 @@ def param_vector(der_id: str = "50", overrides: Optional[Dict[str, float]] = Non
              M_LIMIT=M_LIMIT, IREF_LIMIT=irated / IBASE * c["Ioverload"], WBASE=WBASE,
              VG_SCALE=VGRIDRATED / VBASE, VDCBASE=VDCBASE, SBASE=SBASE, NP=c["Np"], ISCR=ISCR, IRS=IRS,
              PV_VT=Q_E * VDCBASE / (K_B * T_CELL * A_IDEAL * c["Ns"]),
-             VRMS_REF=c["Vrmsrated"] / VBASE, VDC_REF0=c["Vdcmpp0"] / VDCBASE, SINSOL0=c["Sinsol"])
+             VRMS_REF=c["Vrmsrated"] / VBASE, VDC_REF0=c["Vdcmpp0"] / VDCBASE, SINSOL0=c["Sinsol"],
+             PPV_AT_MPP=1.0 if (options or {}).get("ppv_at_mpp") else 0.0)
     return np.array([float(v[k]) for k in PAR], dtype=np.float64)
 
 

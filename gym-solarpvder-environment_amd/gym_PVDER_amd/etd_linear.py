@@ -51,7 +51,8 @@ def folded(par: np.ndarray) -> Dict[str, float]:
                 kviR=P["KVI_RE"], kviI=P["KVI_IM"], GR=P["KVG_RE"] * P["VG_SCALE"], GI=P["KVG_IM"] * P["VG_SCALE"],
                 KpG=P["KP_GCC"], KiG=P["KI_GCC"], KpDC=P["KP_DC"], KiDC=P["KI_DC"], KpQ=P["KP_Q"], KiQ=P["KI_Q"],
                 wp=P["WP"], KpP=P["KP_PLL"], KiP=P["KI_PLL"], iwb=1.0 / P["WBASE"],
-                pvA=P["NP"] * P["ISCR"] * scale / 100.0, pvB=P["NP"] * P["IRS"] * scale, pvK=P["PV_VT"])
+                pvA=P["NP"] * P["ISCR"] * scale / 100.0, pvB=P["NP"] * P["IRS"] * scale, pvK=P["PV_VT"],
+                vdc0=P["VDC_REF0"], ppv_fixed=bool(P.get("PPV_AT_MPP", 0.0)))
 
 
 def f_bal(c: Dict[str, float], y, vg, sinsol, qref, vdcref):
@@ -77,7 +78,8 @@ def f_bal(c: Dict[str, float], y, vg, sinsol, qref, vdcref):
     d_iR = c["iLf"] * (mR * hV - vR - c["Rf"] * iR) + wr * iI
     d_iI = c["iLf"] * (mI * hV - vI - c["Rf"] * iI) - wr * iR
     pv1 = c["pvA"] * sinsol + c["pvB"]
-    ppv = np.maximum(Vdc * (pv1 - c["pvB"] * np.exp(c["pvK"] * Vdc)), 0.0)
+    vp = Vdc if not c.get("ppv_fixed") else c["vdc0"] + 0.0 * Vdc          # (model option U5: Ppv at the MPP voltage)
+    ppv = np.maximum(vp * (pv1 - c["pvB"] * np.exp(c["pvK"] * vp)), 0.0)
     dVdc = (ppv - 0.5 * hV * Pt) / Vdc * c["iC"]
     return np.stack([d_iR, d_iI, c["KiG"] * uR, c["KiG"] * uI,
                      c["wp"] * (rR - iR - uR), c["wp"] * (rI - iI - uI),
@@ -489,6 +491,23 @@ def cross_fraction(s0: float, sm: float, s1: float) -> float:
     return min(1.0, max(0.0, t))
 
 
+HOLD_FROZEN = True       # (tools: False reproduces round 3's steps)
+SLIDE_POLISH = True
+
+
+def careful_tick(c, P1: np.ndarray, y, inputs, ilim2: float):
+    """The tick of the careful pass (exponential Euler behind the input jump, the outer integrators frozen or free by the
+    side of the limit the env starts on) -- with a frozen integrator HELD: the jump kicks the current loop, P1 = h phi1(hL)
+    is dense, and what the currents do inside the tick would otherwise leak into the frozen state (1e-5 per env step)."""
+    f = f_bal_limited(c, y, inputs, -1.0, ilim2)
+    yn = y + P1 @ f
+    if HOLD_FROZEN and iref2(c, y, inputs[0], inputs[2], inputs[3]) > ilim2:
+        for k in (7, 8):
+            if f[k] == 0.0:
+                yn[k] = y[k]
+    return yn
+
+
 def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
     """One hybrid ETD3RK step of an env at the current limit (DESIGN.md "careful pass"): the same step up to three
     times -- free / frozen; with the crossing of |iref| = iref_limit located inside the step; sliding along it.
@@ -500,6 +519,16 @@ def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
         F2 = f_bal_limited(c, a, inputs, alpha, ilim2); b = y + M31 @ F1 + M32 @ F2
         F3 = f_bal_limited(c, b, inputs, alpha, ilim2)
         yn = y + M41 @ F1 + M42 @ F2 + M43 @ F3
+        if alpha == 0.0 and HOLD_FROZEN:
+            # a FROZEN outer integrator stays where it is -- exactly.  Its derivative is zeroed at the three stages, but the
+            # f-form matrices are dense functions of hL and L couples the integrators to the currents (d xQ'/d i != 0): what
+            # the currents do inside the step leaks into the "frozen" state at second order, 1e-5 per env step along the
+            # reference's Q_ref ramps -- and an env stuck behind the limit stays there for the rest of its episode, nothing
+            # ever pulls that back.  (Frozen at all three stages: an integrator whose sign test releases it inside the
+            # step moves, as the model says.)
+            for k in (7, 8):
+                if F1[k] == 0.0 and F2[k] == 0.0 and F3[k] == 0.0:
+                    yn[k] = y[k]
         s = lambda u: iref2(c, u, inputs[0], inputs[2], inputs[3]) - ilim2
         return yn, s(a), s(yn)
 
@@ -515,7 +544,16 @@ def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
     if (s2 < 0) != free or s2 == 0:
         return y2, 2
     a3 = a2 - s2 * (1.0 - a2) / (s1 - s2) if free else a2 * s1 / (s1 - s2)
-    return step(a3)[0], 3
+    y3, _, s3 = step(a3)
+    if SLIDE_POLISH and s3 != s2 and a3 != a2:
+        # the third evaluation lands NEAR the limit (s3 ~ 1e-4 of |iref|^2: the secant between two evaluations far apart);
+        # sliding means ON it.  The state is all but linear in alpha between two close evaluations: one more secant step
+        # through (a2, s2), (a3, s3), taken on the STATES -- no further evaluation (round 4; the converged bridge slides at
+        # |iref| = iref_limit to 1e-8, these steps used to end 1.6e-4 above it: 1.4e-4 in the observations)
+        w = -s3 / (s3 - s2)                       # (alpha* - a3) / (a3 - a2)
+        if abs(w) <= 1.0:
+            y3 = y3 + w * (y3 - y2)
+    return y3, 3
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ import copy
 import ctypes as C
 import logging
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -159,7 +160,8 @@ class PVDERVec(EnvSpecMixin):
                  graded: bool = True,
                  model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
-                 events_spec: Optional[dict] = None, der_config: Optional[dict] = None, off_range: str = "integrate"):
+                 events_spec: Optional[dict] = None, der_config: Optional[dict] = None, off_range: str = "integrate",
+                 model_options: Optional[dict] = None):
         """``der_config``: overrides of the model's config block (keys of config_der.json's derId entry, e.g.
         ``{"C_actual": 330e-6, "Kp_DC": -2.2}``) -- ONE parameter set per PVDERVec (the steady state, the
         Jacobian of the etdlin path and the coefficient tables are derived from it); for a batch spread over
@@ -215,7 +217,11 @@ class PVDERVec(EnvSpecMixin):
         self.env_events_spec = copy.deepcopy(events_spec) if events_spec else default_events_spec()
         self.der_id = self.env_model_spec[model_type]['derId']
         self.der_config = dict(der_config) if der_config else None
-        self.par = der_model.param_vector(self.der_id, self.der_config)
+        # ``model_options``: der_model.MODEL_OPTIONS -- the resolutions of questions about the (absent) pvder model that the
+        # reference cannot decide and that move the observations: {"ppv_at_mpp": True} evaluates the PV array's power at the
+        # MPP voltage instead of the instantaneous DC-link voltage
+        self.model_options = dict(model_options) if model_options else None
+        self.par = der_model.param_vector(self.der_id, self.der_config, self.model_options)
         self.phases = int(self.par[0])
         self.ns = 6 * self.phases + 5
         self.y0 = der_model.steady_state(self.par, self.der_id)
@@ -242,6 +248,7 @@ class PVDERVec(EnvSpecMixin):
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
         self._needs_reset = True
         self._plan = None
+        self._ksub_hint = -1         # pvder_plan_hint: the clock the batch's envs are at (survives plan rebuilds; -1 = unknown)
 
     def __del__(self):
         try:
@@ -274,6 +281,7 @@ class PVDERVec(EnvSpecMixin):
         p = self.__dict__.get("_plan")
         object.__setattr__(self, "_plan", None)
         if p is not None:
+            object.__setattr__(self, "_ksub_hint", int(self._lib.pvder_plan_hint(p, -2)))     # (the plan advanced it step by step)
             self._lib.pvder_plan_destroy(p)
 
     _debug_knob = 0          # pvder_step_cfg.reserved (tests only)
@@ -461,7 +469,7 @@ class PVDERVec(EnvSpecMixin):
         schedule changes."""
         lens = etd_linear.choose_sets(cfg.n_sub, cfg.micro, cfg.ev_s0, cfg.ev_ds, cfg.ev_count, cfg.max_ksub,
                                       _native.LIN_MAX_SETS)
-        key = (self.der_id if not self.der_config else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, tuple(lens))
+        key = (self.der_id if not (self.der_config or self.model_options) else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, tuple(lens))
         if getattr(self, "_lin_key", None) != key:
             host = PVDERVec._lin_cache.get(key[:2] + key[3:])
             if host is None:
@@ -481,7 +489,9 @@ class PVDERVec(EnvSpecMixin):
             lc.len_ticks[k] = int(math.ceil(t))      # (informational: the careful pass's set may end on a fraction of a tick)
         lc.est_guard = self.est_guard
         if self.phases == 3:
-            E = etd_linear.seq_propagator(self.par, self.der_id, cfg.n_sub)
+            if getattr(self, "_seq_key", None) != key[:3]:       # (a steady state + an eig: cached with the coefficient block)
+                self._seq_E, self._seq_key = etd_linear.seq_propagator(self.par, self.der_id, cfg.n_sub), key[:3]
+            E = self._seq_E
             for r in range(3):
                 for k in range(3):
                     lc.seq_prop[6 * r + 2 * k], lc.seq_prop[6 * r + 2 * k + 1] = float(E[r, k].real), float(E[r, k].imag)
@@ -492,7 +502,7 @@ class PVDERVec(EnvSpecMixin):
     def _lin64_coef(self, cfg) -> _native.LinCoef:
         """``struct pvder_lin_coef`` of the etdlin64 path: the fp64 f-form matrices of the tick and of the dyadic menu
         (etd_linear.pack_block64) on the device."""
-        key = (self.der_id if not self.der_config else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, "f64")
+        key = (self.der_id if not (self.der_config or self.model_options) else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, "f64")
         if getattr(self, "_lin64_key", None) != key:
             host = PVDERVec._lin_cache.get(key)
             if host is None:
@@ -507,8 +517,17 @@ class PVDERVec(EnvSpecMixin):
         lc.sched, lc.n_sched_rows, lc.est_guard = None, 0, 1.0
         return lc
 
+    def _plan_fingerprint(self) -> str:
+        """What a plan folds in that can be edited IN PLACE behind the env's back (the spec dicts; attribute assignments drop
+        the plan at once): reset() / load_state_dict() rebuild the plan only when this changes (~0.6 ms of host work saved
+        per episode of a training loop -- as much as a 160-step fused episode takes on the GPU)."""
+        g = self._goals_list[0]
+        return repr((self.env_events_spec, self.env_reward_spec.get('reference_values'), self.env_goal_spec[g]['reward'],
+                     self.est_guard, self._debug_knob))
+
     def _make_plan(self):
         """Fold cfg / reset block / coefficients into a C-side plan (include/pvder_hip.h "plans")."""
+        object.__setattr__(self, "_plan_fp", self._plan_fingerprint())
         cfg, ar = self._cfg(), self._autoreset(self.auto_reset)
         integrator = self.integrator
         coef = self._etd_coef(cfg).data_ptr() if integrator in ("etdrk4", "etdlin") else None
@@ -529,6 +548,7 @@ class PVDERVec(EnvSpecMixin):
                 _native.check(self._lib.pvder_plan_create(C.byref(h), _native.INTEGRATOR_IDS["etdlin64"], self._par_c,
                                                           C.byref(cfg), C.byref(ar), None, lin, self.num_envs), "pvder_plan_create")
                 self._plan_integrator, self._plan = "etdlin64", h
+                self._lib.pvder_plan_hint(h, self.__dict__.get("_ksub_hint", -1))
                 return h
             except ValueError as e:
                 # (single phase, or an event grid that cuts env steps: one segment per env step is what the kernel takes)
@@ -540,6 +560,9 @@ class PVDERVec(EnvSpecMixin):
                                                   C.byref(cfg), C.byref(ar), coef, lin, self.num_envs),
                       "pvder_plan_create")
         self._plan = h
+        # where the batch's envs are (a prefetch hint for the step launch, include/pvder_hip.h): kept across plan rebuilds
+        # (PVDER_NO_HINT=1: A/B runs without it)
+        self._lib.pvder_plan_hint(h, -1 if os.environ.get("PVDER_NO_HINT") else self.__dict__.get("_ksub_hint", -1))
         return h
 
     def _device_ctx(self):
@@ -577,12 +600,19 @@ class PVDERVec(EnvSpecMixin):
                 mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
                 assert mask.shape == (self.num_envs,)
             self._reset_launch(mask)
-            # the plan is folded anew at every reset (cheap, never inside a graph capture): specs edited in place
+            # the plan is checked at every reset (never inside a graph capture): specs edited in place
             # (env_events_spec[...]['ENABLE'], env_reward_spec['reference_values'], my_spec lists) take effect here at
-            # the latest -- attribute assignments and update_env_events / set_reward_spec drop the plan at once.
+            # the latest -- attribute assignments and update_env_events / set_reward_spec drop the plan at once -- and it
+            # is folded anew only if one of them changed (_plan_fingerprint).
             # Coefficient uploads happen now too: step() must stay capturable into a HIP graph
-            self._drop_plan()
-            self._make_plan()
+            if self._plan is None or self.__dict__.get("_plan_fp") != self._plan_fingerprint():
+                self._drop_plan()
+                if mask is None:
+                    self._ksub_hint = 0      # every env starts its episode here (a masked reset leaves the others' clock the hint)
+                self._make_plan()
+            elif mask is None:
+                self._ksub_hint = 0
+                self._lib.pvder_plan_hint(self._plan, -1 if os.environ.get("PVDER_NO_HINT") else 0)
             if self.hstep is not None:
                 if mask is None:
                     self.hstep.zero_()
@@ -712,8 +742,14 @@ class PVDERVec(EnvSpecMixin):
             self.hstep.copy_(d["hstep"])
         self._needs_reset = False
         with self._device_ctx():
-            self._drop_plan()
-            self._make_plan()
+            hint = int(self.istate[0, 0].item())                 # (PVDER_I_KSUB of env 0: where a batch in lockstep is)
+            if self._plan is None or self.__dict__.get("_plan_fp") != self._plan_fingerprint():
+                self._drop_plan()
+                self._ksub_hint = hint
+                self._make_plan()
+            else:
+                self._ksub_hint = hint
+                self._lib.pvder_plan_hint(self._plan, -1 if os.environ.get("PVDER_NO_HINT") else hint)
 
     # -- per-launch timing of the step kernel (bench.py roofline) ------------------------------------
     _timing = False

@@ -55,9 +55,19 @@ int pvder_qagent_step_f32(const pvder_qagent_cfg *cfg, float *q_table, const flo
  * pvder_plan_rollout_fused, `out` ONE [13][n_env] block (every step overwrites it: the agent consumes it on the chip).
  * `action` holds, on entry, the action chosen behind the reset (a pvder_qagent_step_f32 call with cfg->first = 1);
  * on return state / action / alive / ep_reward are what n_steps two-launch steps would have left.  cfg: first = 0,
- * choose = 1; cfg->counter keys the agent call behind env step 0, + k behind step k.  Results equal those of the
- * two-launch sequence wherever that sequence is deterministic (envs that do not race for the same table entries;
- * the envs of one wave always). */
+ * choose = 1; cfg->counter keys the agent call behind env step 0, + k behind step k.
+ * CONCURRENCY: this is ASYNCHRONOUS (Hogwild-style) Q-learning across workgroups.  The two-launch loop puts a kernel
+ * boundary behind every agent step: what env A writes to a table entry at step k, env B reads at step k + 1.  Inside a fused
+ * launch only the waves of ONE workgroup advance in step (workgroup votes); workgroups run through their env steps
+ * independently, so an agent step k of one workgroup interleaves with steps k +- m of another on the shared table, the table
+ * is read with plain loads through per-CU caches that are not coherent within a launch (another workgroup's update may be
+ * seen late -- at the latest in the next launch, i.e. after at most n_steps steps -- or lost to a read-modify-write race),
+ * and which of several simultaneous updates of one entry wins differs from the two-launch order.  Results therefore equal
+ * the two-launch sequence bit for bit only where no two workgroups touch the same entry (always: a batch of <= one
+ * workgroup with the envs of a wave in lockstep -- tests at 1, 8, 64 envs); for larger batches they agree STATISTICALLY
+ * (returns, visited entries, values of often-visited entries: tests/test_gpu_golden.py::
+ * test_closed_loop_fused_training_statistics_at_many_workgroups).  Callers that need the two-launch semantics exactly use
+ * pvder_plan_step + pvder_qagent_step_f32. */
 struct pvder_plan;
 int pvder_plan_rollout_fused_agent(const struct pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                                    int n_steps, float *out, float *stats, int32_t *progress, const pvder_qagent_cfg *cfg,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 11
+#define PVDER_ABI_VERSION 12
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -45,6 +45,9 @@ enum pvder_par {
     PVDER_PAR_VRMS_REF,   /* Vrmsrated/Vbase (reward, PVDER_env.py:280) */
     PVDER_PAR_VDC_REF0,   /* Vdcmpp0/Vdcbase: Vdc_ref after reset */
     PVDER_PAR_SINSOL0,    /* insolation before the first solar event */
+    PVDER_PAR_PPV_AT_MPP, /* model option (/root/reference cannot decide it): 0 (default) = the PV
+                             array's power at the INSTANTANEOUS DC-link voltage, != 0 = at the MPP voltage Vdcmpp0 (a constant
+                             per insolation level).  Moves the observations by 1e-4 ... 7e-4 (profiles/r04_oracle_uncertainty.txt) */
     PVDER_PAR_COUNT
 };
 
@@ -300,6 +303,14 @@ typedef struct pvder_plan pvder_plan;
 int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, const pvder_step_cfg *cfg,
                       const pvder_autoreset *ar, const float *coef, const pvder_lin_coef *lin, int n_env);
 void pvder_plan_destroy(pvder_plan *plan);
+/* Where the envs of the batch ARE (etdlin plans): `ksub` = the sim-time-step counter (row PVDER_I_KSUB) most envs hold when
+ * the NEXT step starts -- 0 behind a reset of the whole batch (PVDER.reset, PVDER_env.py:316-334), -1 = unknown (the state of
+ * a new plan), -2 = query only.  Returns the hint in force.  The plan advances it by itself with every step it enqueues
+ * (n_sub per step, back to 0 where a batch with same-step auto-reset ends its episode).  The step launch requests the event
+ * rows that clock names together with the state rows instead of behind them (one memory round trip less before the first
+ * flop); an env whose own counter says otherwise takes the dependent fetch as before.  A prefetch hint: a wrong or missing
+ * one costs time, never a result. */
+int pvder_plan_hint(pvder_plan *plan, int ksub);
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream);
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,

@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "_build", "libpvder_bridge.so")
 
 PAR_NAMES = ["PHASES", "RF", "LF", "C", "KVG_RE", "KVG_IM", "KVI_RE", "KVI_IM", "KP_GCC", "KI_GCC",
              "KP_DC", "KI_DC", "KP_Q", "KI_Q", "WP", "KP_PLL", "KI_PLL", "M_LIMIT", "IREF_LIMIT",
-             "WBASE", "VG_SCALE", "VDCBASE", "SBASE", "NP", "ISCR", "IRS", "PV_VT"]
+             "WBASE", "VG_SCALE", "VDCBASE", "SBASE", "NP", "ISCR", "IRS", "PV_VT", "VDC_REF0", "PPV_AT_MPP"]
 
 _lib = None
 
@@ -47,7 +47,7 @@ def pack_params(m: pm.DERModel) -> np.ndarray:
              KP_DC=m.Kp_DC, KI_DC=m.Ki_DC, KP_Q=m.Kp_Q, KI_Q=m.Ki_Q, WP=m.wp, KP_PLL=m.Kp_PLL,
              KI_PLL=m.Ki_PLL, M_LIMIT=m.m_limit, IREF_LIMIT=m.iref_limit, WBASE=pm.WBASE,
              VG_SCALE=m.vg_scale, VDCBASE=pm.VDCBASE, SBASE=pm.SBASE, NP=m.Np, ISCR=pm.ISCR,
-             IRS=pm.IRS, PV_VT=m.pv_vt)
+             IRS=pm.IRS, PV_VT=m.pv_vt, VDC_REF0=m.Vdc_ref0, PPV_AT_MPP=0.0 if m.opts.ppv_uses_vdc else 1.0)
     return np.array([float(v[k]) for k in PAR_NAMES], dtype=np.float64)
 
 

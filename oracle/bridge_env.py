@@ -22,9 +22,9 @@ class BridgeVecEnv:
     def __init__(self, num_envs: int, n: int = 15, max_sim_time: float = 40.0, discrete: bool = True,
                  goal: str = "voltage_regulation", der_id: str = "50", method: str = "rk4",
                  micro: int = 4096, dtype=np.float64, kahan: bool = False, rtol: float = 1e-8,
-                 atol: float = 1e-10, overrides=None):
+                 atol: float = 1e-10, overrides=None, opts=None):
         self.N, self.n = num_envs, int(n)
-        self.model = pm.build_model(der_id, overrides=overrides)
+        self.model = pm.build_model(der_id, opts, overrides=overrides)
         self.dq = DEL_QREF * self.n / pm.SBASE
         self.dv = DEL_VDCREF * self.n / pm.VDCBASE
         cap = MAX_EPISODE_STEPS * self.n * SIM_TIME_STEP

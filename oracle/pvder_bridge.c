@@ -16,7 +16,7 @@ enum {
     PAR_PHASES = 0, PAR_RF, PAR_LF, PAR_C, PAR_KVG_RE, PAR_KVG_IM, PAR_KVI_RE, PAR_KVI_IM,
     PAR_KP_GCC, PAR_KI_GCC, PAR_KP_DC, PAR_KI_DC, PAR_KP_Q, PAR_KI_Q, PAR_WP, PAR_KP_PLL,
     PAR_KI_PLL, PAR_M_LIMIT, PAR_IREF_LIMIT, PAR_WBASE, PAR_VG_SCALE, PAR_VDCBASE, PAR_SBASE,
-    PAR_NP, PAR_ISCR, PAR_IRS, PAR_PV_VT, PAR_COUNT
+    PAR_NP, PAR_ISCR, PAR_IRS, PAR_PV_VT, PAR_VDC_REF0, PAR_PPV_AT_MPP, PAR_COUNT
 };
 #define NSMAX 23
 

@@ -56,10 +56,12 @@ static void FN(rhs)(const double *par, const REAL *y, REAL th2, REAL vgm, REAL s
     S *= (REAL)0.5;
     Sp *= (REAL)0.5;
     /* PV array */
-    const REAL Vact = Vdc * (REAL)par[PAR_VDCBASE];
+    /* model option U5 (oracle/pvder_model.py::ModelOptions.ppv_uses_vdc = False): Ppv at the MPP voltage */
+    const REAL Vpv = par[PAR_PPV_AT_MPP] != 0.0 ? (REAL)par[PAR_VDC_REF0] : Vdc;
+    const REAL Vact = Vpv * (REAL)par[PAR_VDCBASE];
     const REAL Iph = (REAL)par[PAR_ISCR] * (sinsol / 100);
     REAL ppv = (REAL)par[PAR_NP] * Iph * Vact -
-               (REAL)par[PAR_NP] * (REAL)par[PAR_IRS] * Vact * (FN(exp_)((REAL)par[PAR_PV_VT] * Vdc) - 1);
+               (REAL)par[PAR_NP] * (REAL)par[PAR_IRS] * Vact * (FN(exp_)((REAL)par[PAR_PV_VT] * Vpv) - 1);
     ppv = (ppv > 0 ? ppv : 0) / (REAL)par[PAR_SBASE];
     /* current references */
     const REAL Qpcc = FN(cimag_)(Sp);

@@ -23,7 +23,11 @@ def _ramp(action):
 _SAMPLE_IDS = tuple(int(i) for i in np.sort(np.random.default_rng(77).choice(65536, size=48, replace=False)))
 
 CASES = {
-    "ramp_a1": _ramp(1), "ramp_a2": _ramp(2), "ramp_a3": _ramp(3), "ramp_a4": _ramp(4),
+    "ramp_a1": _ramp(1), "ramp_a2": _ramp(2), "ramp_a3": _ramp(3),
+    # action 4 SATURATES the duty cycle from env step ~116: there the bridge's RK45 is a chattering approximation of the sliding
+    # solution whose error falls like tol^0.2 only (profiles/r04_saturation_convergence.txt: 6e-3 / 3e-3 per env step at rtol
+    # 1e-8 / 1e-10 against 1e-12) -- the golden is the 1e-12 run and carries the 1e-10 run beside it (obs_coarser): its OWN spread
+    "ramp_a4": dict(_ramp(4), rtol=1e-12),
     # four envs of the 65 536-env action-1 ramp (seed 3) in which the +2 % voltage event of env step 121 takes the duty
     # cycle -- |m| = 0.97 by then -- across its limit for a moment: one env step on the 23-state path (switched operator
     # sets), a 1e-3 imbalance in the current controller's integrators behind it that takes the rest of the episode to die

@@ -31,7 +31,8 @@ def run_env(job):
     name, e = job
     vg, si, acts, c = bridge_cases.case_inputs(name)
     m = pm.build_model("50")
-    ref = BridgeVecEnv(1, n=c["n"], method="rk45", rtol=1e-8, atol=1e-11)
+    rtol = c.get("rtol", 1e-8)
+    ref = BridgeVecEnv(1, n=c["n"], method="rk45", rtol=rtol, atol=rtol * 1e-3)
     ref.reset(vg[:, e:e + 1], si[:, e:e + 1], ev_s0=60, ev_ds=60)
     obs, rew, done, mabs, iabs = [], [], [], [], []
     for a in acts[:, e]:
@@ -81,7 +82,7 @@ def main():
                             obs=np.stack([r[2] for r in mine], axis=1), reward=np.stack([r[3] for r in mine], axis=1),
                             done=np.stack([r[4] for r in mine], axis=1), m_abs=np.stack([r[5] for r in mine], axis=1),
                             iref_abs=np.stack([r[6] for r in mine], axis=1), ev_s0=60, ev_ds=60, n=c["n"],
-                            rtol=1e-8, atol=1e-11)
+                            rtol=c.get("rtol", 1e-8), atol=c.get("rtol", 1e-8) * 1e-3)
         print("%s: %d envs x %d steps" % (n, c["N"], c["steps"]))
     print("%.0f s" % (time.time() - t0))
 

@@ -32,11 +32,12 @@ def expand(y11, ph=3):
     return np.array(out + list(y11[6:]))
 
 
+@pytest.mark.parametrize("u5", [False, True], ids=["shipped", "U5_ppv_at_mpp"])
 @pytest.mark.parametrize("der_id", ["50", "10"])
-def test_balanced_rhs_equals_oracle_rhs(der_id):
-    par = der_model.param_vector(der_id)
+def test_balanced_rhs_equals_oracle_rhs(der_id, u5):
+    par = der_model.param_vector(der_id, options={"ppv_at_mpp": True} if u5 else None)
     c = el.folded(par)
-    m = pm.build_model(der_id)
+    m = pm.build_model(der_id, pm.ModelOptions(ppv_uses_vdc=False) if u5 else None)
     ph = c["PH"]
     rng = np.random.default_rng(0)
     y0 = der_model.steady_state(par, der_id)
@@ -164,10 +165,10 @@ def test_current_limit_hybrid_steps_fp64(lin50):
     P1 = tick * el.phis(L, tick, 1)[1]
     M = el.etd3rk_f_matrices(L, (0.25 - tick) / el.CAREFUL_STEPS)
     worst, evals, crossed = 0.0, 0, False
-    for k in range(24):
+    for k in range(40):                    # (16 env steps stuck BEHIND the limit: a frozen integrator that leaks shows here)
         inp = (1.0, 100.0, 0.95 + 0.0075 * (k + 1), vdc0)
         yr = solve_ivp(f_ref, (0, 0.25), yr, args=(inp,), method="LSODA", rtol=1e-10, atol=1e-12, max_step=1e-3).y[:, -1]
-        y = y + P1 @ el.f_bal_limited(c, y, inp, -1.0, ilim2)
+        y = el.careful_tick(c, P1, y, inp, ilim2)
         for _ in range(el.CAREFUL_STEPS):
             y, ne = el.hybrid_step(c, M, y, inp, ilim2)
             evals += ne
@@ -175,8 +176,10 @@ def test_current_limit_hybrid_steps_fp64(lin50):
         sel = [0, 1, 6, 7, 8]
         worst = max(worst, float(np.linalg.norm((y - yr)[sel]) / np.linalg.norm(yr[sel])))
     assert crossed, "the scenario must reach the current limit"
-    assert evals > el.CAREFUL_STEPS * 24                   # the crossing / sliding branches ran
-    assert worst < 2e-4, worst
+    assert evals > el.CAREFUL_STEPS * 40                   # the crossing / sliding branches ran
+    # (round 3: 1.1e-4 over 24 steps and GROWING, 1.8e-4 over 40 -- what the f-form's dense matrices leaked into the frozen
+    # integrators; held exactly since round 4: 1.8e-5)
+    assert worst < 4e-5, worst
 
 
 @pytest.mark.parametrize("name", ["random_both_n15", "random_both_n4", "vdcalt_both_n15"])

@@ -69,6 +69,48 @@ def test_etdlin_trajectory_vs_converged_bridge(gpu_device, n_sub, steps, micro):
     assert env.step_stats()["n_nonfinite"] == 0
 
 
+@pytest.mark.parametrize("integrator,tol", [("etdlin", FP32_TOL / 2), ("etdrk4", FP32_TOL), ("rk45", 2e-6)])
+def test_model_option_ppv_at_mpp_vs_bridge_under_the_same_option(gpu_device, integrator, tol):
+    """the questions about the (absent) pvder model that /root/reference cannot decide, as named switches of
+    the PRODUCT where they move an observation by more than 1e-4 -- U5, the PV array's power at the MPP voltage instead of
+    the instantaneous DC-link voltage (profiles/r04_oracle_uncertainty.txt: 1e-4 ... 7e-4).  The device under
+    model_options={'ppv_at_mpp': True} against the converged bridge under ModelOptions(ppv_uses_vdc=False): random actions,
+    both kinds of events, 8 env steps -- and the switch DOES something (the default device run is > 1e-4 away)."""
+    from oracle import pvder_model as pm
+    N, steps = 64, 8
+    rng = np.random.default_rng(29)
+    actions = rng.integers(0, 5, size=(steps, N))
+    kw = dict(seed=31, events_spec=both_events_spec(), auto_reset=False, integrator=integrator)
+    if integrator == "rk45":
+        kw.update(rtol=1e-8, atol=1e-11)
+    spec = both_events_spec()
+    for k in spec:                                    # events from t = 0.25 s: four of the eight steps start behind one
+        spec[k]["t_events_start"] = 0.25
+        spec[k]["t_events_step"] = 0.5
+    kw["events_spec"] = spec
+    env = make_vec(N, gpu_device, model_options={"ppv_at_mpp": True}, **kw)
+    dflt = make_vec(N, gpu_device, **kw)
+    env.reset(); dflt.reset()
+    assert torch.equal(env.ev_vg, dflt.ev_vg) and torch.equal(env.out, dflt.out)       # same tables, same reset observation
+    vg, si = env.ev_vg.cpu().numpy().astype(np.float64), env.ev_si.cpu().numpy().astype(np.float64)
+    ref = BridgeVecEnv(N, n=15, method="rk45", rtol=1e-8, atol=1e-11, opts=pm.ModelOptions(ppv_uses_vdc=False))
+    ref.reset(vg, si, ev_s0=env.ev_s0, ev_ds=env.ev_ds)
+    got, want, plain = [], [], []
+    for t in range(steps):
+        a = torch.as_tensor(actions[t], device=gpu_device)
+        obs, rew, done, _ = env.step(a)
+        o0, _, _, _ = dflt.step(a)
+        o2, r2, d2 = ref.step(actions[t])
+        got.append(obs.cpu().numpy().astype(np.float64)); plain.append(o0.cpu().numpy().astype(np.float64)); want.append(o2)
+        assert np.array_equal(done.cpu().numpy(), d2)
+    got, want, plain = np.stack(got), np.stack(want), np.stack(plain)
+    flat = lambda a: a.transpose(1, 0, 2).reshape(N, -1)
+    err = rel_l2(flat(got), flat(want), axis=1)
+    assert err.max() < tol, "max rel-L2 over envs %.3e" % err.max()
+    assert rel_l2(flat(plain), flat(want), axis=1).max() > 1e-4          # the shipped resolution is a DIFFERENT model
+    assert env.step_stats()["n_nonfinite"] == 0
+
+
 def test_etdlin_full_episode_does_not_drift(gpu_device):
     """One complete default episode (160 env steps, 38 events of both kinds, random actions) against the committed
     converged-bridge golden (tests/golden/bridge_episode_random.npz; tests/bridge_cases.py)."""
@@ -665,8 +707,10 @@ def test_q_ref_ramps_on_a_sample_of_the_batch(gpu_device, action):
     traj = rel_l2(got.transpose(1, 0, 2).reshape(c["N"], -1), want.transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
     worst = per.max(axis=0)
     assert per[:100].max() < TIGHT * 2, per[:100].max()                       # up to the careful pass
-    assert worst.max() < 2e-4 and np.median(worst) < 1.3e-4, (worst.max(), np.median(worst))
-    assert traj.max() < 7e-5, traj.max()
+    # round 4 (frozen integrators held exactly, sliding steps polished onto the limit): worst env step of any of the 48 envs
+    # 6.9e-5 / 6.5e-5 (round 3: 1.36e-4 / 1.31e-4), median 2.9e-5 / 3.3e-5 -- every env step inside north_star's 1e-4
+    assert worst.max() < 1e-4 and np.median(worst) < 5e-5, (worst.max(), np.median(worst))
+    assert traj.max() < 3e-5, traj.max()
 
 
 @pytest.mark.parametrize("action", [1, 2, 3, 4])
@@ -676,9 +720,11 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
     (hybrid ETD3RK steps with the outer loops' conditional integration) --, actions 3 / 4 walk Vdc_ref +9 % / -9 %:
     action 4 ends at the duty-cycle limit (23-state path on the switched operator sets).  Four envs on their own
     voltage + insolation events against the committed converged-bridge goldens (tests/golden/bridge_ramp_a*.npz,
-    tests/bridge_cases.py): whole trajectory and worst single env step.  Where the duty cycle has saturated the
-    solution is not reproducible by ANY integrator (DESIGN.md "Saturation"): compared up to there, and beyond it
-    only for what is robust -- finite states, the duty cycle pinned at its limit."""
+    tests/bridge_cases.py): whole trajectory and worst single env step.  Action 4 is compared over ALL 160 steps
+    (VERDICT r3 #3): up to the first saturated step at the parity bar; beyond it against the golden at rtol 1e-12 with the
+    bound that regime supports -- the golden's OWN spread there is 3e-3 per env step (its 1e-10 run, stored beside it:
+    profiles/r04_saturation_convergence.txt, error ~ tol^0.17: a chattering approximation of the sliding solution), the
+    device's switched steps hold an anti-windup mode over a whole integrator step and are 1e-2 ... 1e-1 off."""
     import bridge_cases
     name = "ramp_a%d" % action
     g = bridge_cases.load(name)
@@ -708,14 +754,28 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
         assert g["iref_abs"].max() > 1.7316                            # the ramp does reach the current limit
         free = int(np.argmax(g["iref_abs"].max(axis=1) > 0.9 * 1.7316))
         assert per_step[:free].max() < TIGHT * 1.5, per_step[:free].max()     # the standard path
-        assert per_step.max() < 1.5e-4, (int(per_step.max(axis=1).argmax()), per_step.max())    # the careful pass
-        assert traj.max() < 5e-5, traj.max()
+        assert per_step.max() < 1e-4, (int(per_step.max(axis=1).argmax()), per_step.max())      # the careful pass (r4: 4.7 / 5.2e-5)
+        assert traj.max() < 2.5e-5, traj.max()
     else:
         assert per_step.max() < 1e-4, (int(per_step.max(axis=1).argmax()), per_step.max())
         assert traj.max() < TIGHT, traj.max()
     if action == 4:
         assert last < c["steps"] - 20 and max(mmax[last:]) > 0.9995   # the scenario saturates the duty cycle ...
         assert max(mmax) < 1.03                                        # ... which stays pinned at its limit
+        # every step BEYOND the onset of saturation, per env, against the rtol-1e-12 golden: a quantitative bound
+        # (the waiver "finite, |m| < 1.03" said nothing about accuracy), next to the golden's own spread
+        e_sat = rel_l2(got[last:], want[last:], axis=2)
+        spread = rel_l2(g["obs_coarser"][last:], want[last:], axis=2)
+        assert float(g["rtol"]) <= 1e-12 and spread.max() < 5e-3, spread.max()
+        # measured (tools/a4_saturated_numbers.py, profiles/r04_a4_saturated_numbers.txt): worst env step 9.0e-2 (where a phase
+        # enters or leaves the limit), MEDIAN 8.0e-4
+        assert e_sat.max() < 1.5e-1, (last + int(e_sat.max(axis=1).argmax()), e_sat.max())
+        assert np.median(e_sat) < 5e-3, np.median(e_sat)
+        # ... and the quantities a policy is rewarded on stay close: Vdc (obs 6: worst 1.4e-2, median 2.8e-4) and P_PCC
+        # (obs 4: worst 4.2e-2, median 8.3e-4)
+        assert np.abs(got[last:, :, 6] / want[last:, :, 6] - 1.0).max() < 2.5e-2
+        assert np.abs(got[last:, :, 4] / want[last:, :, 4] - 1.0).max() < 8e-2
+        assert np.median(np.abs(got[last:, :, 6] / want[last:, :, 6] - 1.0)) < 1e-3
         # an env that has left the limit again finds its way back to the converged solution (fp64 prototype of the
         # switched steps: 1e-2 two env steps behind a saturated stretch, 1e-3 after six)
         e_all = rel_l2(got, want, axis=2)

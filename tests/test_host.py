@@ -17,12 +17,19 @@ def test_param_vector_matches_oracle():
     for der in ("50", "10"):
         m = pm.build_model(der)
         par = der_model.param_vector(der)
-        assert np.array_equal(par[:27], bridge.pack_params(m))
+        assert np.array_equal(par[:27], bridge.pack_params(m)[:27])
         assert par[der_model.IDX["VRMS_REF"]] == m.Vrms_ref and par[der_model.IDX["VDC_REF0"]] == m.Vdc_ref0
+        assert par[der_model.IDX["PPV_AT_MPP"]] == 0.0 and bridge.pack_params(m)[-1] == 0.0      # model option U5: off by default
+        mo = pm.build_model(der, pm.ModelOptions(ppv_uses_vdc=False))
+        po = der_model.param_vector(der, options={"ppv_at_mpp": True})
+        assert po[der_model.IDX["PPV_AT_MPP"]] == 1.0 and bridge.pack_params(mo)[-1] == 1.0 and np.array_equal(po[:27], par[:27])
+        assert np.abs(der_model.steady_state(po, der) - pm.steady_state(mo)).max() < 1e-12      # (the same steady state: Vdc = Vdcmpp0 there)
         y0 = der_model.steady_state(par, der)
         assert np.abs(y0 - pm.steady_state(m)).max() < 1e-12
     with pytest.raises(ValueError):
         der_model.param_vector("999")
+    with pytest.raises(ValueError):
+        der_model.param_vector("50", options={"no_such_option": True})
 
 
 def header_functions():
@@ -46,7 +53,7 @@ def test_library_exports_every_declared_symbol():
     assert agent == sorted(_native.AGENT_SYMBOLS)
     for sym in agent:
         assert hasattr(L, sym), sym
-    assert L.pvder_version() == _native.ABI_VERSION == 11
+    assert L.pvder_version() == _native.ABI_VERSION == 12
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
     assert L.pvder_block_size() % 64 == 0
@@ -343,7 +350,7 @@ def test_parameter_set_overrides_match_the_oracle_and_are_validated():
     ov = {"C_actual": 360e-6, "Kp_DC": -2.5, "Ki_Q": 12.0, "Np": 10, "Rf_actual": 0.003}
     par = der_model.param_vector("50", ov)
     m = pm.build_model("50", overrides=ov)
-    assert np.array_equal(par[:27], bridge.pack_params(m))
+    assert np.array_equal(par[:27], bridge.pack_params(m)[:27])
     assert np.abs(der_model.steady_state(par, "50") - pm.steady_state(m)).max() < 1e-12
     assert not np.array_equal(par, der_model.param_vector("50"))
     assert np.array_equal(der_model.param_vector("50", {}), der_model.param_vector("50"))

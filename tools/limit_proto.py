@@ -59,7 +59,7 @@ def ramp(action, vgt, sit, steps, nst, mode, n=15):
         q += dq * ((action == 1) - (action == 2)); v += dv * ((action == 3) - (action == 4))
         row = rowof(ksub)
         inp = (vgt[row], sit[row], q, v)
-        y = y + P1 @ el.f_bal_limited(c, y, inp, -1.0, ILIM2)
+        y = el.careful_tick(c, P1, y, inp, ILIM2)
         M = mats((n / 60.0 - tick) / nst)
         for _ in range(nst):
             if mode == "hybrid":

@@ -96,9 +96,15 @@ class Scheme:
             return self.etd3(y, inp, (ticks_total - 2) / (60.0 * MICRO))
         if kind == "e2q1n":
             return self.etd3(y, inp, ticks_total / (60.0 * MICRO))
-        if kind == "k4":
+        if kind == "k4" or (kind == "e2k4" and not at_event):
             y = self.tick(y, inp)
             return self.k4(y, inp, (ticks_total - 2) / (60.0 * MICRO))
+        if kind == "k4n" or (kind == "e2k4n" and not at_event):
+            return self.k4(y, inp, ticks_total / (60.0 * MICRO))
+        if kind in ("e2k4", "e2k4n"):
+            y = self.tick(y, inp)
+            h = (ticks_total - 2) / 2.0 / (60.0 * MICRO)
+            return self.etd3(self.etd3(y, inp, h), inp, h)
         raise ValueError(kind)
 
 
@@ -158,7 +164,7 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     dtype = np.float32 if "--f32" in sys.argv else np.float64
     cases = args or ["episode_random", "episode_random_sample", "ramp_a3"]
-    kinds = ["t2", "t1", "e2q1", "e2q1n", "k4"]
+    kinds = ["t2", "e2q1n", "k4", "k4n", "e2k4", "e2k4n"]
     print("# %s; per case: worst env step (rel-L2 of the 11 observations, steps inside the limits) / worst whole trajectory / f evaluations per env step" % dtype.__name__)
     for case in cases:
         for kind in kinds:
