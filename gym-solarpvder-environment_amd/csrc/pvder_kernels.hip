@@ -66,6 +66,20 @@ __device__ unsigned long long g_trace[4096 * 32];
 #define PVDER_TRACE_AT(slot) do { } while (0)
 #define PVDER_TRACE_DEP(slot, val) do { } while (0)
 #endif
+// (-DPVDER_TRACE -DPVDER_TRACE_COLD: the stamps of the second pass of step_etdlin_kernel -- lin_step_body behind the lean
+//  pass -- instead of the lean pass's own: slots 8 entry | 9 standard pass done | 10 careful pass done | 11 epilogue done |
+//  12 23-state tail done; tools/ramp_timeline.py)
+#if defined(PVDER_TRACE) && defined(PVDER_TRACE_COLD)
+#define PVDER_TRACE_COLD_AT(slot) PVDER_TRACE_AT(slot)
+// ... the LATEST wave of the workgroup to get there (slots 13 tail: operator sets staged | 14 state loaded | 15 + s: sim time step s done)
+#define PVDER_TRACE_COLD_MAX(slot, cond)                                                                          \
+    do {                                                                                                           \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && (cond)) atomicMax(&g_trace[blockIdx.x * 32 + (slot)], (unsigned long long)wall_clock64()); \
+    } while (0)
+#else
+#define PVDER_TRACE_COLD_AT(slot) do { } while (0)
+#define PVDER_TRACE_COLD_MAX(slot, cond) do { } while (0)
+#endif
 
 // A/B switches of the kernarg laundering (tools/ab_variant.sh): -DPVDER_NO_LAUNDER_EPI / _ROLL let hipcc
 // keep the kernel arguments live instead of re-reading them
@@ -265,9 +279,11 @@ template <typename T, int NS>
 __device__ __forceinline__ void prologue(const StepK<T> &C, const T *__restrict__ fstate,
                                          const int32_t *__restrict__ istate,
                                          const uint8_t *__restrict__ action, int n_env, Lane<T> &L, T *y,
-                                         int run_status = 0) {
+                                         int run_status = 0, int e_own = -1) {
     const size_t N = (size_t)n_env;
-    L.e = blockIdx.x * kBlock + threadIdx.x;
+    // (e_own: the env this lane works on when it is not the one its thread index names -- the 23-state tail packs the
+    //  workgroup's deferred envs into its first lanes)
+    L.e = e_own >= 0 ? e_own : (int)(blockIdx.x * kBlock + threadIdx.x);
     L.live = L.e < n_env;
     L.ec = L.live ? L.e : n_env - 1;               // clamp: tail lanes recompute env n-1, never store
     L.ksub = ld(&istate[PVDER_I_KSUB * N + L.ec]);
@@ -735,9 +751,16 @@ __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
 // profiles/r03_saturation_floor.txt), so this path is checked for what is robust: the duty cycle pinned at the limit,
 // the DC link and the powers at the converged solution's level, finite states (tests/test_gpu_parity.py).
 struct Mat16 { v4 a, b, c, d; };     // (col 0, col 1 of rows i), (col 2, col 3 of rows i), the same for rows u
-__device__ __forceinline__ Mat16 load_mat16(const lds_v4 *M, int k) {
+// LDS layout of the switched block (etdrk4_full_tail stages it that way): [step size][matrix][16-byte word j = 0..3][mode] --
+// the four MODES of a word side by side.  A lane addresses its pair's operator set by its own mode: lanes of one mode read
+// one address (a broadcast), lanes of different modes read ADJACENT 16-byte words, i.e. different banks -- conflict-free
+// whatever the mix.  (Round 3 laid the block out [mode][matrix][word]: modes 832 B apart, and a wave whose envs sat at
+// different modes -- every wave while a batch APPROACHES the duty-cycle limit -- serialised each of its 2500 operand reads
+// per env step: the 23-state path took 140 us there against 63 us once the whole batch had saturated,
+// profiles/r04_ramp4_timeline.txt.)
+__device__ __forceinline__ Mat16 load_mat16(const lds_v4 *M /* + mode */, int k) {
     Mat16 m;
-    m.a = M[4 * k + 0]; m.b = M[4 * k + 1]; m.c = M[4 * k + 2]; m.d = M[4 * k + 3];
+    m.a = M[(4 * k + 0) * kSwModes]; m.b = M[(4 * k + 1) * kSwModes]; m.c = M[(4 * k + 2) * kSwModes]; m.d = M[(4 * k + 3) * kSwModes];
     return m;
 }
 __device__ __forceinline__ void matvec16(const Mat16 &M, v2 ni, v2 nu, v2 &oi, v2 &ou) {
@@ -775,7 +798,7 @@ __device__ __forceinline__ float etd_switched_step(const ModelK<float> &P, const
     const float m2a = etd_eval(P, K, Ec, S, y, t0, qref, vdcref, n1f, ns1);                // N1
     int mode = 0;        // 2 bits per phase
     // (the operator set of a pair is addressed from its mode wherever it is read: three pointers less to keep)
-#define PVDER_MP(p) (Mset + ((mode >> (2 * (p))) & 3) * (kMatCount * 4))
+#define PVDER_MP(p) (Mset + ((mode >> (2 * (p))) & 3))
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const v2 u = y[3 * p + 2], m = fma2(bc2(P.KpG), u, y[3 * p + 1]);
@@ -892,12 +915,43 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     for (int k = threadIdx.x; k < kCoefFloats; k += kBlock) Mlds[k] = coef[k];
 #endif
     __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // the operator sets per anti-windup mode (mode 0: the complex block)
-    for (int k = threadIdx.x; k < kSwFloats; k += kBlock) Msw[k] = coef[kCoefFloats + k];
-    __syncthreads();
+    for (int k = threadIdx.x; k < kSwFloats; k += kBlock) {
+        // buffer: [step size][mode][matrix][word j][4 floats]  ->  LDS: [step size][matrix][word j][mode][4 floats] (load_mat16)
+        const int c = k & 3, j = (k >> 2) & 3, mat = (k >> 4) % kMatCount, sm = (k >> 4) / kMatCount, mode = sm % kSwModes, set = sm / kSwModes;
+        Msw[((((set * kMatCount + mat) * 4 + j) * kSwModes + mode) << 2) + c] = coef[kCoefFloats + k];
+    }
+    // PACK the workgroup's deferred envs into its first lanes (deterministic order: by thread index).  The step loop below is
+    // a single wave's dependent chain, and what it costs depends on how the deferred lanes are spread: ONE lane in each of a
+    // workgroup's four waves -- what a batch looks like while it approaches the duty-cycle limit, a few envs per wave behind
+    // every insolation event -- runs the loop in 150 us, the same four envs in ONE wave in 63 us, and so do 256 of them
+    // (tools/sparse_saturated_envs.py, profiles/r04_sparse_saturated_envs.txt: 93 us per batched step with one deferred env per
+    // workgroup, 155 with one per wave, 95 with every env deferred).  The states come from memory anyway.
+    __shared__ int wave_cnt[kBlock / 64];
+    __shared__ int packed[kBlock];
+    {
+        const unsigned long long bal = __ballot((int)defer);
+        if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (int)__popcll(bal);
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) base += w < (int)(threadIdx.x >> 6) ? wave_cnt[w] : 0;
+        if (defer) packed[base + (int)__popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)threadIdx.x;
+        __syncthreads();
+    }
+    int n_def = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) n_def += wave_cnt[w];
+    const bool mine = (int)threadIdx.x < n_def;
+    PVDER_TRACE_COLD_MAX(13, true);
     Lane<float> L;
     float ys[NS];
-    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys, run_status);
-    L.live = L.run = L.run && defer;               // everyone else in the workgroup is done already
+    prologue<float, NS>(C, fstate, istate, action, n_env, L, ys, run_status,
+                        (int)(blockIdx.x * kBlock) + (mine ? packed[threadIdx.x] : (int)threadIdx.x));
+    L.live = L.run = L.run && mine;                // everyone else in the workgroup is done already
+    PVDER_TRACE_COLD_MAX(14, __any((int)L.run));
+#if defined(PVDER_TRACE) && defined(PVDER_TRACE_COLD)
+    const unsigned long long trc_c0 = clock64(), trc_w0 = wall_clock64();      // (shader cycles / 100 MHz wall clock at the loop's start)
+#endif
     if (L.run) {
         v2 y[NP], comp[NP];
         to_pairs(ys, y);
@@ -931,7 +985,13 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                 const v2 h2 = pvder::bc2(0.5f * h), h4 = pvder::bc2(0.25f * h), h8 = pvder::bc2(0.125f * h),
                          h6 = pvder::bc2(h * (float)(1.0 / 6.0)), h23 = pvder::bc2(h * (float)(2.0 / 3.0));
                 const float tq = 120.f * h;                   // 2*theta advances 2 turns per 1/60 s
-                const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
+                // (the guard from a SCALAR load, selected by value: left to itself hipcc selects the ADDRESS by the per-lane
+                // condition and fetches the guard with a vector load from the kernel-argument segment -- a memory round trip
+                // inside every step of this latency-bound loop)
+                float g_sm = Ec.sat2_smooth;
+                asm volatile("" : "+s"(g_sm));
+                // (sat2_event / sat2_smooth = (0.97 / 0.998)^2: one scalar instead of two -- this path has no SGPR to spare)
+                const float guard = (j == 0 && input_jump) ? g_sm * 0.94467492f : g_sm;
 #ifndef PVDER_RK4_FALLBACK
                 // ONE step function for every lane of this path: the (i_p, u_p) pairs on the real 4x4 operator set of the
                 // anti-windup mode each is in at the start of the step -- mode 0 (below the limit: every pair of an env that
@@ -1049,7 +1109,16 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
                 t0 = t2;
             }
             }
+            PVDER_TRACE_COLD_MAX(15 + (s < 3 ? s : 3), true);
         }
+#if defined(PVDER_TRACE) && defined(PVDER_TRACE_COLD)
+        if (blockIdx.x < 4096) {       // the loop's length in shader cycles (slot 30) and in wall-clock ticks (slot 31): the clock it ran at
+            // (slot 5: cycles << 8 | lanes of THIS wave in the loop -- the wave with the longest loop and how many lanes it carried)
+            atomicMax(&g_trace[blockIdx.x * 32 + 5], ((unsigned long long)(clock64() - trc_c0) << 8) | (unsigned long long)__popcll(__ballot(1)));
+            atomicMax(&g_trace[blockIdx.x * 32 + 30], (unsigned long long)(clock64() - trc_c0));
+            atomicMax(&g_trace[blockIdx.x * 32 + 31], (unsigned long long)(wall_clock64() - trc_w0));
+        }
+#endif
         from_pairs(y, ys);
         L.ksub += C.n_sub;
         L.steps += 1;
@@ -2007,6 +2076,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     // `only`: the lanes this pass advances (step_etdlin_kernel: the envs its lean first pass, lin_step_lean, left alone;
     // everyone else of the workgroup has stored its result -- and been counted -- already)
     if (!only) { L.run = false; L.live = false; L.bad_action = 0.f; }
+    PVDER_TRACE_COLD_AT(8);
     // ksub is the first state word to arrive: the event inputs and the schedule row of the first segment
     // are requested while the other state rows are still in flight
     const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
@@ -2047,6 +2117,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         // step) belongs to the careful pass, which decides with its own guards
         careful = careful && L.run && !defer0;
         defer = defer0 || (defer && !careful);
+        PVDER_TRACE_COLD_AT(9);
         PVDER_DBG_COUNT(2, careful);
         if (__builtin_amdgcn_readfirstlane(__any((int)careful))) {
             // envs at the current limit: their env step again, from the state it started with, by the careful pass
@@ -2057,6 +2128,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             defer |= careful && dc;
             PVDER_DBG_COUNT(3, careful && dc);
         }
+        PVDER_TRACE_COLD_AT(10);
         if (L.run && !defer) {
             lin_to_rows<PH>(Y, ys);
             L.ksub += A.C.n_sub;
@@ -2094,8 +2166,10 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             PVDER_DBG_COUNT(11, threadIdx.x == 0);
             KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
             asm volatile("" : "+s"(kb));
+            PVDER_TRACE_COLD_AT(11);
             if constexpr (PH == 3) etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
             else rk4_tail_1ph(*(const EtdArgs *)kb, defer, act, out_off);
+            PVDER_TRACE_COLD_AT(12);
         }
     }
 }
