@@ -71,6 +71,11 @@ __device__ unsigned long long g_trace[4096 * 32];
 //  12 23-state tail done; tools/ramp_timeline.py)
 #if defined(PVDER_TRACE) && defined(PVDER_TRACE_COLD)
 #define PVDER_TRACE_COLD_AT(slot) PVDER_TRACE_AT(slot)
+// ... the shader clock (cycles) at the same point: slot 26 second pass entry | 27 careful pass done (tools/careful_timeline.py)
+#define PVDER_TRACE_COLD_CYC(slot)                                                              \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 32 + (slot)] = clock64(); \
+    } while (0)
 // ... the LATEST wave of the workgroup to get there (slots 13 tail: operator sets staged | 14 state loaded | 15 + s: sim time step s done)
 #define PVDER_TRACE_COLD_MAX(slot, cond)                                                                          \
     do {                                                                                                           \
@@ -78,6 +83,7 @@ __device__ unsigned long long g_trace[4096 * 32];
     } while (0)
 #else
 #define PVDER_TRACE_COLD_AT(slot) do { } while (0)
+#define PVDER_TRACE_COLD_CYC(slot) do { } while (0)
 #define PVDER_TRACE_COLD_MAX(slot, cond) do { } while (0)
 #endif
 
@@ -1709,6 +1715,11 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
         const bool standard = sg.seg >= C.n_sub && (sg.sch & 0xffffffull) == (unsigned long long)(cur | (cur << 8));
         if (__builtin_amdgcn_readfirstlane(__any((int)(run && !defer && !standard))) == 0) {
             if (!__builtin_amdgcn_readfirstlane(__any((int)(run && !defer)))) return defer;
+#ifndef PVDER_NO_WAVE_BAIL
+            if constexpr (!SPLIT) {          // (an env that leaves from the start -- off balance, forced: see the wave bail below)
+                if (__builtin_amdgcn_readfirstlane(__any((int)(run && defer)))) return true;
+            }
+#endif
             if (trace_step == 0) PVDER_TRACE_AT(3);
             v2 yp[6], F[6];
             float m2a, ir2a;
@@ -1728,6 +1739,16 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
             // straight to the careful pass)
 #ifndef PVDER_NO_EARLY
             if (!__builtin_amdgcn_readfirstlane(__any((int)(run && !defer && !careful)))) return defer;
+#endif
+#ifndef PVDER_NO_WAVE_BAIL
+            // The lean first pass (SPLIT = false: step_etdlin_kernel's, the fused rollout's) gives the WAVE up as soon as one
+            // of its envs leaves: the workgroup goes through the second pass anyway (the fused rollout: to the finish kernel),
+            // which redoes this wave's envs from the state in memory with the same arithmetic -- the two ETD3RK steps here
+            // would be 4 us spent on results nobody needs at every step of a batch held at a limit (fixed-action policies:
+            // PVDER_env.py:480-487).  Nothing of a wave that bails is stored: bit-identical results.
+            if constexpr (!SPLIT) {
+                if (__builtin_amdgcn_readfirstlane(__any((int)(run && defer)))) return true;
+            }
 #endif
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -2077,6 +2098,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
     // everyone else of the workgroup has stored its result -- and been counted -- already)
     if (!only) { L.run = false; L.live = false; L.bad_action = 0.f; }
     PVDER_TRACE_COLD_AT(8);
+    PVDER_TRACE_COLD_CYC(26);
     // ksub is the first state word to arrive: the event inputs and the schedule row of the first segment
     // are requested while the other state rows are still in flight
     const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
@@ -2129,6 +2151,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             PVDER_DBG_COUNT(3, careful && dc);
         }
         PVDER_TRACE_COLD_AT(10);
+        PVDER_TRACE_COLD_CYC(27);
         if (L.run && !defer) {
             lin_to_rows<PH>(Y, ys);
             L.ksub += A.C.n_sub;

@@ -27,7 +27,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "ramp":        # one action held from th
         env.step(a, return_tensors=False)
         torch.cuda.synchronize()
         L.pvder_debug_counters(buf, 1)
-        if t >= (60 if act == 4 else 115):
+        if t >= (60 if act == 4 else int(os.environ.get("FROM", "115"))):
             print("step %3d" % t, "  ".join("%s %d" % (names[k][:28], buf[k]) for k in show), flush=True)
     sys.exit(0)
 for q in [float(x) for x in sys.argv[1:]] or [1.0, -1.0]:
