@@ -894,10 +894,15 @@ __device__ __forceinline__ float etd_switched_step(const ModelK<float> &P, const
 // a scratch allocation -- AMDGPU callees save callee-saved VGPRs even when they never return -- and
 // with scratch enabled the workgroups start ~2 us later).
 typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
+// LP (step_etdrk4_lane_kernel): every env with its OWN values of the parameters that stay outside the exponential operator
+// (lane_par: [PVDER_LPF_ROWS][n_env] folded constants, pvder_fold_lane_params) -- the lane's ModelK is the launch's with
+// those seven fields replaced (VGPRs instead of SGPRs); stats_fresh: this pass starts the step's statistics.
+template <bool LP = false>
 __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, const uint8_t *act = nullptr,
-                                                 long long out_off = 0) {
+                                                 long long out_off = 0, const float *__restrict__ lane_par = nullptr,
+                                                 int stats_fresh = 0) {
     const int run_status = 0;
-    const ModelK<float> &P = A.P;
+    const ModelK<float> &P0 = A.P;
     const StepK<float> &C = A.C;
     const ResetK &R = A.R;
     const EtdK &Ec = A.Ec;
@@ -953,7 +958,17 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     float ys[NS];
     prologue<float, NS>(C, fstate, istate, action, n_env, L, ys, run_status,
                         (int)(blockIdx.x * kBlock) + (mine ? packed[threadIdx.x] : (int)threadIdx.x));
-    L.live = L.run = L.run && mine;                // everyone else in the workgroup is done already
+    L.live = L.live && mine;                       // everyone else in the workgroup is done already
+    L.run = L.run && mine;
+    ModelK<float> Pl = P0;
+    if constexpr (LP) {
+        const float *__restrict__ lp = lane_par + L.ec;
+        Pl.iC = lp[(size_t)PVDER_LPF_IC * N];
+        Pl.KpDC = lp[(size_t)PVDER_LPF_KP_DC * N]; Pl.KiDC = lp[(size_t)PVDER_LPF_KI_DC * N];
+        Pl.KpQ = lp[(size_t)PVDER_LPF_KP_Q * N];   Pl.KiQ = lp[(size_t)PVDER_LPF_KI_Q * N];
+        Pl.pvA = lp[(size_t)PVDER_LPF_PVA * N];    Pl.pvB = lp[(size_t)PVDER_LPF_PVB * N];
+    }
+    const ModelK<float> &P = LP ? Pl : P0;
     PVDER_TRACE_COLD_MAX(14, __any((int)L.run));
 #if defined(PVDER_TRACE) && defined(PVDER_TRACE_COLD)
     const unsigned long long trc_c0 = clock64(), trc_w0 = wall_clock64();      // (shader cycles / 100 MHz wall clock at the loop's start)
@@ -1129,7 +1144,7 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env);
+    epilogue<float, 3>(P, C, R, L, ys, fstate, istate, ev_vg, ev_si, out, stats, n_env, stats_fresh);
 }
 
 // Single phase: the envs the fast path hands over (estimate guard, duty cycle at its limit -- the single-phase inverter
@@ -1396,6 +1411,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         if constexpr (PH == 3) etdrk4_full_tail(*(const EtdArgs *)ka, defer);
         else rk4_tail_1ph(*(const EtdArgs *)ka, defer);
     }
+}
+
+// Per-LANE parameter override ("optional per-env override [P][N] for domain randomisation"; config_der.json:2-21):
+// every env of the batch on the 23-state ETDRK4 path with its own DC-link capacitance, outer-loop gains, PV array size and
+// insolation scale -- the parameters that stay OUTSIDE the exponential operator (the stiff (i_p, u_p) pairs: Rf, Lf, Kp_GCC,
+// wp, and the operator sets of the anti-windup modes, belong to the parameter GROUP: param_groups.PVDERVecGroups).  No
+// balanced reduction here: an env with its own PV array is not at the group's operating point, and the reduction's guards
+// are folded for that one.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1))) void step_etdrk4_lane_kernel(const EtdArgs A, const float *lane_par) {
+    etdrk4_full_tail<true>(A, true, nullptr, 0, lane_par, A.stats_fresh);
 }
 
 // =============================================================================================
@@ -3362,6 +3387,7 @@ struct pvder_plan {
     StepK<double> Cd;
     Lin64K l64;                      // etdlin64
     ResetK R;
+    const float *lane_par;           // etdrk4: [PVDER_LPF_ROWS][n_env] folded per-lane constants (pvder_plan_lane_params), or NULL
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
@@ -3380,6 +3406,7 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     p.episode_steps = (cfg->max_ksub + cfg->n_sub - 1) / cfg->n_sub;
     if (cfg->max_steps > 0 && cfg->max_steps < p.episode_steps) p.episode_steps = cfg->max_steps;
     p.ksub_hint = -1;
+    p.lane_par = nullptr;
     p.n_sub = cfg->n_sub;
     rc = fold_reset(par, cfg, ar, p.R);
     if (rc) return rc;
@@ -3482,7 +3509,8 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
                 hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, p.ksub_hint, G);
             advance_hint(p, 1);
         } else {
-            if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
+            if (p.ph == 3 && p.lane_par) hipLaunchKernelGGL(step_etdrk4_lane_kernel, grid, block, 0, st, A, p.lane_par);
+            else if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
         }
         break;
@@ -3610,6 +3638,41 @@ int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, cons
 }
 
 void pvder_plan_destroy(pvder_plan *plan) { delete plan; }
+
+int pvder_fold_lane_params(const double *par, const double *lane, int n_env, float *folded) {
+    if (!par || !lane || !folded || n_env <= 0) return PVDER_EINVAL;
+    static const int idx[PVDER_LP_ROWS - 1] = {PVDER_PAR_C, PVDER_PAR_KP_DC, PVDER_PAR_KI_DC, PVDER_PAR_KP_Q, PVDER_PAR_KI_Q, PVDER_PAR_NP};
+    const size_t N = (size_t)n_env;
+    for (int e = 0; e < n_env; ++e) {
+        double q[PVDER_PAR_COUNT];
+        for (int k = 0; k < PVDER_PAR_COUNT; ++k) q[k] = par[k];
+        for (int r = 0; r < PVDER_LP_ROWS - 1; ++r) {
+            const double v = lane[(size_t)r * N + e];
+            if (v == v) q[idx[r]] = v;                       // (NaN: the group's value)
+        }
+        double sc = lane[(size_t)PVDER_LP_SINSOL_SCALE * N + e];
+        if (!(sc == sc)) sc = 1.0;
+        if (!(q[PVDER_PAR_C] > 0.0) || !(q[PVDER_PAR_NP] >= 0.0) || !(sc >= 0.0)) return PVDER_EINVAL;
+        for (int r = 0; r < PVDER_LP_ROWS - 1; ++r)
+            if (!(fabs(q[idx[r]]) < 1e30)) return PVDER_EINVAL;
+        const ModelK<float> P = fold_params<float>(q, true);
+        folded[(size_t)PVDER_LPF_IC * N + e] = P.iC;
+        folded[(size_t)PVDER_LPF_KP_DC * N + e] = P.KpDC; folded[(size_t)PVDER_LPF_KI_DC * N + e] = P.KiDC;
+        folded[(size_t)PVDER_LPF_KP_Q * N + e] = P.KpQ;   folded[(size_t)PVDER_LPF_KI_Q * N + e] = P.KiQ;
+        // the insolation scale multiplies the photo-current term only:  pv1 = pvA * Sinsol + pvB  (make_sub; with model option
+        // U5 pvA carries -Vdcmpp0 times it, the same factor)
+        folded[(size_t)PVDER_LPF_PVA * N + e] = (float)((double)P.pvA * sc);
+        folded[(size_t)PVDER_LPF_PVB * N + e] = P.pvB;
+    }
+    return 0;
+}
+
+int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded) {
+    if (!plan) return PVDER_EINVAL;
+    if (lane_folded && (plan->integrator != PVDER_INT_ETDRK4 || plan->ph != 3)) return PVDER_EINVAL;
+    plan->lane_par = lane_folded;
+    return 0;
+}
 
 int pvder_plan_hint(pvder_plan *plan, int ksub) {
     if (!plan) return -1;

@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -28,7 +28,8 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_etdrk4_coef_count", "pvder_etdrk4_coefficients", "pvder_lin_set_floats", "pvder_lin_max_sets",
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
-           "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint"]
+           "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
+           "pvder_fold_lane_params", "pvder_plan_lane_params"]
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3, "etdlin64": 4}       # enum pvder_integrator
@@ -154,6 +155,10 @@ def lib() -> C.CDLL:
     L.pvder_plan_destroy.argtypes = [vp]
     L.pvder_plan_hint.restype = i32
     L.pvder_plan_hint.argtypes = [vp, i32]
+    L.pvder_fold_lane_params.restype = i32
+    L.pvder_fold_lane_params.argtypes = [dp, vp, i32, vp]
+    L.pvder_plan_lane_params.restype = i32
+    L.pvder_plan_lane_params.argtypes = [vp, vp]
     L.pvder_plan_step.restype = i32
     L.pvder_plan_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pvder_plan_rollout.restype = i32

@@ -107,6 +107,26 @@ def param_vector(der_id: str = "50", overrides: Optional[Dict[str, float]] = Non
     return np.array([float(v[k]) for k in PAR], dtype=np.float64)
 
 
+# Per-LANE overrides (include/pvder_hip.h PVDER_LP_*: the parameters outside the exponential operator of the 23-state ETDRK4
+# path): config_der.json keys (:2-21) plus the insolation scale, in the row order of the C ABI
+LANE_PARAMS = ("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q", "Np", "Sinsol_scale")
+
+
+def lane_param_rows(lane_params: Dict[str, "np.ndarray"], num_envs: int) -> np.ndarray:
+    """``{key: [N] values}`` (keys of LANE_PARAMS; a missing key or a NaN entry keeps the env at the group's value) ->
+    ``double[PVDER_LP_ROWS][N]`` in the units of ``par`` (C per unit, the rest as configured)."""
+    rows = np.full((len(LANE_PARAMS), int(num_envs)), np.nan, dtype=np.float64)
+    for k, v in lane_params.items():
+        if k not in LANE_PARAMS:
+            raise ValueError("lane_params key %r is not one of %s (everything else belongs to the parameter group: "
+                             "der_config / param_groups.PVDERVecGroups)" % (k, LANE_PARAMS))
+        a = np.asarray(v, dtype=np.float64).reshape(-1)
+        if a.shape != (int(num_envs),):
+            raise ValueError("lane_params[%r] must hold one value per env (%d)" % (k, num_envs))
+        rows[LANE_PARAMS.index(k)] = a / CBASE if k == "C_actual" else a
+    return rows
+
+
 def ppv(par: np.ndarray, vdc: float, sinsol: float) -> float:
     """PV array power in pu at DC-link voltage ``vdc`` (single-diode array model)."""
     vact = vdc * par[IDX["VDCBASE"]]

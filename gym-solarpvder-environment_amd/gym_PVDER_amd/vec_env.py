@@ -161,11 +161,16 @@ class PVDERVec(EnvSpecMixin):
                  model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
                  events_spec: Optional[dict] = None, der_config: Optional[dict] = None, off_range: str = "integrate",
-                 model_options: Optional[dict] = None):
+                 model_options: Optional[dict] = None, lane_params: Optional[dict] = None):
         """``der_config``: overrides of the model's config block (keys of config_der.json's derId entry, e.g.
         ``{"C_actual": 330e-6, "Kp_DC": -2.2}``) -- ONE parameter set per PVDERVec (the steady state, the
         Jacobian of the etdlin path and the coefficient tables are derived from it); for a batch spread over
         several parameter sets see gym_PVDER_amd.param_groups.PVDERVecGroups.
+        ``lane_params``: per-ENV values (domain randomisation) of the parameters outside the exponential operator --
+        ``{"C_actual": [N], "Kp_DC": [N], "Ki_DC": [N], "Kp_Q": [N], "Ki_Q": [N], "Np": [N], "Sinsol_scale": [N]}``, any subset,
+        NaN = the set's value -- with ``integrator="etdrk4"`` (three-phase model): every env then steps on the 23-state
+        ETDRK4 path with its own constants (include/pvder_hip.h pvder_plan_lane_params; ~0.1 ms per batched step).  reset()
+        starts every env from the SET's steady state, from where it settles at its own operating point.
         ``off_range``: an env driven out of the range the fast fp32 integrators cover (duty cycle / current
         reference at their limits: e.g. Vdc_ref walked down 6 %) is ``"integrate"``d through as the reference
         does -- on the 23-state path, its steps at the duty-cycle limit on the operator sets of the anti-windup modes:
@@ -246,6 +251,9 @@ class PVDERVec(EnvSpecMixin):
         self.hstep = torch.zeros(N, dtype=torch.float64, device=self.device) if integrator in ("rk45", "etdlin64") else None
         self._par_c = (C.c_double * len(self.par))(*self.par)
         self._y0_c = (C.c_double * len(self.y0))(*self.y0)
+        self._lane_folded = None
+        if lane_params:
+            self.set_lane_params(lane_params)
         self._needs_reset = True
         self._plan = None
         self._ksub_hint = -1         # pvder_plan_hint: the clock the batch's envs are at (survives plan rebuilds; -1 = unknown)
@@ -261,6 +269,21 @@ class PVDERVec(EnvSpecMixin):
                             "est_guard", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
                             "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "env_goal_spec", "integrator",
                             "off_range"))
+
+    def set_lane_params(self, lane_params: Optional[dict]):
+        """Install (or, with None, remove) the per-env parameter override -- see the constructor's ``lane_params``."""
+        self._drop_plan()
+        if not lane_params:
+            object.__setattr__(self, "_lane_folded", None)
+            return
+        if self.integrator != "etdrk4" or self.ns != 23:
+            raise ValueError("lane_params need integrator='etdrk4' and the three-phase model (the default integrator's "
+                             "tables belong to ONE parameter set: see param_groups.PVDERVecGroups)")
+        rows = np.ascontiguousarray(der_model.lane_param_rows(lane_params, self.num_envs))
+        folded = np.empty((7, self.num_envs), dtype=np.float32)
+        _native.check(self._lib.pvder_fold_lane_params(self._par_c, rows.ctypes.data, self.num_envs, folded.ctypes.data),
+                      "pvder_fold_lane_params")
+        object.__setattr__(self, "_lane_folded", torch.from_numpy(folded).to(self.device))
 
     def set_reward_spec(self, reward_types):
         """``env_goal_spec[goal]['reward']['my_spec'] = reward_types`` for the active goal (the reference's
@@ -560,6 +583,10 @@ class PVDERVec(EnvSpecMixin):
                                                   C.byref(cfg), C.byref(ar), coef, lin, self.num_envs),
                       "pvder_plan_create")
         self._plan = h
+        if self.__dict__.get("_lane_folded") is not None:
+            if integrator != "etdrk4":
+                raise RuntimeError("lane_params are installed but this configuration steps with integrator=%r" % integrator)
+            _native.check(self._lib.pvder_plan_lane_params(h, self._lane_folded.data_ptr()), "pvder_plan_lane_params")
         # where the batch's envs are (a prefetch hint for the step launch, include/pvder_hip.h): kept across plan rebuilds
         # (PVDER_NO_HINT=1: A/B runs without it)
         self._lib.pvder_plan_hint(h, -1 if os.environ.get("PVDER_NO_HINT") else self.__dict__.get("_ksub_hint", -1))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 12
+#define PVDER_ABI_VERSION 13
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -311,6 +311,32 @@ void pvder_plan_destroy(pvder_plan *plan);
  * flop); an env whose own counter says otherwise takes the dependent fetch as before.  A prefetch hint: a wrong or missing
  * one costs time, never a result. */
 int pvder_plan_hint(pvder_plan *plan, int ksub);
+
+/* Per-LANE parameter override (PVDER_INT_ETDRK4, three-phase model): every env of the batch with its own values of the
+ * parameters that stay outside the exponential operator of the 23-state ETDRK4 path -- domain randomisation over the
+ * DC-link capacitance, the outer PI loops, the PV array size and the insolation scale (config_der.json:2-21: C, Kp_DC,
+ * Ki_DC, Kp_Q, Ki_Q, Np; SURVEY.md a10 "optional per-env override [P][N]").  Everything inside the operator (Rf, Lf,
+ * Kp_GCC, Ki_GCC, wp, the ratings and limits) stays per parameter GROUP: one plan per set (param_groups.PVDERVecGroups).
+ *   lane rows, in the units of par[] (PVDER_PAR_C ... are per-unit values): NaN = keep par[]'s value for that env. */
+enum {
+    PVDER_LP_C = 0, PVDER_LP_KP_DC, PVDER_LP_KI_DC, PVDER_LP_KP_Q, PVDER_LP_KI_Q, PVDER_LP_NP,
+    PVDER_LP_SINSOL_SCALE, /* factor on the insolation the env sees (event table and reset value alike); NaN = 1 */
+    PVDER_LP_ROWS
+};
+/*   folded rows (what the kernel reads; float32): 1/C, the four gains, and the two constants of the PV array model
+ *   pv1 = pvA * Sinsol + pvB (pvder_model.hpp ModelK; pvA carries Np and the insolation scale, pvB Np). */
+enum { PVDER_LPF_IC = 0, PVDER_LPF_KP_DC, PVDER_LPF_KI_DC, PVDER_LPF_KP_Q, PVDER_LPF_KI_Q, PVDER_LPF_PVA, PVDER_LPF_PVB, PVDER_LPF_ROWS };
+/* pvder_fold_lane_params (host, no GPU): lane[PVDER_LP_ROWS][n_env] doubles -> folded[PVDER_LPF_ROWS][n_env] floats, by
+ * the SAME folding as the plan's own constants (model option PVDER_PAR_PPV_AT_MPP included).  PVDER_EINVAL for a
+ * non-positive C, a negative Np or scale, or a non-finite value. */
+int pvder_fold_lane_params(const double *par, const double *lane, int n_env, float *folded);
+/* pvder_plan_lane_params: lane_folded = DEVICE pointer to float[PVDER_LPF_ROWS][n_env] (kept by the plan, not copied;
+ * NULL returns the plan to its own constants).  While set, pvder_plan_step / pvder_plan_rollout advance EVERY env on the
+ * 23-state path (step_etdrk4_lane_kernel; no balanced reduction: an env with its own PV array is not at the group's
+ * operating point).  Reset and same-step auto-reset restart an env from the GROUP's steady state (ResetK.y0), from where
+ * it settles at its own operating point; the observation's Ppv and the reward use the env's own constants.
+ * PVDER_EINVAL unless the plan is a three-phase PVDER_INT_ETDRK4 plan. */
+int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded);
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream);
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,

@@ -30,10 +30,20 @@ from oracle.bridge_env import BridgeVecEnv  # noqa: E402
 def run_env(job):
     name, e = job
     vg, si, acts, c = bridge_cases.case_inputs(name)
-    m = pm.build_model("50")
     rtol = c.get("rtol", 1e-8)
-    ref = BridgeVecEnv(1, n=c["n"], method="rk45", rtol=rtol, atol=rtol * 1e-3)
-    ref.reset(vg[:, e:e + 1], si[:, e:e + 1], ev_s0=60, ev_ds=60)
+    if "lane_seed" in c:
+        # an env with its own parameter set: a model from its own config block, the insolation it sees scaled, started
+        # from the DEFAULT set's steady state
+        sets = bridge_cases.lane_param_sets(name)
+        ref = BridgeVecEnv(1, n=c["n"], method="rk45", rtol=rtol, atol=rtol * 1e-3,
+                           overrides={k: float(v[e]) for k, v in sets.items() if k != "Sinsol_scale"})
+        ref.reset(vg[:, e:e + 1], si[:, e:e + 1] * sets["Sinsol_scale"][e], ev_s0=60, ev_ds=60)
+        from oracle import bridge
+        ref.Y[0] = bridge.to_delta(pm.steady_state(pm.build_model("50")), 0.0)
+    else:
+        ref = BridgeVecEnv(1, n=c["n"], method="rk45", rtol=rtol, atol=rtol * 1e-3)
+        ref.reset(vg[:, e:e + 1], si[:, e:e + 1], ev_s0=60, ev_ds=60)
+    m = ref.model
     obs, rew, done, mabs, iabs = [], [], [], [], []
     for a in acts[:, e]:
         o, r, d = ref.step(np.array([a]))

@@ -1,0 +1,77 @@
+"""-m gpu: per-LANE parameter override of the ETDRK4 integrator (SURVEY.md a10 "optional per-env override [P][N] for domain
+randomisation"; config_der.json:2-21) -- one launch with 64 distinct parameter sets against the fp64 bridge integrating
+each set with a model built from its own config block (tests/golden/bridge_lane_params.npz, tests/bridge_cases.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def make_vec(N, device, **kw):
+    from gym_PVDER_amd.vec_env import PVDERVec
+    return PVDERVec(N, device=device, **kw)
+
+
+def _replay(env, acts, device):
+    got = []
+    for t in range(acts.shape[0]):
+        obs, rew, done, _ = env.step(torch.as_tensor(acts[t], dtype=torch.uint8, device=device))
+        got.append(np.concatenate([obs.cpu().numpy().astype(np.float64), rew.cpu().numpy()[:, None].astype(np.float64)], axis=1))
+        assert env.step_stats()["n_nonfinite"] == 0
+    return np.stack(got)
+
+
+def test_64_distinct_parameter_sets_in_one_launch_vs_the_bridge(gpu_device):
+    import bridge_cases
+    name = "lane_params"
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    sets = bridge_cases.lane_param_sets(name)
+    env = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4",
+                   lane_params=sets)
+    env.reset()
+    assert np.array_equal(env.ev_vg.cpu().numpy(), vg.astype(np.float32)) and np.array_equal(env.ev_si.cpu().numpy(), si.astype(np.float32))
+    got = _replay(env, acts, gpu_device)
+    want = g["obs"]
+    per_step = rel_l2(got[:, :, :10], want[:, :, :10], axis=2)
+    traj = rel_l2(got[:, :, :10].transpose(1, 0, 2).reshape(c["N"], -1), want[:, :, :10].transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
+    # the bar of VERDICT r3 #8: < 1e-4 (measured: see the assertion messages / DESIGN.md)
+    assert per_step.max() < 1e-4, (np.unravel_index(per_step.argmax(), per_step.shape), per_step.max())
+    assert traj.max() < 3e-5, traj.max()
+    assert np.array_equal(got[:, :, 11], g["reward"])                 # discrete rewards: exact
+    # ... and the sets DO matter: the same batch without the override is far from these goldens
+    ref = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4")
+    ref.reset()
+    plain = _replay(ref, acts, gpu_device)
+    assert rel_l2(plain[:, :, :10], want[:, :, :10], axis=2).max() > 1e-2
+
+
+def test_lanes_left_at_the_sets_values_match_the_plain_integrator(gpu_device):
+    """NaN rows / missing keys keep the group's constants: the 23-state path with the override installed but empty gives
+    what the same path gives without it (force-full ETDRK4 == lane kernel, bit for bit), and the balanced fast path's
+    results to its tolerance."""
+    import bridge_cases
+    vg, si, acts, cc = bridge_cases.case_inputs("lane_params")
+    N = 64
+    kw = dict(seed=21, auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4")
+    a = make_vec(N, gpu_device, lane_params={"Np": np.full(N, np.nan)}, **kw)
+    b = make_vec(N, gpu_device, **kw)
+    a.reset(); b.reset()
+    ga, gb = _replay(a, acts[:12], gpu_device), _replay(b, acts[:12], gpu_device)
+    assert rel_l2(ga[:, :, :10], gb[:, :, :10], axis=2).max() < 2e-5
+    assert np.array_equal(ga[:, :, 11], gb[:, :, 11])
+
+
+def test_lane_params_are_refused_where_they_cannot_apply(gpu_device):
+    with pytest.raises(ValueError):
+        make_vec(8, gpu_device, lane_params={"Np": np.full(8, 10.0)})                      # the default integrator: per-set tables
+    with pytest.raises(ValueError):
+        make_vec(8, gpu_device, integrator="etdrk4", lane_params={"Rf_actual": np.full(8, 0.002)})   # inside the operator
+    with pytest.raises(ValueError):
+        make_vec(8, gpu_device, integrator="etdrk4", lane_params={"Np": np.full(7, 10.0)})
+    with pytest.raises(ValueError):
+        make_vec(8, gpu_device, integrator="etdrk4", lane_params={"C_actual": np.zeros(8)})  # pvder_fold_lane_params: EINVAL

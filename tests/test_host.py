@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol():
     assert agent == sorted(_native.AGENT_SYMBOLS)
     for sym in agent:
         assert hasattr(L, sym), sym
-    assert L.pvder_version() == _native.ABI_VERSION == 12
+    assert L.pvder_version() == _native.ABI_VERSION == 13
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
     assert L.pvder_block_size() % 64 == 0
@@ -357,3 +357,41 @@ def test_parameter_set_overrides_match_the_oracle_and_are_validated():
     for bad in ({"nope": 1.0}, {"phases": 1}, {"C_actual": float("nan")}, {"C_actual": "big"}, {"Np": True}):
         with pytest.raises(ValueError):
             der_model.param_vector("50", bad)
+
+
+def test_lane_parameter_folding_on_the_host():
+    """pvder_fold_lane_params (no GPU): per-env values of the parameters outside the exponential operator, folded by the
+    same code as a plan's own constants -- against der_model.param_vector / etd_linear.folded of each env's config block."""
+    import ctypes as C
+    from gym_PVDER_amd import _native, der_model, etd_linear
+    L = _native.lib()
+    N = 5
+    rng = np.random.default_rng(0)
+    base = der_model.DER_CONFIG["50"]
+    sets = {"C_actual": base["C_actual"] * rng.uniform(0.5, 2.0, N), "Kp_DC": base["Kp_DC"] * rng.uniform(0.5, 2.0, N),
+            "Ki_Q": base["Ki_Q"] * rng.uniform(0.5, 2.0, N), "Np": np.array([8.0, 9.0, np.nan, 11.0, 10.0]),
+            "Sinsol_scale": np.array([1.0, 0.5, 0.9, np.nan, 0.8])}
+    rows = np.ascontiguousarray(der_model.lane_param_rows(sets, N))
+    assert rows.shape == (7, N) and np.isnan(rows[2]).all() and np.isnan(rows[5, 2])
+    for opts in (None, {"ppv_at_mpp": True}):
+        par = der_model.param_vector("50", None, opts)
+        out = np.empty((7, N), dtype=np.float32)
+        assert L.pvder_fold_lane_params((C.c_double * len(par))(*par), rows.ctypes.data, N, out.ctypes.data) == 0
+        for e in range(N):
+            ov = {k: float(v[e]) for k, v in sets.items() if k != "Sinsol_scale" and not np.isnan(v[e])}
+            c = etd_linear.folded(der_model.param_vector("50", ov, opts))
+            sc = 1.0 if np.isnan(sets["Sinsol_scale"][e]) else sets["Sinsol_scale"][e]
+            want = [c["iC"], c["KpDC"], c["KiDC"], c["KpQ"], c["KiQ"]]
+            np.testing.assert_allclose(out[:5, e], want, rtol=2e-7)
+            if not opts:
+                np.testing.assert_allclose(out[5:, e], [c["pvA"] * sc, c["pvB"]], rtol=2e-7)
+            else:       # model option U5: pv1 = pvA * Sinsol + pvB = -Ppv(Vdcmpp0) -- linear in the photo current, hence in the scale
+                v0, e0 = c["vdc0"], np.exp(c["pvK"] * c["vdc0"])
+                np.testing.assert_allclose(out[5:, e], [-v0 * c["pvA"] * sc, -v0 * c["pvB"] * (1.0 - e0)], rtol=2e-6)
+    bad = rows.copy(); bad[0, 1] = 0.0
+    out = np.empty((7, N), dtype=np.float32)
+    assert L.pvder_fold_lane_params((C.c_double * len(par))(*par), bad.ctypes.data, N, out.ctypes.data) == _native.EINVAL
+    with pytest.raises(ValueError):
+        der_model.lane_param_rows({"Rf_actual": np.ones(N)}, N)
+    with pytest.raises(ValueError):
+        der_model.lane_param_rows({"Np": np.ones(N + 1)}, N)
