@@ -100,6 +100,13 @@ __device__ __forceinline__ void bal_f(const ModelK<float> &P, const PkConst &K, 
 // register per (matrix, row group, column), data in lanes 0..3 only: 231 registers, the whole AGPR file).
 typedef float LinMatRegs[3];
 typedef float LinSetRegs[kLinMats][3];
+// Krogstad's ETDRK4 in f-form (round 4: the env step behind a mere action, lin_k4): U2 = y + M21 F1, U3 = y + M31 F1 + M32 F2,
+// U4 = y + M41 F1 + M42 F2 + M43 F3, y+ = y + B1 F1 + B2 F2 + B3 F3 + B4 F4 -- ten dense matrices (a zero of the N-form tableau
+// is not one here), 30 registers
+constexpr int kLinK4Mats = 10;
+constexpr int kLinK4Floats = kLinK4Mats * kLinMatFloats;
+enum { KM21 = 0, KM31, KM32, KM41, KM42, KM43, KB1, KB2, KB3, KB4 };
+typedef float LinK4Regs[kLinK4Mats][3];
 
 // lane 4k + r <- M[4g + r][k]  (row-major, 12 floats per row; blocks 11..15 are never selected)
 __device__ __forceinline__ void lin_load_mat(const float *__restrict__ m, int lane, LinMatRegs &A) {
@@ -112,11 +119,15 @@ __device__ __forceinline__ void lin_load_set(const float *__restrict__ set, int 
 #pragma unroll
     for (int m = 0; m < kLinMats; ++m) lin_load_mat(set + m * kLinMatFloats, lane, A[m]);
 }
+__device__ __forceinline__ void lin_load_k4(const float *__restrict__ blk, int lane, LinK4Regs &A) {
+#pragma unroll
+    for (int m = 0; m < kLinK4Mats; ++m) lin_load_mat(blk + m * kLinMatFloats, lane, A[m]);
+}
 
 // acc[j] += M_mat[j] f  for NM matrices of the set that share the input vector f (six pairs); column K and
 // the ones behind it (abid is an immediate of the instruction: compile-time recursion over the columns)
-template <int NM, int K>
-__device__ __forceinline__ void lin_mfma_cols(const LinSetRegs &A, const int (&mat)[NM], const v2 *__restrict__ f,
+template <int NM, int K, int NSET>
+__device__ __forceinline__ void lin_mfma_cols(const float (&A)[NSET][3], const int (&mat)[NM], const v2 *__restrict__ f,
                                               v4f (&acc)[NM][3]) {
     if constexpr (K < kLinN) {
         const float fk = (K & 1) ? f[K >> 1].y : f[K >> 1].x;
@@ -125,13 +136,13 @@ __device__ __forceinline__ void lin_mfma_cols(const LinSetRegs &A, const int (&m
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 acc[j][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[mat[j]][g], fk, acc[j][g], 4, K, 0);
-        lin_mfma_cols<NM, K + 1>(A, mat, f, acc);
+        lin_mfma_cols<NM, K + 1, NSET>(A, mat, f, acc);
     }
 }
-template <int NM>
-__device__ __forceinline__ void lin_mfma(const LinSetRegs &A, const int (&mat)[NM], const v2 *__restrict__ f,
+template <int NM, int NSET>
+__device__ __forceinline__ void lin_mfma(const float (&A)[NSET][3], const int (&mat)[NM], const v2 *__restrict__ f,
                                          v4f (&acc)[NM][3]) {
-    lin_mfma_cols<NM, 0>(A, mat, f, acc);
+    lin_mfma_cols<NM, 0, NSET>(A, mat, f, acc);
 }
 // acc += M f for ONE matrix: three row groups give three dependent chains of eleven MFMAs, and a dependent
 // 4x4x1 issues every ~16 clocks where an independent one issues every 8 -- so the columns are summed as two

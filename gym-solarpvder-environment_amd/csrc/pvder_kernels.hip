@@ -1458,6 +1458,18 @@ struct LinK {
                                      // careful pass -- the anti-windup does not engage below m_limit, the reduction is exact
     float seqE[18];                  // exp(A0 T): what an env step does to a negative- / zero-sequence component (i, x, u) of an
                                      // env slightly off balance (lin_seq_split); complex 3x3, row-major (re, im)
+    const float *k4coef;             // device: the ten f-form matrices of ONE Krogstad ETDRK4 step over a whole env step (behind the
+                                     // sets in the coefficient block; pvder_lin_coef.k4), or NULL: every segment by tick + ETD3RK steps
+};
+// The coefficient registers of the matrix-core path and what they hold (wave-uniform): the tick matrix, ONE ETD3RK set
+// (`cur`: its index, 0 = none) and the Krogstad block.  A launch loads what the step it expects needs (step_etdlin_kernel:
+// the plan's hint says whether the batch's env step starts at an event row change); whoever needs the rest loads it.
+struct LinRegs {
+    pvder::LinMatRegs At;
+    pvder::LinSetRegs Ac;
+    pvder::LinK4Regs Ak;
+    int cur;
+    bool at_ok, k4_ok;
 };
 struct LinArgs {
     EtdArgs A;                       // at kernarg offset 0: the 23-state tail re-reads it from there
@@ -1485,6 +1497,7 @@ struct RollK {
 // event-row change; the segment's inputs and schedule row are requested right away
 struct LinSeg {
     int row, until, seg;
+    bool at_event;                   // an event row starts exactly at the segment's first sim time step (an input jump whatever the action)
     float in_vg, in_si;
     unsigned long long sch;
 };
@@ -1492,7 +1505,7 @@ __device__ __forceinline__ LinSeg lin_first_segment(const StepK<float> &C, const
                                                     const float *ev_si, size_t N, int ec) {
     constexpr int kBig = 0x3fffffff;
     LinSeg s;
-    s.row = 0; s.until = kBig;
+    s.row = 0; s.until = kBig; s.at_event = false;
     if (C.ev_count > 0) {
         const int d = ksub - C.ev_s0;
         if (d < 0) {
@@ -1501,6 +1514,7 @@ __device__ __forceinline__ LinSeg lin_first_segment(const StepK<float> &C, const
             const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
             s.row = qd + 1 < C.ev_count ? qd + 1 : C.ev_count;
             s.until = qd + 1 < C.ev_count ? C.ev_ds - rd : kBig;
+            s.at_event = rd == 0 && qd < C.ev_count;
         }
     }
     s.seg = s.until < C.n_sub ? s.until : C.n_sub;
@@ -1676,6 +1690,67 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
+// One Krogstad ETDRK4 step of every lane over a WHOLE env step (round 4: the env step behind a mere action -- no event row
+// change at its start, so no input jump the stiff loop would ring from and no tick: tools/scheme_proto.py, fp32 on the
+// committed episodes: 7.0 -> 4.7 right-hand sides per env step of a PVDER-v0 rollout at unchanged accuracy).  Same guards as
+// lin_etd3rk: |m| at the start, the two middle stages, the c = 1 stage and the end; |iref| at the start and the middle (the
+// careful pass's threshold); embedded indicator y+ against the stage value U4.
+template <int PH>
+__device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs &Ak, const pvder::v4f (&Y)[3],
+                                       const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
+                                       float msc, pvder::v4f (&Yn)[3], bool &near_ilim) {
+    using namespace pvder;
+    const ModelK<float> &P = G.A.P;
+    const EtdK &Ec = G.A.Ec;
+    const PkConst K = make_pkconst(P);
+    v2 yp[6], F[6];
+    float m2a, ir2a, m2x, ir2x, m2y, ir2y, m2b, ir2b;
+    lin_pairs(Y, yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
+    v4f acc4[4][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
+    {
+        const int m4[4] = {KM21, KM31, KM41, KB1};
+        lin_mfma<4>(Ak, m4, F, acc4);                     // U2 = y + M21 F1; U3, U4, y+ started
+    }
+    lin_pairs(acc4[0], yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2x, ir2x);
+    v4f acc3[3][3] = {{acc4[1][0], acc4[1][1], acc4[1][2]}, {acc4[2][0], acc4[2][1], acc4[2][2]}, {acc4[3][0], acc4[3][1], acc4[3][2]}};
+    {
+        const int m3[3] = {KM32, KM42, KB2};
+        lin_mfma<3>(Ak, m3, F, acc3);                     // U3 complete
+    }
+    lin_pairs(acc3[0], yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2y, ir2y);
+    v4f acc2[2][3] = {{acc3[1][0], acc3[1][1], acc3[1][2]}, {acc3[2][0], acc3[2][1], acc3[2][2]}};
+    {
+        const int m2[2] = {KM43, KB3};
+        lin_mfma<2>(Ak, m2, F, acc2);                     // U4 complete
+    }
+    lin_pairs(acc2[0], yp);
+    bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2b, ir2b);
+    Yn[0] = acc2[1][0]; Yn[1] = acc2[1][1]; Yn[2] = acc2[1][2];
+    lin_mfma1(Ak[KB4], F, Yn);                            // y+
+    const float est = fmaxf(fmaxf(fabsf(Yn[0].x - acc2[0][0].x), fabsf(Yn[0].y - acc2[0][0].y)),
+                            fabsf(Yn[1].z - acc2[0][1].z));
+    const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
+    const float mmax = msc * fmaxf(fmaxf(fmaxf(m2a, m2x), fmaxf(m2y, m2b)), __builtin_fmaf(mn.y, mn.y, mn.x * mn.x));
+    near_ilim = ir2a > irg || ir2y > irg || mmax > Ec.sat2_smooth;
+    return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
+}
+
+// the tick matrix and an ETD3RK set in registers (whoever steps by tick + ETD3RK steps: a launch that expected a quiet
+// env step has loaded the Krogstad block only)
+__device__ __forceinline__ void lin_need_t2(const LinArgs &G, int lane, LinRegs &R) {
+    if (!R.at_ok) {
+        pvder::lin_load_mat(G.Lk.lcoef, lane, R.At);
+        R.at_ok = true;
+    }
+    if (R.cur == 0) {
+        pvder::lin_load_set(G.Lk.lcoef + pvder::kLinMatFloats, lane, R.Ac);
+        R.cur = 1;
+    }
+}
+
 // Does the duty cycle stay clear of its limit over the TICK behind an input jump (Y -> acc)?  The jump kicks the
 // under-damped current loop (poles -1.0e5 +- j5.8e5 1/s, zeta = 0.17): m = Kp_GCC u + x rings around its new value --
 // reached well inside the tick, 20 decay times -- with a first overshoot of exp(-pi zeta / sqrt(1 - zeta^2)) = 0.58
@@ -1709,9 +1784,9 @@ __device__ __forceinline__ unsigned long long lin_sched_next(const LinArgs &G, u
 // redoes their env step from the state they started with (their Y is meaningless too).
 // SPLIT = false (the fused rollout kernel, which hands both kinds to the per-step body): one flag, returned.
 template <int PH, bool SPLIT = true>
-__device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
-                                              int &cur, pvder::v4f (&Y)[3], float qref, float vdcref, int ec, LinSeg sg,
-                                              bool run, bool defer, bool &careful, int trace_step, float msc = 1.f) {
+__device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinRegs &R, pvder::v4f (&Y)[3], float qref,
+                                              float vdcref, int ec, LinSeg sg, bool run_all, bool defer, bool &careful,
+                                              int trace_step, float msc = 1.f) {
     using namespace pvder;
     constexpr int kBig = 0x3fffffff;
     const ModelK<float> &P = G.A.P;
@@ -1725,11 +1800,51 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, const 
     const v2 kpo = mk2(g_kpdc, g_kpq), kio = mk2(g_kidc, g_kiq);
     float irg = G.Lk.ir2_careful;
     asm volatile("" : "+v"(irg));
+    careful = false;
+    SubPk S;
+    // ---- the QUIET env step: one segment, no event row change at its start (a new action at most) -- ONE Krogstad step, no
+    // tick (lin_k4).  Per lane, as everything here: the lanes of a wave whose envs start at an event row take the tick + ETD3RK
+    // path below, in the same launch (envs in lockstep -- PVDER-v0 rollouts -- agree).
+    bool quiet = false;
+#ifndef PVDER_NO_WAVE_BAIL
+    if constexpr (!SPLIT) {          // (an env that leaves from the start -- off balance, forced: see the wave bail below)
+        if (__builtin_amdgcn_readfirstlane(__any((int)(run_all && defer)))) return true;
+    }
+#endif
+#ifndef PVDER_NO_K4
+    quiet = sg.seg >= C.n_sub && !sg.at_event && G.Lk.k4coef != nullptr;
+    if (__builtin_amdgcn_readfirstlane(__any((int)(run_all && !defer && quiet)))) {
+        if (!R.k4_ok) {
+            lin_load_k4(G.Lk.k4coef, lane, R.Ak);
+            R.k4_ok = true;
+        }
+        if (trace_step == 0) PVDER_TRACE_AT(3);
+        make_sub_pk(P, sg.in_vg, sg.in_si, S);
+        v4f Yn[3];
+        bool near;
+        const bool trip = lin_k4<PH>(G, R.Ak, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, near);
+        if (run_all && quiet) {
+            if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
+            Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
+        }
+    }
+#endif
+    const bool run = run_all && !quiet;          // (the lanes the tick + ETD3RK schedule below is for)
+    if (!__builtin_amdgcn_readfirstlane(__any((int)(run && !defer)))) {
+#ifndef PVDER_NO_WAVE_BAIL
+        if constexpr (!SPLIT) {          // (the lean first pass gives the WAVE up as soon as one of its envs leaves: see below)
+            if (__builtin_amdgcn_readfirstlane(__any((int)(run_all && defer)))) return true;
+        }
+#endif
+        return defer;
+    }
+    lin_need_t2(G, lane, R);
+    const LinMatRegs &At = R.At;
+    LinSetRegs &Ac = R.Ac;
+    int &cur = R.cur;
     int spos = 0;                        // sim time steps of the env step behind this lane
     bool start = true;                   // this lane is at the start of a segment (its tick is due)
     bool done = !run;
-    careful = false;
-    SubPk S;
     cur = __builtin_amdgcn_readfirstlane(cur);           // (wave-uniform by construction: tell hipcc)
     // ---- the standard env step, straight-line: every lane that runs has ONE segment (no event row change
     // inside the env step) covered by the tick and two steps of the resident set -- PVDER-v0 with its envs
@@ -2014,10 +2129,13 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
 // env step with.  Same frame as lin_integrate's general loop -- per-lane schedule rows (the careful ones), one pass
 // per distinct coefficient set, wave-uniform trip counts, a lane's arithmetic independent of its neighbours.
 template <int PH>
-__device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane, const pvder::LinMatRegs &At,
-                                                      pvder::LinSetRegs &Ac, int &cur, pvder::v4f (&Y)[3], float qref,
+__device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane, LinRegs &R, pvder::v4f (&Y)[3], float qref,
                                                       float vdcref, int ec, LinSeg sg, bool run, bool defer, float msc) {
     using namespace pvder;
+    lin_need_t2(G, lane, R);
+    const LinMatRegs &At = R.At;
+    LinSetRegs &Ac = R.Ac;
+    int &cur = R.cur;
     constexpr int kBig = 0x3fffffff;
     const ModelK<float> &P = G.A.P;
     const StepK<float> &C = G.A.C;
@@ -2107,8 +2225,8 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
 // KOFF: byte offset of G in the kernel-argument segment; fstate / istate / n_env: the copies the caller
 // holds (step_etdlin_kernel: preloaded into SGPRs by the dispatcher, see there).
 template <int PH, int KOFF>
-__device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
-                                              int &cur, const uint8_t *__restrict__ act, long long out_off, int stats_fresh,
+__device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinRegs &R,
+                                              const uint8_t *__restrict__ act, long long out_off, int stats_fresh,
                                               const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env,
                                               bool only = true) {
     using namespace pvder;
@@ -2155,7 +2273,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
         PVDER_TRACE_AT(2);
         bool careful;
         const bool defer0 = defer;          // (off balance / forced: the 23-state path whatever the standard pass finds)
-        defer = lin_integrate<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, careful, 0, msc);
+        defer = lin_integrate<PH>(G, lane, R, Y, L.qref, L.vdcref, L.ec, sg, L.run, defer, careful, 0, msc);
         PVDER_DBG_COUNT(0, L.run);
         PVDER_DBG_COUNT(1, L.run && defer && !careful);
         PVDER_DBG_COUNT(9, L.run && defer && careful);
@@ -2171,7 +2289,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, const 
             v4f Yc[3];
             lin_from_rows<PH>(ys, Yc);
             if (careful) { Y[0] = Yc[0]; Y[1] = Yc[1]; Y[2] = Yc[2]; }
-            const bool dc = lin_integrate_careful<PH>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, careful, false, msc);
+            const bool dc = lin_integrate_careful<PH>(G, lane, R, Y, L.qref, L.vdcref, L.ec, sg, careful, false, msc);
             defer |= careful && dc;
             PVDER_DBG_COUNT(3, careful && dc);
         }
@@ -2232,8 +2350,10 @@ struct LinHead {
     int32_t *istate;
     const uint8_t *action;
     const float *lcoef;
-    int n_env, ksub_hint;
+    int n_env, ksub_hint;            // ksub_hint: -1 = none; else the clock, | kLinHintQuiet when the env step that starts there is a QUIET one
+    const float *k4coef;
 };
+constexpr int kLinHintQuiet = 1 << 30;
 constexpr int kLinHeadBytes = (int)sizeof(LinHead);
 // lin_step_body / the 23-state tail re-read G (and G.A at its start) from the kernel-argument segment at this byte
 // offset: the by-value LinArgs must follow the head without padding, and the blocks the tails re-read sit at offset 0
@@ -2250,8 +2370,8 @@ static_assert(offsetof(LinArgs, A) == 0, "the 23-state tail reads EtdArgs at the
 // state rows kept for the careful pass's restart rode along on the standard path -- 8.3 -> 8.8 us per step).  Same
 // arithmetic for the envs that stay (msc = 1 is exact), same body for the ones that leave: bit-identical results.
 template <int PH, int KOFF>
-__device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const pvder::LinMatRegs &At, pvder::LinSetRegs &Ac,
-                                              int &cur, const uint8_t *__restrict__ act, int stats_fresh,
+__device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinRegs &R,
+                                              const uint8_t *__restrict__ act, int stats_fresh,
                                               const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env,
                                               int ksub_hint) {
     using namespace pvder;
@@ -2296,7 +2416,7 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const 
         lin_from_rows<PH>(ys, Y);
         PVDER_TRACE_AT(2);
         bool careful;
-        leave = lin_integrate<PH, false>(G, lane, At, Ac, cur, Y, L.qref, L.vdcref, L.ec, sg, L.run, leave, careful, 0) && L.run;
+        leave = lin_integrate<PH, false>(G, lane, R, Y, L.qref, L.vdcref, L.ec, sg, L.run, leave, careful, 0) && L.run;
         if (L.run && !leave) {
             lin_to_rows<PH>(Y, ys);
             L.ksub += A.C.n_sub;
@@ -2316,7 +2436,7 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, const 
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
-                                                             const float *lcoef, int n_env, int ksub_hint, const LinArgs G) {
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
     using namespace pvder;
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
@@ -2324,17 +2444,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     // an env needs it (an env off the event grid).  Issued FIRST (they depend on nothing but the kernel
     // arguments), the state rows right behind them: one memory latency.
     const int lane = threadIdx.x & 63;
-    LinMatRegs At;
-    LinSetRegs Ac;
+    // (round 4) ... or, where the plan expects a QUIET env step -- no event row change at its start: three of four PVDER-v0
+    // steps --, the Krogstad block alone (lin_k4); what a lane needs beyond that is loaded where it is needed
+    const int ksub_hint = ksub_word < 0 ? -1 : (ksub_word & (kLinHintQuiet - 1));
+    LinRegs R;
     PVDER_TRACE_DEP(18, (float)n_env);                  // (trace builds: the leading kernel arguments are there)
-    lin_load_mat(lcoef, lane, At);
-    lin_load_set(lcoef + kLinMatFloats, lane, Ac);
-    PVDER_TRACE_DEP(19, At[0] + Ac[5][2]);               // (... the coefficient registers are loaded)
-    int cur = 1;
+    if (ksub_word >= 0 && (ksub_word & kLinHintQuiet) != 0 && k4coef != nullptr) {
+        lin_load_k4(k4coef, lane, R.Ak);
+        R.k4_ok = true; R.at_ok = false; R.cur = 0;
+        PVDER_TRACE_DEP(19, R.Ak[0][0] + R.Ak[9][2]);
+    } else {
+        lin_load_mat(lcoef, lane, R.At);
+        lin_load_set(lcoef + kLinMatFloats, lane, R.Ac);
+        R.k4_ok = false; R.at_ok = true; R.cur = 1;
+        PVDER_TRACE_DEP(19, R.At[0] + R.Ac[5][2]);       // (... the coefficient registers are loaded)
+    }
 #ifdef PVDER_NO_LEAN
-    lin_step_body<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, 0, G.A.stats_fresh, fstate, istate, n_env);
+    lin_step_body<PH, kLinHeadBytes>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
 #else
-    const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, At, Ac, cur, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
+    const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, R, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
     if (__syncthreads_or((int)leave)) {
         // (rare: every argument again through a laundered copy of the kernarg pointer -- nothing of this pass stays
         // live across the lean one)
@@ -2343,7 +2471,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         LinKernargPtr kc = (LinKernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + kLinHeadBytes);
         asm volatile("" : "+s"(kc));
         const LinArgs &Gc = *(const LinArgs *)kc;
-        lin_step_body<PH, kLinHeadBytes>(Gc, lane, At, Ac, cur, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
+        LinRegs Rc;                      // (its coefficient registers too: loaded where the pass needs them)
+        Rc.at_ok = false; Rc.cur = 0; Rc.k4_ok = false;
+        lin_step_body<PH, kLinHeadBytes>(Gc, lane, Rc, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
     }
 #endif
 }
@@ -2386,11 +2516,14 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
     constexpr int NS = 6 * PH + 5;
     if (Q.Rk.resume && Q.Rk.progress[blockIdx.x] >= Q.Rk.n_steps) return;      // (workgroup-uniform) nothing left
     const int lane = threadIdx.x & 63;
-    LinMatRegs At;
-    LinSetRegs Ac;
-    lin_load_mat(Q.G.Lk.lcoef, lane, At);
-    lin_load_set(Q.G.Lk.lcoef + kLinMatFloats, lane, Ac);
-    int cur = 1;
+    LinRegs R;                        // tick matrix, first ETD3RK set and Krogstad block resident for the whole rollout
+    lin_load_mat(Q.G.Lk.lcoef, lane, R.At);
+    lin_load_set(Q.G.Lk.lcoef + kLinMatFloats, lane, R.Ac);
+    R.at_ok = true; R.cur = 1; R.k4_ok = false;
+    if (Q.G.Lk.k4coef != nullptr) {
+        lin_load_k4(Q.G.Lk.k4coef, lane, R.Ak);
+        R.k4_ok = true;
+    }
     const int e = blockIdx.x * kBlock + threadIdx.x;
     v4f Y[3];
     float qref, vdcref;
@@ -2470,7 +2603,7 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             else if (a != 0) bad = 1.f;
             if (!__builtin_amdgcn_readfirstlane(__any((int)leave))) {
                 bool careful;          // (an env at the current limit leaves too: its step belongs to the per-step body's careful pass)
-                leave = lin_integrate<PH, false>(Q1.G, lane, At, Ac, cur, Y, qref, vdcref, ec, sg, true, false, careful, traced ? 0 : 1);
+                leave = lin_integrate<PH, false>(Q1.G, lane, R, Y, qref, vdcref, ec, sg, true, false, careful, traced ? 0 : 1);
             }
             if (traced) PVDER_TRACE_DEP(20, Y[0].x + Y[2].z);
             float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
@@ -2549,9 +2682,9 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
 
 template <int PH>
 __global__ __launch_bounds__(kBlock)
-#ifndef PVDER_ROLLOUT_OCC2
-__attribute__((amdgpu_waves_per_eu(3)))      // 168 VGPRs: three waves per SIMD for batches beyond 131 072 envs
-#endif
+#ifdef PVDER_ROLLOUT_OCC3
+__attribute__((amdgpu_waves_per_eu(3)))      // 168 VGPRs: three waves per SIMD for batches beyond 131 072 envs (rounds 2-3; with the
+#endif                                       // Krogstad block resident next to the ETD3RK set the loop needs ~200: two waves per SIMD)
 void step_etdlin_rollout_kernel(const RollArgs Q) { rollout_body<PH, false>(Q); }
 
 template <int PH>
@@ -2578,12 +2711,9 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
                 for (int q = 0; q < PVDER_OROWS; ++q) o[(size_t)q * N + e] = (o - Rk.out_stride)[(size_t)q * N + e];
             }
         }
-        LinMatRegs At;
-        LinSetRegs Ac;
-        lin_load_mat(G.Lk.lcoef, lane, At);
-        lin_load_set(G.Lk.lcoef + kLinMatFloats, lane, Ac);
-        int cur = 1;
-        lin_step_body<PH, 0>(G, lane, At, Ac, cur, AG ? Rk.ag_action : Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1,
+        LinRegs R;
+        R.at_ok = false; R.cur = 0; R.k4_ok = false;       // (loaded where the step needs them)
+        lin_step_body<PH, 0>(G, lane, R, AG ? Rk.ag_action : Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1,
                              G.A.fstate, G.A.istate, G.A.n_env);
         if constexpr (AG) {
             // the agent step behind this env step, from the output block the step has just written (this lane's own
@@ -3466,6 +3596,9 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         // against ABI 10) would silently drop what an anti-windup episode leaves in the controller's integrators
         if (p.ph == 3 && !(lin->seq_prop[8] > 0.f && lin->seq_prop[8] <= 1.f)) return PVDER_EINVAL;
         for (int k = 0; k < 18; ++k) K.seqE[k] = lin->seq_prop[k];
+        // the Krogstad block of the quiet env step sits behind the sets (pvder_lin_coef.k4; PVDER_NO_K4=1: A/B runs without it)
+        static const bool no_k4 = []() { const char *v = getenv("PVDER_NO_K4"); return v && v[0] == '1'; }();
+        K.k4coef = (lin->k4 != 0 && !no_k4) ? lin->sets + pvder::kLinMatFloats + (size_t)(lin->n_sets - 1) * pvder::kLinSetFloats : nullptr;
     }
     return 0;
 }
@@ -3477,6 +3610,27 @@ void advance_hint(const pvder_plan &p, int steps) {
     if (p.R.enabled) k %= p.episode_steps;
     else if (k > p.episode_steps) k = p.episode_steps;        // (finished, not running: whatever)
     p.ksub_hint = (int)k * p.n_sub;
+}
+
+// the hint as the step kernel takes it: the clock, and whether the env step that starts there is a quiet one (one segment, no
+// event row change at its start: lin_first_segment) -- which coefficient registers the launch loads first
+int hint_word(const pvder_plan &p) {
+    const int k = p.ksub_hint;
+    if (k < 0) return -1;
+    const StepK<float> &C = p.lin.A.C;
+    bool at_event = false;
+    int until = 0x3fffffff;
+    if (C.ev_count > 0) {
+        const int d = k - C.ev_s0;
+        if (d < 0) until = -d;
+        else {
+            const int qd = d / C.ev_ds, rd = d - qd * C.ev_ds;
+            until = qd + 1 < C.ev_count ? C.ev_ds - rd : 0x3fffffff;
+            at_event = rd == 0 && qd < C.ev_count;
+        }
+    }
+    const bool quiet = p.lin.Lk.k4coef != nullptr && !at_event && until >= C.n_sub;
+    return quiet ? (k | kLinHintQuiet) : k;
 }
 
 int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *action,
@@ -3504,9 +3658,9 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         // (none in PVDER-v0 rollouts).
         if (p.integrator == PVDER_INT_ETDLIN) {
             if (p.ph == 3)
-                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, p.ksub_hint, G);
+                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G);
             else
-                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, p.ksub_hint, G);
+                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G);
             advance_hint(p, 1);
         } else {
             if (p.ph == 3 && p.lane_par) hipLaunchKernelGGL(step_etdrk4_lane_kernel, grid, block, 0, st, A, p.lane_par);

@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -71,7 +71,8 @@ class QAgentCfg(C.Structure):
 class LinCoef(C.Structure):
     """``struct pvder_lin_coef`` (include/pvder_hip.h)."""
     _fields_ = [("sets", C.c_void_p), ("n_sets", C.c_int32), ("len_ticks", C.c_int32 * LIN_MAX_SETS),
-                ("sched", C.c_void_p), ("est_guard", C.c_float), ("n_sched_rows", C.c_int32), ("seq_prop", C.c_float * 18)]
+                ("sched", C.c_void_p), ("est_guard", C.c_float), ("n_sched_rows", C.c_int32), ("seq_prop", C.c_float * 18),
+                ("k4", C.c_int32)]
 
 
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs (the VALU code reads them without

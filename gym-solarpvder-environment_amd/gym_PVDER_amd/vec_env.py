@@ -492,13 +492,16 @@ class PVDERVec(EnvSpecMixin):
         schedule changes."""
         lens = etd_linear.choose_sets(cfg.n_sub, cfg.micro, cfg.ev_s0, cfg.ev_ds, cfg.ev_count, cfg.max_ksub,
                                       _native.LIN_MAX_SETS)
+        # the quiet env step (no event row change at its start) as ONE Krogstad step: its block sits behind the sets
+        k4_h = etd_linear.quiet_step_length(cfg.n_sub)
         key = (self.der_id if not (self.der_config or self.model_options) else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, tuple(lens))
         if getattr(self, "_lin_key", None) != key:
-            host = PVDERVec._lin_cache.get(key[:2] + key[3:])
+            host = PVDERVec._lin_cache.get(key)
             if host is None:
-                host = etd_linear.build_coefficients(self.par, self.der_id, cfg.micro, lens)
-                PVDERVec._lin_cache[key[:2] + key[3:]] = host
-            assert host.size == etd_linear.MAT_FLOATS + (len(lens) - 1) * self._lib.pvder_lin_set_floats()
+                host = etd_linear.build_coefficients(self.par, self.der_id, cfg.micro, lens, k4_h)
+                PVDERVec._lin_cache[key] = host
+            assert host.size == etd_linear.MAT_FLOATS + (len(lens) - 1) * self._lib.pvder_lin_set_floats() \
+                + (etd_linear.N_K4_MATS * etd_linear.MAT_FLOATS if k4_h > 0.0 else 0)
             self._lin_dev = torch.from_numpy(host).to(self.device)
             sched = etd_linear.build_schedule(cfg.n_sub, cfg.micro, lens)
             self._lin_sched = torch.from_numpy(sched).to(self.device)
@@ -511,6 +514,7 @@ class PVDERVec(EnvSpecMixin):
         for k, t in enumerate(lens):
             lc.len_ticks[k] = int(math.ceil(t))      # (informational: the careful pass's set may end on a fraction of a tick)
         lc.est_guard = self.est_guard
+        lc.k4 = 1 if k4_h > 0.0 else 0
         if self.phases == 3:
             if getattr(self, "_seq_key", None) != key[:3]:       # (a steady state + an eig: cached with the coefficient block)
                 self._seq_E, self._seq_key = etd_linear.seq_propagator(self.par, self.der_id, cfg.n_sub), key[:3]

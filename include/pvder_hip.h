@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 13
+#define PVDER_ABI_VERSION 14
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -271,6 +271,12 @@ typedef struct pvder_lin_coef {
                               * zero-sequence component (i, x, u) of an env slightly off balance, which the kernel carries on
                               * the matrix-core path by its positive-sequence component (etd_linear.py::seq_propagator);
                               * all zero: such components are dropped at the end of the step -- do not */
+    int32_t k4;              /* (ABI 14) != 0: 10 * PVDER_LIN_MAT_FLOATS more floats follow the sets in `sets` -- the f-form matrices
+                              * M21 | M31 M32 | M41 M42 M43 | B1 B2 B3 B4 of ONE Krogstad ETDRK4 step of n_sub / 60 s
+                              * (etd_linear.py::k4_f_matrices).  An env step that is one segment and does not start at an event row
+                              * change (a new action at most: no input jump the stiff loop rings from) is then taken as that one
+                              * step, without tick: 4 right-hand sides instead of 7 at unchanged accuracy (tools/scheme_proto.py).
+                              * 0: every segment by tick + ETD3RK steps (the schedule table) */
 } pvder_lin_coef;
 int pvder_lin_set_floats(void);
 int pvder_lin_max_sets(void);

@@ -108,6 +108,38 @@ def test_f_form_equals_n_form(lin50):
     assert all(not np.any(M) for M in el.etd3rk_f_matrices(L, 0.0))
 
 
+def test_krogstad_f_form_equals_n_form(lin50):
+    """The quiet env step's ONE Krogstad ETDRK4 step (el.k4_f_matrices / k4_step, csrc lin_k4): its f-form is the textbook
+    N-form; its non-stiff limit is the classic RK4 tableau; one step over an env step behind an action's jump is within
+    2e-6 of LSODA."""
+    from scipy.integrate import solve_ivp
+    par, c, L, ystar = lin50
+    rng = np.random.default_rng(2)
+    inp = (1.01, 92.0, 0.03, par[der_model.IDX["VDC_REF0"]] * 1.002)
+    for h in (1 / 60, 0.25):
+        y = ystar * (1 + 1e-3 * rng.standard_normal(11))
+        got, u4 = el.k4_step(c, el.k4_f_matrices(L, h), y, inp)
+        Es, A, E, B = el.krogstad_tableau(L, h)
+        N = lambda u: el.f_bal(c, u, *inp) - L @ u
+        N1 = N(y); U2 = Es[1] @ y + A[1][0] @ N1
+        N2 = N(U2); U3 = Es[2] @ y + A[2][0] @ N1 + A[2][1] @ N2
+        N3 = N(U3); U4 = Es[3] @ y + A[3][0] @ N1 + A[3][2] @ N3
+        N4 = N(U4)
+        want = E @ y + B[0] @ N1 + B[1] @ N2 + B[2] @ N3 + B[3] @ N4
+        assert np.allclose(got, want, rtol=0, atol=2e-9) and np.allclose(u4, U4, rtol=0, atol=2e-9)
+    M = el.k4_f_matrices(np.zeros((11, 11)), 0.1)
+    I = np.eye(11)
+    for Mk, w in zip(M, (0.05, 0.0, 0.05, 0.0, 0.0, 0.1, 0.1 / 6, 0.1 / 3, 0.1 / 3, 0.1 / 6)):
+        assert np.allclose(Mk, w * I, atol=1e-14)
+    # accuracy where it is used: an env step of 0.25 s behind an action-sized jump of Q_ref or Vdc_ref, against LSODA
+    for inp in ((1.0, 100.0, 25.0 * 15 / 50e3, par[der_model.IDX["VDC_REF0"]]), (1.0, 100.0, 0.0, par[der_model.IDX["VDC_REF0"]] + 0.02 * 15 / 500.0)):
+        ref = solve_ivp(lambda t, u: el.f_bal(c, u, *inp), (0, 0.25), ystar, method="LSODA", rtol=1e-12, atol=1e-14).y[:, -1]
+        one, _ = el.k4_step(c, el.k4_f_matrices(L, 0.25), ystar, inp)
+        sel = [0, 1, 6, 7, 8]
+        assert np.linalg.norm((one - ref)[sel]) / np.linalg.norm(ref[sel]) < 2e-6
+    assert el.quiet_step_length(15) == 0.25 and el.quiet_step_length(16) == 0.0 and el.quiet_step_length(1) == 1 / 60
+
+
 @pytest.mark.parametrize("n_sub,micro,s0,ds", [(15, 32, 60, 60), (4, 32, 60, 60), (15, 32, 12, 12), (1, 32, 60, 60),
                                                 (7, 16, 5, 3), (60, 32, 60, 60), (15, 1, 60, 60)])
 def test_step_menu_tiles_every_segment(n_sub, micro, s0, ds):
@@ -212,7 +244,7 @@ def test_fp32_emulation_of_the_kernel_arithmetic_vs_golden(lin50, name):
         return np.array([i.real, i.imag, va.real, va.imag, S.real, S.imag, y[6], ppv, v, q])
 
     rowof = lambda gk: 0 if gk < s0 else min((gk - s0) // ds + 1, K)
-    out, ksub, est = [observe(y, vgt[0], sit[0], q, v)], 0, 0.0
+    out, ksub, est, quiet = [observe(y, vgt[0], sit[0], q, v)], 0, 0.0, 0
     for a in acts:
         q = f32(q + dq * (int(a == 1) - int(a == 2))); v = f32(v + dv * (int(a == 3) - int(a == 4)))
         s = 0
@@ -221,16 +253,27 @@ def test_fp32_emulation_of_the_kernel_arithmetic_vs_golden(lin50, name):
             while e < n and rowof(ksub + e) == row:
                 e += 1
             inp = (vgt[row], sit[row], q, v)
-            y = el.euler_tick(c, P1, y, inp, np.float32)                  # the tick (2/1920 s) behind the jump
-            for _ in range(2):                                            # then two equal ETD3RK steps
-                y, b = el.etd3rk_step(c, mats(((e - s) * 32 - 2) / 2 / 1920.0), y, inp, np.float32)
+            at_event = row > 0 and ksub + s == s0 + (row - 1) * ds
+            k4_h = el.quiet_step_length(n)
+            if s == 0 and e == n and not at_event and k4_h > 0:
+                # a QUIET env step (one segment, a new action at most at its start): ONE Krogstad step, no tick (csrc lin_k4)
+                if "k4" not in cache:
+                    cache["k4"] = el.k4_f_matrices(L, k4_h)
+                y, b = el.k4_step(c, cache["k4"], y, inp, np.float32)
                 est = max(est, float(np.abs((y - b)[[0, 1, 6]]).max()))
+                quiet += 1
+            else:
+                y = el.euler_tick(c, P1, y, inp, np.float32)              # the tick (2/1920 s) behind the jump
+                for _ in range(2):                                        # then two equal ETD3RK steps
+                    y, b = el.etd3rk_step(c, mats(((e - s) * 32 - 2) / 2 / 1920.0), y, inp, np.float32)
+                    est = max(est, float(np.abs((y - b)[[0, 1, 6]]).max()))
             s = e
         ksub += n
         out.append(observe(y, vgt[rowof(ksub)], sit[rowof(ksub)], q, v))
     got, want = np.array(out), g["obs"][:len(out), :10]
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-6
     assert est < el.EST_GUARD / 10                   # these cases stay far from the hand-over guard
+    assert quiet > len(acts) // 2 or n != 15         # PVDER-v0: three env steps in four are quiet ones
 
 
 def test_etdlin64_step_doubling_reference_vs_golden(lin50):
