@@ -52,6 +52,7 @@ BYTES_PER_ENV_STEP = {"f32": 269, "f64": 533}      # three-phase
 #  matrix cores (242 flop each); the tick = 1 evaluation + 1 product)
 FLOP_PER_STEP = {"rk4": 1201, "etdrk4": 907, "etdlin": 3 * 70 + 6 * 242}
 FLOP_PER_TICK = 70 + 242
+FLOP_PER_K4 = 4 * 70 + 10 * 242       # (round 4: the quiet env step as ONE Krogstad step: 4 evaluations, 10 products, no tick)
 INSTR_PER_STEP = {"etdrk4": 396}
 DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1}
 KERNEL_NAME = {"etdlin": "step_etdlin_kernel", "etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel",
@@ -841,6 +842,12 @@ def run_rank(args):
             # when n_sub divides 60: one segment per env step)
             segs = 1.0 + (0 if 60 % args.n_sub == 0 else (args.n_sub - 1) / 60.0)
             steps_per_env_step = 2.0 * segs
+            # ... and an env step that does not start at an event row change (n_sub / 60 s <= 0.25 s: all but one per second)
+            # is ONE Krogstad step without tick
+            quiet_frac = 0.0
+            if 60 % args.n_sub == 0 and args.n_sub <= 15 and not os.environ.get("PVDER_NO_K4"):
+                quiet_frac = 1.0 - args.n_sub / 60.0
+                steps_per_env_step = 2.0 * (1.0 - quiet_frac) + 1.0 * quiet_frac
         elif args.integrator == "etdrk4":
             n_fine = 1.0 + (args.n_sub - 1) / 60.0
             steps_per_env_step = n_fine * (2 if env.graded else args.micro) + (args.n_sub - n_fine) * env.micro_coarse \
@@ -856,7 +863,7 @@ def run_rank(args):
                 fps = 7 * 300 + 23 * 60
         flops = fps * steps_per_env_step * N / avg_kern_s if (fps and avg_kern_s) else None
         if flops and args.integrator == "etdlin":
-            flops += FLOP_PER_TICK * segs * N / avg_kern_s
+            flops = ((1.0 - quiet_frac) * (2.0 * fps + FLOP_PER_TICK) * segs + quiet_frac * FLOP_PER_K4) * N / avg_kern_s
         traffic, traffic_src = pmc_traffic(KERNEL_NAME[args.integrator], N)
         valu_peak = VALU_PEAK_F64 if prec == "f64" else VALU_PEAK_F32
         out = {
@@ -871,7 +878,8 @@ def run_rank(args):
                                    % (N, args.n_sub, {"etdlin": "fp32 ETD3RK on the full nonlinear model, f = L y + N(y) (exponential RK: the 11x11 Jacobian at the "
                                                                 "operating point in the exponential, N in the stages; matrix-vector products on the matrix cores), "
                                                                 "per segment between input jumps: exponential-Euler tick of 2/(60*%d) s + two "
-                                                                "equal ETD3RK steps" % args.micro,
+                                                                "equal ETD3RK steps; an env step that does not start at an event row change "
+                                                                "(three in four): ONE Krogstad ETDRK4 step, no tick" % args.micro,
                                                       "etdrk4": ("fp32 ETDRK4 (exponential RK, stiff order 4, 5 stages), sim time step behind an input jump: "
                                                                  + ("first step 1/(60*%d) s + one over the remainder" if env.graded else "%d uniform steps")
                                                                  + ", every other one: %d step(s)") % (args.micro, env.micro_coarse or args.micro),
