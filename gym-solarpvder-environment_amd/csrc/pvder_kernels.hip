@@ -886,6 +886,181 @@ __device__ __forceinline__ float etd_switched_step(const ModelK<float> &P, const
 #undef PVDER_MP
 }
 
+// =============================================================================================
+// The 23-state ETDRK4 step with an env's three PHASES ON THREE LANES (round 4; step_etdrk4_lane_kernel).  The (i_p, x_p, u_p)
+// triple of phase p lives in lane p of a QUAD (lane 3 mirrors phase a and is left out of every sum); the five shared states
+// (Vdc, xDC, xQ, xPLL, delta) are carried by all four lanes, which compute them from the same operands in the same order --
+// bit-equal by construction.  What couples the phases crosses the quad by DPP (quad_perm broadcasts: no LDS, no barrier): the
+// three power sums and the phase currents the PLL's sequence components need.  A wave's instruction stream per step drops
+// from the three phases' 39 operator products + five full right-hand sides to one phase's 13 + five reduced ones (~0.6 x),
+// and a batch gives four times the waves: the lone wave per SIMD of the one-lane-per-env form becomes four.
+// Same scheme, same operator sets, same guards as etd_switched_step / etd_eval (which stay the tail of the step kernels).
+// =============================================================================================
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {       // lane K of the quad, to all four
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ v2 quad_bcast2(v2 v) { return pvder::mk2(quad_bcast<K>(v.x), quad_bcast<K>(v.y)); }
+// sum / max over the three phase lanes, the same value (bit for bit) in every lane of the quad
+__device__ __forceinline__ float quad_sum3(float v) { return (quad_bcast<0>(v) + quad_bcast<1>(v)) + quad_bcast<2>(v); }
+__device__ __forceinline__ float quad_max3(float v) { return fmaxf(fmaxf(quad_bcast<0>(v), quad_bcast<1>(v)), quad_bcast<2>(v)); }
+
+struct Phase3 {             // what a lane holds of its env
+    v2 i, x, u;             // its phase
+    v2 s0, s1, s2;          // (Vdc, xDC), (xQ, xPLL), (delta, 0): shared
+};
+struct PhaseK {             // per-lane constants of its phase
+    v2 Asw, D;              // SubPk::Asw[p], D[p]
+    v2 rot;                 // (cos, sin) of the phase's rotation: 0, -120, +120 degrees
+};
+
+// N(y) of one phase + the shared slow derivatives: ni / nu = N_i / N_u of the lane's phase, nx = dx_p/dt,
+// n0 = d(Vdc, xDC), n1 = d(xQ, xPLL), n2 = d(delta, 0).  Returns the lane's |m_p|^2.
+__device__ __forceinline__ float etd_eval3(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec, const pvder::SubPk &S,
+                                           const PhaseK &Q, const Phase3 &y, float th2t, float qref, float vdcref,
+                                           v2 &ni, v2 &nu, v2 &nx, v2 &n0, v2 &n1, v2 &n2) {
+    using namespace pvder;
+    const float Vdc = y.s0.x, xDC = y.s0.y, xQ = y.s1.x, xPLL = y.s1.y, delta = y.s2.x;
+    const v2 m = fma2(bc2(P.KpG), y.u, y.x);
+    const v2 aP = m * y.i, aQ = Q.Asw * y.i, aI = y.i * y.i;
+    const float Pt = quad_sum3(aP.x + aP.y);
+    const float Qs = quad_sum3(aQ.x + aQ.y);
+    const float Is = quad_sum3(aI.x + aI.y);
+    const float Qpcc = 0.5f * Qs + K.qk * Is;
+    const float qerr = qref - Qpcc;
+    const float iarR = xDC + P.KpDC * (vdcref - Vdc);
+    const float iarI = xQ - P.KpQ * qerr;
+    float s1, c1, s2, c2;
+    const float dturn = delta * (float)(1.0 / kTwoPi);
+    Math<float>::sincos_turns(dturn, s1, c1);
+    Math<float>::sincos_turns(th2t + dturn, s2, c2);
+    // the PLL sees the positive- and negative-sequence components of the PCC voltage: all three phase currents
+    const v2 ia = quad_bcast2<0>(y.i), ib = quad_bcast2<1>(y.i), ic = quad_bcast2<2>(y.i);
+    const v2 sb = ib + ic, db = ib - ic;
+    const v2 base = fma2(bc2(-0.5f), sb, ia);
+    const v2 jh3 = mk2(-kHalfSqrt3, kHalfSqrt3);
+    const v2 rdb = swp(db) * jh3;
+    const v2 i1 = base + rdb, i2 = base - rdb;
+    const v2 jk3 = mk2(-P.kvi3I, P.kvi3I);
+    v2 V1 = fma2(bc2(P.kvi3R), i1, S.A0); V1 = fma2(jk3, swp(i1), V1);
+    v2 V2c = mk2(P.kvi3R, -P.kvi3R) * i2; V2c = fma2(bc2(-P.kvi3I), swp(i2), V2c);
+    const v2 t1 = V1 * mk2(c1, s1);
+    const v2 t2 = fma2(V2c, mk2(c2, s2), t1);
+    const float vd = t2.x + t2.y;
+    const float dw = P.KpP * vd + xPLL;
+    const float dwr = dw * P.iwb;
+    const float cmf = K.hiLf * Vdc;
+    v2 n = fma2(bc2(cmf), y.x, Q.D);
+    n = fma2(bc2(cmf * P.KpG - Ec.c0kp), y.u, n);
+    ni = fma2(mk2(dwr, -dwr), swp(y.i), n);
+    // N_u = wp * iref_p,  iref_p = iref_a rotated into the lane's phase
+    const v2 wra = mk2(P.wp * iarR, P.wp * iarI);
+    nu = mk2(Q.rot.x * wra.x - Q.rot.y * wra.y, Q.rot.y * wra.x + Q.rot.x * wra.y);
+    nx = bc2(P.KiG) * y.u;
+    const float ppv = ppv_of(P, S.pv1, Vdc);
+    const float ReS = 0.25f * Vdc * Pt;
+    const float dVdc = (ppv - ReS) * Math<float>::rcp(Vdc) * P.iC;
+    float dxDC = P.KiDC * (vdcref - Vdc);
+    float dxQ = -P.KiQ * qerr;
+    if (iarR * iarR + iarI * iarI > P.ilim2) {
+        dxDC = (dxDC * xDC > 0.f) ? 0.f : dxDC;
+        dxQ = (dxQ * xQ > 0.f) ? 0.f : dxQ;
+    }
+    n0 = mk2(dVdc, dxDC);
+    n1 = mk2(dxQ, P.KiP * vd);
+    n2 = mk2(dw, 0.f);
+    const v2 mm = m * m;
+    return mm.x + mm.y;
+}
+
+// the model's sign tests on dx_p/dt at a stage state, and the frozen rows of N_u (the lane's phase; `mode`: its two bits)
+__device__ __forceinline__ void sw_mask3(const ModelK<float> &P, v2 x, v2 u, int mode, v2 &nu, v2 &nx) {
+    using namespace pvder;
+    const v2 m = fma2(bc2(P.KpG), u, x);
+    if (__builtin_fmaf(m.y, m.y, m.x * m.x) > P.mlim2) {
+        nx.x = nx.x * x.x > 0.f ? 0.f : nx.x;
+        nx.y = nx.y * x.y > 0.f ? 0.f : nx.y;
+    }
+    if (mode & 1) nu.x = 0.f;
+    if (mode & 2) nu.y = 0.f;
+}
+
+// one ETDRK4 step (etd_switched_step, a phase per lane); comp: Kahan compensation of (x, s0, s1, s2).  Returns the largest
+// |m_p|^2 of the ENV at the start and at the end of the step (the same in the quad's lanes).
+__device__ __forceinline__ float etd_switched_step3(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
+                                                    const pvder::SubPk &S, const PhaseK &Q, Phase3 &y, v2 (&comp)[4],
+                                                    const lds_v4 *Mset, float h, float t0, float tq, float qref, float vdcref) {
+    using namespace pvder;
+    const v2 h2 = bc2(0.5f * h), h4 = bc2(0.25f * h), h8 = bc2(0.125f * h), h6 = bc2(h * (float)(1.0 / 6.0)),
+             h23 = bc2(h * (float)(2.0 / 3.0));
+    const float t1 = t0 + 0.5f * tq, t2 = t0 + tq;
+    v2 n1i, n1u, ni, nu;
+    v2 ns1[4], nsl[4], s23[4], k14[4];        // slow derivatives: x, s0, s1, s2
+    const float m2a = etd_eval3(P, K, Ec, S, Q, y, t0, qref, vdcref, n1i, n1u, ns1[0], ns1[1], ns1[2], ns1[3]);       // N1
+    int mode = 0;
+    {
+        const v2 m = fma2(bc2(P.KpG), y.u, y.x);
+        const v2 du = fma2(bc2(-P.wp), y.i + y.u, n1u);                                    // wp (iref_p - i_p - u_p)
+        mode = __builtin_fmaf(m.y, m.y, m.x * m.x) > P.mlim2 ? ((du.x * y.u.x > 0.f ? 1 : 0) | (du.y * y.u.y > 0.f ? 2 : 0)) : 0;
+    }
+    const lds_v4 *Mp = Mset + mode;
+    sw_mask3(P, y.x, y.u, mode, n1u, ns1[0]);
+    v2 e2i = bc2(0.f), e2u = bc2(0.f), ei = bc2(0.f), eu = bc2(0.f);
+    matvec16(load_mat16(Mp, EM_E2), y.i, y.u, e2i, e2u);
+    matvec16(load_mat16(Mp, EM_E), y.i, y.u, ei, eu);
+    Phase3 yt;
+    yt.i = e2i; yt.u = e2u;
+    matvec16(load_mat16(Mp, EM_A21), n1i, n1u, yt.i, yt.u);                               // U2
+    v2 u3i = e2i, u3u = e2u, u4i = ei, u4u = eu, u5i = e2i, u5u = e2u, zi = ei, zu = eu;
+    matvec16(load_mat16(Mp, EM_A31), n1i, n1u, u3i, u3u);
+    matvec16(load_mat16(Mp, EM_A41), n1i, n1u, u4i, u4u);
+    matvec16(load_mat16(Mp, EM_A51), n1i, n1u, u5i, u5u);
+    matvec16(load_mat16(Mp, EM_B1), n1i, n1u, zi, zu);
+    yt.x = fma2(h2, ns1[0], y.x); yt.s0 = fma2(h2, ns1[1], y.s0); yt.s1 = fma2(h2, ns1[2], y.s1); yt.s2 = fma2(h2, ns1[3], y.s2);
+    etd_eval3(P, K, Ec, S, Q, yt, t1, qref, vdcref, ni, nu, nsl[0], nsl[1], nsl[2], nsl[3]);                        // N2
+    sw_mask3(P, yt.x, yt.u, mode, nu, nsl[0]);
+    v2 n23i = ni, n23u = nu;
+    matvec16(load_mat16(Mp, EM_A32), ni, nu, u3i, u3u);                                   // U3
+    yt.i = u3i; yt.u = u3u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s23[q] = nsl[q];
+    yt.x = fma2(h2, nsl[0], y.x); yt.s0 = fma2(h2, nsl[1], y.s0); yt.s1 = fma2(h2, nsl[2], y.s1); yt.s2 = fma2(h2, nsl[3], y.s2);
+    etd_eval3(P, K, Ec, S, Q, yt, t1, qref, vdcref, ni, nu, nsl[0], nsl[1], nsl[2], nsl[3]);                        // N3
+    sw_mask3(P, yt.x, yt.u, mode, nu, nsl[0]);
+    n23i += ni; n23u += nu;
+    matvec16(load_mat16(Mp, EM_A42), n23i, n23u, u4i, u4u);                               // U4
+    matvec16(load_mat16(Mp, EM_A52), n23i, n23u, u5i, u5u);
+    yt.i = u4i; yt.u = u4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s23[q] += nsl[q];
+    yt.x = fma2(h2, s23[0], y.x); yt.s0 = fma2(h2, s23[1], y.s0); yt.s1 = fma2(h2, s23[2], y.s1); yt.s2 = fma2(h2, s23[3], y.s2);
+    etd_eval3(P, K, Ec, S, Q, yt, t2, qref, vdcref, ni, nu, nsl[0], nsl[1], nsl[2], nsl[3]);                        // N4
+    sw_mask3(P, yt.x, yt.u, mode, nu, nsl[0]);
+    matvec16(load_mat16(Mp, EM_A54), ni, nu, u5i, u5u);                                   // U5
+    matvec16(load_mat16(Mp, EM_B4), ni, nu, zi, zu);
+    yt.i = u5i; yt.u = u5u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k14[q] = ns1[q] + nsl[q];
+    yt.x = fma2(h8, s23[0], fma2(h4, ns1[0], y.x)); yt.s0 = fma2(h8, s23[1], fma2(h4, ns1[1], y.s0));
+    yt.s1 = fma2(h8, s23[2], fma2(h4, ns1[2], y.s1)); yt.s2 = fma2(h8, s23[3], fma2(h4, ns1[3], y.s2));
+    etd_eval3(P, K, Ec, S, Q, yt, t1, qref, vdcref, ni, nu, nsl[0], nsl[1], nsl[2], nsl[3]);                        // N5
+    sw_mask3(P, yt.x, yt.u, mode, nu, nsl[0]);
+    matvec16(load_mat16(Mp, EM_B5), ni, nu, zi, zu);
+    // Kahan-compensated slow update:  y+ = y + h (N1 + N4)/6 + 2h N5/3
+    auto kahan = [&](v2 &yq, v2 &cq, v2 n5, v2 n14) {
+        const v2 inc = fma2(h23, n5, fma2(h6, n14, -cq));
+        const v2 tsum = yq + inc;
+        cq = (tsum - yq) - inc;
+        yq = tsum;
+    };
+    kahan(y.x, comp[0], nsl[0], k14[0]); kahan(y.s0, comp[1], nsl[1], k14[1]);
+    kahan(y.s1, comp[2], nsl[2], k14[2]); kahan(y.s2, comp[3], nsl[3], k14[3]);
+    y.i = zi; y.u = zu;
+    const v2 mn = fma2(bc2(P.KpG), y.u, y.x);
+    return quad_max3(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
+}
+
 // The 23-state ETDRK4 path, the tail of step_etdrk4_bal_kernel<3>: its workgroups run it for the lanes
 // they must defer (`defer`; their state in memory is untouched, every other lane of the workgroup is
 // finished).  It takes a LAUNDERED copy of the kernarg address and re-reads every argument through
@@ -1421,6 +1596,120 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
 // are folded for that one.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1))) void step_etdrk4_lane_kernel(const EtdArgs A, const float *lane_par) {
     etdrk4_full_tail<true>(A, true, nullptr, 0, lane_par, A.stats_fresh);
+}
+
+// ... and the same transition with an env's three phases on three lanes of a quad (etd_switched_step3): grid = 4 n_env / 256.
+// 16 envs per wave, four times the waves, 0.6 x the instructions per wave and step.  Measured (tools/lane_params_rate.py, us
+// per batched step, this kernel / a lane per env): 16 384 envs 45 / 71, 32 768 envs 65 / 71, 49 152 envs 89 / 72, 65 536 envs
+// 115 / 72 -- the operand reads of the stiff pairs (LDS) and the issue slots are shared by the SIMD's waves, so the form that
+// wins a lone wave's latency loses the batch's throughput: launch_plan picks by batch size.
+constexpr int kLane3MaxEnvs = 32768;
+__global__ __launch_bounds__(kBlock) void step_etdrk4_lane3_kernel(const EtdArgs A, const float *lane_par) {
+    using namespace pvder;
+    const StepK<float> &C = A.C;
+    const EtdK &Ec = A.Ec;
+    const int n_env = A.n_env;
+    const size_t N = (size_t)n_env;
+    constexpr int NS = 23;
+    __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // (as etdrk4_full_tail stages them)
+    __shared__ __attribute__((aligned(16))) float wstats[4 * (kBlock / 64)];
+    for (int k = threadIdx.x; k < kSwFloats; k += kBlock) {
+        const int c = k & 3, j = (k >> 2) & 3, mat = (k >> 4) % kMatCount, sm = (k >> 4) / kMatCount, mode = sm % kSwModes, set = sm / kSwModes;
+        Msw[((((set * kMatCount + mat) * 4 + j) * kSwModes + mode) << 2) + c] = A.coef[kCoefFloats + k];
+    }
+    __syncthreads();
+    const int ph = threadIdx.x & 3;                      // 0, 1, 2: phases a, b, c; 3: mirrors phase a (left out of every sum)
+    const int e_quad = (int)((blockIdx.x * (unsigned)kBlock + threadIdx.x) >> 2);
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(C, A.fstate, A.istate, A.action, n_env, L, ys, 0, e_quad);
+    ModelK<float> P = A.P;
+    {
+        const float *__restrict__ lp = lane_par + L.ec;
+        P.iC = lp[(size_t)PVDER_LPF_IC * N];
+        P.KpDC = lp[(size_t)PVDER_LPF_KP_DC * N]; P.KiDC = lp[(size_t)PVDER_LPF_KI_DC * N];
+        P.KpQ = lp[(size_t)PVDER_LPF_KP_Q * N];   P.KiQ = lp[(size_t)PVDER_LPF_KI_Q * N];
+        P.pvA = lp[(size_t)PVDER_LPF_PVA * N];    P.pvB = lp[(size_t)PVDER_LPF_PVB * N];
+    }
+    if (__any((int)L.run)) {                             // (every lane of a quad runs or none: no DPP partner is ever masked off)
+        const int p3 = ph == 3 ? 0 : ph;
+        Phase3 y;
+        y.i = mk2(p3 == 0 ? ys[0] : (p3 == 1 ? ys[6] : ys[12]), p3 == 0 ? ys[1] : (p3 == 1 ? ys[7] : ys[13]));
+        y.x = mk2(p3 == 0 ? ys[2] : (p3 == 1 ? ys[8] : ys[14]), p3 == 0 ? ys[3] : (p3 == 1 ? ys[9] : ys[15]));
+        y.u = mk2(p3 == 0 ? ys[4] : (p3 == 1 ? ys[10] : ys[16]), p3 == 0 ? ys[5] : (p3 == 1 ? ys[11] : ys[17]));
+        y.s0 = mk2(ys[18], ys[19]); y.s1 = mk2(ys[20], ys[21]); y.s2 = mk2(ys[22], 0.f);
+        v2 comp[4] = {bc2(0.f), bc2(0.f), bc2(0.f), bc2(0.f)};
+        const PkConst K = make_pkconst(P);
+        PhaseK Q;
+        Q.rot = p3 == 0 ? mk2(1.f, 0.f) : (p3 == 1 ? mk2(-0.5f, -kHalfSqrt3) : mk2(-0.5f, kHalfSqrt3));
+        SubPk S;
+        bool fail = false;
+        int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
+        for (int s = 0; s < C.n_sub; ++s) {
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            const bool input_jump = row != prev_row;
+            prev_row = row;
+            const bool lane_fine = (s == 0) || input_jump;        // two-rate schedule, per env (etdrk4_full_tail)
+            make_sub_pk(P, A.ev_vg[(size_t)row * N + L.ec], A.ev_si[(size_t)row * N + L.ec], S);
+            Q.Asw = p3 == 0 ? S.Asw[0] : (p3 == 1 ? S.Asw[1] : S.Asw[2]);
+            Q.D = p3 == 0 ? S.D[0] : (p3 == 1 ? S.D[1] : S.D[2]);
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool fine = pass == 0;
+                // (a quad's lanes share their env's schedule; the lanes of a wave whose envs take the other pass sit this one out
+                //  TOGETHER with their quad: the DPP exchanges stay inside quads)
+                if (!__builtin_amdgcn_readfirstlane(__any((int)(lane_fine == fine)))) continue;
+                const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
+                float t0 = 0.f;
+                for (int j = 0; j < nst; ++j) {
+                    const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
+                    const float h = set == 0 ? Ec.hset[0] : (set == 1 ? Ec.hset[1] : Ec.hset[2]);
+                    const float tq = 120.f * h;
+                    const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
+                    const lds_v4 *Ms = (const lds_v4 *)Msw + (kSwModes * kMatCount * 4) * set;
+                    Phase3 yn = y;
+                    v2 cn[4] = {comp[0], comp[1], comp[2], comp[3]};
+                    const float mm2 = etd_switched_step3(P, K, Ec, S, Q, yn, cn, Ms, h, t0, tq, L.qref, L.vdcref);
+                    if (lane_fine == fine) {
+                        y = yn;
+                        comp[0] = cn[0]; comp[1] = cn[1]; comp[2] = cn[2]; comp[3] = cn[3];
+                        if (mm2 > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) fail = true;
+                    }
+                    t0 += tq;
+                }
+            }
+        }
+        // the env's 23 states back in the order of the state rows (every lane of the quad holds them; lane 0 stores)
+        const v2 ib = quad_bcast2<1>(y.i), xb = quad_bcast2<1>(y.x), ub = quad_bcast2<1>(y.u);
+        const v2 ic = quad_bcast2<2>(y.i), xc = quad_bcast2<2>(y.x), uc = quad_bcast2<2>(y.u);
+        const v2 ia = quad_bcast2<0>(y.i), xa = quad_bcast2<0>(y.x), ua = quad_bcast2<0>(y.u);
+        if (L.run) {
+            ys[0] = ia.x; ys[1] = ia.y; ys[2] = xa.x; ys[3] = xa.y; ys[4] = ua.x; ys[5] = ua.y;
+            ys[6] = ib.x; ys[7] = ib.y; ys[8] = xb.x; ys[9] = xb.y; ys[10] = ub.x; ys[11] = ub.y;
+            ys[12] = ic.x; ys[13] = ic.y; ys[14] = xc.x; ys[15] = xc.y; ys[16] = uc.x; ys[17] = uc.y;
+            ys[18] = y.s0.x; ys[19] = y.s0.y; ys[20] = y.s1.x; ys[21] = y.s1.y; ys[22] = y.s2.x;
+            L.ksub += C.n_sub;
+            L.steps += 1;
+            L.fail = fail;
+        }
+    }
+    // lane 0 of each quad is the env: reward / done / (auto-)reset / stores / statistics as everywhere (epilogue); the wave's
+    // statistics go to LDS first -- the caller's slots are per 64 envs (include/pvder_hip.h), a workgroup here
+    L.live = L.live && ph == 0;
+    L.run = L.run && ph == 0;
+    float *wst = (A.stats ? (float *)wstats : nullptr);
+    epilogue<float, 3>(P, C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out,
+                       wst ? wst - (size_t)blockIdx.x * (kBlock / 64) * 4 : nullptr, n_env, 1);
+    if (A.stats) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            v4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) t += ((const v4 *)wstats)[w];
+            v4 *slot = (v4 *)A.stats + blockIdx.x;
+            if (!A.stats_fresh) t += *slot;
+            *slot = t;
+        }
+    }
 }
 
 // =============================================================================================
@@ -3663,7 +3952,15 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
                 hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G);
             advance_hint(p, 1);
         } else {
-            if (p.ph == 3 && p.lane_par) hipLaunchKernelGGL(step_etdrk4_lane_kernel, grid, block, 0, st, A, p.lane_par);
+            // per-lane parameters: a phase per lane (four times the waves, 0.6 x the instructions per wave: the LATENCY form) while
+            // that leaves one or two waves per SIMD -- 45 us per batched step up to 16 384 envs, 65 up to 32 768 --, a lane per env
+            // (72 us whatever the batch up to 65 536: the THROUGHPUT form) beyond; PVDER_LANE1=1 / PVDER_LANE3=1 force one (A/B)
+            static const int lane_form = []() { const char *a = getenv("PVDER_LANE1"), *b = getenv("PVDER_LANE3");
+                                                return (a && a[0] == '1') ? 1 : ((b && b[0] == '1') ? 3 : 0); }();
+            const bool lane1 = lane_form == 1 || (lane_form == 0 && n_env > kLane3MaxEnvs);
+            if (p.ph == 3 && p.lane_par && lane1) hipLaunchKernelGGL(step_etdrk4_lane_kernel, grid, block, 0, st, A, p.lane_par);
+            else if (p.ph == 3 && p.lane_par)
+                hipLaunchKernelGGL(step_etdrk4_lane3_kernel, dim3((unsigned)(((size_t)n_env * 4 + kBlock - 1) / kBlock)), block, 0, st, A, p.lane_par);
             else if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
         }

@@ -50,6 +50,34 @@ def test_64_distinct_parameter_sets_in_one_launch_vs_the_bridge(gpu_device):
     assert rel_l2(plain[:, :, :10], want[:, :, :10], axis=2).max() > 1e-2
 
 
+def test_both_kernel_forms_of_the_override_vs_the_bridge(gpu_device):
+    """The override has two kernels -- a PHASE per lane (the latency form, batches up to 32 768 envs: what the 64-env test above
+    runs) and a LANE per env (the throughput form beyond): a 49 152-env batch that tiles the golden's 64 parameter sets, event
+    tables and actions takes the second; every copy of a set against the bridge, and the copies against each other bit for bit."""
+    import bridge_cases
+    name = "lane_params"
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    sets = bridge_cases.lane_param_sets(name)
+    reps = 768
+    N = c["N"] * reps
+    env = make_vec(N, gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4",
+                   lane_params={k: np.tile(v, reps) for k, v in sets.items()})
+    env.reset()
+    env.set_event_tables(torch.from_numpy(np.tile(vg.astype(np.float32), (1, reps))).to(gpu_device),
+                         torch.from_numpy(np.tile(si.astype(np.float32), (1, reps))).to(gpu_device))
+    env.reset()
+    steps = 16
+    got = _replay(env, np.tile(acts[:steps], (1, reps)), gpu_device)                 # [steps, N, 12]
+    want = g["obs"][:steps, :, :10]
+    blocks = got[:, :, :10].reshape(steps, reps, c["N"], 10)
+    assert rel_l2(blocks[:, 0], want, axis=2).max() < 1e-4
+    assert np.array_equal(blocks, np.broadcast_to(blocks[:, :1], blocks.shape))     # a lane's result does not depend on where it sits
+    assert np.array_equal(got[:, :c["N"], 11], g["reward"][:steps])
+    assert env.step_stats()["n_nonfinite"] == 0
+
+
 def test_lanes_left_at_the_sets_values_match_the_plain_integrator(gpu_device):
     """NaN rows / missing keys keep the group's constants: the 23-state path with the override installed but empty gives
     what the same path gives without it (force-full ETDRK4 == lane kernel, bit for bit), and the balanced fast path's
