@@ -669,24 +669,30 @@ __device__ __forceinline__ void matvec(const Mat4 &M, v2 ni, v2 nu, v2 &oi, v2 &
     ou = cmac(ou, pvder::mk2(M.hi.z, M.hi.w), nu);
 }
 
+__device__ __forceinline__ float dot2(v2 a, v2 b) { return __builtin_fmaf(a.y, b.y, a.x * b.x); }
+
 // N(y): fast part nf[2p] = N_i of phase p, nf[2p+1] = N_u; slow part ns[0..2] = dx_p,
 // ns[3] = d(Vdc,xDC), ns[4] = d(xQ,xPLL), ns[5] = d(delta,0).  Returns max_p |m_p|^2.
 __device__ __forceinline__ float etd_eval(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec,
                                           const pvder::SubPk &S, const v2 *__restrict__ y, float th2t,
                                           float qref, float vdcref, v2 *__restrict__ nf, v2 *__restrict__ ns) {
+    // (contraction is spelled out below: this function and etd_eval3 must round alike -- an env's result does not depend on which
+    //  of the two forms of the 23-state step advances it, bit for bit; left to hipcc the two contexts contract differently)
+#pragma clang fp contract(off)
     using namespace pvder;
     const float Vdc = y[9].x, xDC = y[9].y, xQ = y[10].x, xPLL = y[10].y, delta = y[11].x;
     const v2 ia = y[0], xa = y[1], ua = y[2], ib = y[3], xb = y[4], ub = y[5], ic = y[6], xc = y[7], uc = y[8];
     const v2 kpg = bc2(P.KpG);
     const v2 ma = fma2(kpg, ua, xa), mb = fma2(kpg, ub, xb), mc = fma2(kpg, uc, xc);
-    v2 aP = ma * ia; aP = fma2(mb, ib, aP); aP = fma2(mc, ic, aP);
-    v2 aQ = S.Asw[0] * ia; aQ = fma2(S.Asw[1], ib, aQ); aQ = fma2(S.Asw[2], ic, aQ);
-    v2 aI = ia * ia; aI = fma2(ib, ib, aI); aI = fma2(ic, ic, aI);
-    const float Pt = aP.x + aP.y;
-    const float Q = 0.5f * (aQ.x + aQ.y) + K.qk * (aI.x + aI.y);
+    // the three power sums, phase by phase and then (a + b) + c: the order in which the phase-per-lane form (etd_eval3) adds
+    // what it collects across a quad -- an env's result does not depend on which of the two forms advances it, bit for bit
+    const float Pt = (dot2(ma, ia) + dot2(mb, ib)) + dot2(mc, ic);
+    const float Qs = (dot2(S.Asw[0], ia) + dot2(S.Asw[1], ib)) + dot2(S.Asw[2], ic);
+    const float Is = (dot2(ia, ia) + dot2(ib, ib)) + dot2(ic, ic);
+    const float Q = __builtin_fmaf(K.qk, Is, 0.5f * Qs);
     const float qerr = qref - Q;
-    const float iarR = xDC + P.KpDC * (vdcref - Vdc);
-    const float iarI = xQ - P.KpQ * qerr;
+    const float iarR = __builtin_fmaf(P.KpDC, vdcref - Vdc, xDC);
+    const float iarI = __builtin_fmaf(-P.KpQ, qerr, xQ);
     float s1, c1, s2, c2;
     const float dturn = delta * (float)(1.0 / kTwoPi);
     Math<float>::sincos_turns(dturn, s1, c1);
@@ -702,12 +708,12 @@ __device__ __forceinline__ float etd_eval(const ModelK<float> &P, const pvder::P
     const v2 t1 = V1 * mk2(c1, s1);
     const v2 t2 = fma2(V2c, mk2(c2, s2), t1);
     const float vd = t2.x + t2.y;
-    const float dw = P.KpP * vd + xPLL;
+    const float dw = __builtin_fmaf(P.KpP, vd, xPLL);
     const float dwr = dw * P.iwb;                               // winv/wbase - 1
     // N_i = cm x + D + (cm - c0) Kp u - j dwr i
     const float cmf = K.hiLf * Vdc;
     const v2 cm = bc2(cmf);
-    const v2 dck = bc2(cmf * P.KpG - Ec.c0kp);
+    const v2 dck = bc2(__builtin_fmaf(cmf, P.KpG, -Ec.c0kp));
     const v2 jd = mk2(dwr, -dwr);                               // -j*dwr*(iR + j iI) = (dwr iI, -dwr iR)
     v2 n;
     n = fma2(cm, xa, S.D[0]); n = fma2(dck, ua, n); nf[0] = fma2(jd, swp(ia), n);
@@ -721,19 +727,17 @@ __device__ __forceinline__ float etd_eval(const ModelK<float> &P, const pvder::P
     const v2 kig = bc2(P.KiG);
     ns[0] = kig * ua; ns[1] = kig * ub; ns[2] = kig * uc;
     const float ppv = ppv_of(P, S.pv1, Vdc);
-    const float ReS = 0.25f * Vdc * Pt;
-    const float dVdc = (ppv - ReS) * Math<float>::rcp(Vdc) * P.iC;
+    const float dVdc = __builtin_fmaf(-0.25f * Vdc, Pt, ppv) * Math<float>::rcp(Vdc) * P.iC;        // (Ppv - Re S)/(Vdc C)
     float dxDC = P.KiDC * (vdcref - Vdc);
     float dxQ = -P.KiQ * qerr;
-    if (iarR * iarR + iarI * iarI > P.ilim2) {
+    if (__builtin_fmaf(iarI, iarI, iarR * iarR) > P.ilim2) {
         dxDC = (dxDC * xDC > 0.f) ? 0.f : dxDC;
         dxQ = (dxQ * xQ > 0.f) ? 0.f : dxQ;
     }
     ns[3] = mk2(dVdc, dxDC);
     ns[4] = mk2(dxQ, P.KiP * vd);
     ns[5] = mk2(dw, 0.f);
-    const v2 mma = ma * ma, mmb = mb * mb, mmc = mc * mc;
-    return fmaxf(fmaxf(mma.x + mma.y, mmb.x + mmb.y), mmc.x + mmc.y);
+    return fmaxf(fmaxf(dot2(ma, ma), dot2(mb, mb)), dot2(mc, mc));
 }
 
 __device__ __forceinline__ float max_m2(const ModelK<float> &P, const v2 *y) {
@@ -912,7 +916,7 @@ struct Phase3 {             // what a lane holds of its env
 };
 struct PhaseK {             // per-lane constants of its phase
     v2 Asw, D;              // SubPk::Asw[p], D[p]
-    v2 rot;                 // (cos, sin) of the phase's rotation: 0, -120, +120 degrees
+    v2 rot;                 // .y = 0 / -1 / +1: phase a / b / c (the rotation of iref_a into the phase: 0, -120, +120 degrees)
 };
 
 // N(y) of one phase + the shared slow derivatives: ni / nu = N_i / N_u of the lane's phase, nx = dx_p/dt,
@@ -920,17 +924,17 @@ struct PhaseK {             // per-lane constants of its phase
 __device__ __forceinline__ float etd_eval3(const ModelK<float> &P, const pvder::PkConst &K, const EtdK &Ec, const pvder::SubPk &S,
                                            const PhaseK &Q, const Phase3 &y, float th2t, float qref, float vdcref,
                                            v2 &ni, v2 &nu, v2 &nx, v2 &n0, v2 &n1, v2 &n2) {
+#pragma clang fp contract(off)          // (see etd_eval)
     using namespace pvder;
     const float Vdc = y.s0.x, xDC = y.s0.y, xQ = y.s1.x, xPLL = y.s1.y, delta = y.s2.x;
     const v2 m = fma2(bc2(P.KpG), y.u, y.x);
-    const v2 aP = m * y.i, aQ = Q.Asw * y.i, aI = y.i * y.i;
-    const float Pt = quad_sum3(aP.x + aP.y);
-    const float Qs = quad_sum3(aQ.x + aQ.y);
-    const float Is = quad_sum3(aI.x + aI.y);
-    const float Qpcc = 0.5f * Qs + K.qk * Is;
+    const float Pt = quad_sum3(dot2(m, y.i));
+    const float Qs = quad_sum3(dot2(Q.Asw, y.i));
+    const float Is = quad_sum3(dot2(y.i, y.i));
+    const float Qpcc = __builtin_fmaf(K.qk, Is, 0.5f * Qs);
     const float qerr = qref - Qpcc;
-    const float iarR = xDC + P.KpDC * (vdcref - Vdc);
-    const float iarI = xQ - P.KpQ * qerr;
+    const float iarR = __builtin_fmaf(P.KpDC, vdcref - Vdc, xDC);
+    const float iarI = __builtin_fmaf(-P.KpQ, qerr, xQ);
     float s1, c1, s2, c2;
     const float dturn = delta * (float)(1.0 / kTwoPi);
     Math<float>::sincos_turns(dturn, s1, c1);
@@ -948,30 +952,33 @@ __device__ __forceinline__ float etd_eval3(const ModelK<float> &P, const pvder::
     const v2 t1 = V1 * mk2(c1, s1);
     const v2 t2 = fma2(V2c, mk2(c2, s2), t1);
     const float vd = t2.x + t2.y;
-    const float dw = P.KpP * vd + xPLL;
+    const float dw = __builtin_fmaf(P.KpP, vd, xPLL);
     const float dwr = dw * P.iwb;
     const float cmf = K.hiLf * Vdc;
     v2 n = fma2(bc2(cmf), y.x, Q.D);
-    n = fma2(bc2(cmf * P.KpG - Ec.c0kp), y.u, n);
+    n = fma2(bc2(__builtin_fmaf(cmf, P.KpG, -Ec.c0kp)), y.u, n);
     ni = fma2(mk2(dwr, -dwr), swp(y.i), n);
     // N_u = wp * iref_p,  iref_p = iref_a rotated into the lane's phase
     const v2 wra = mk2(P.wp * iarR, P.wp * iarI);
-    nu = mk2(Q.rot.x * wra.x - Q.rot.y * wra.y, Q.rot.y * wra.x + Q.rot.x * wra.y);
+    {   // (phase a: wra; b, c: -wra/2 -/+ j sqrt(3)/2 wra -- the operations of etd_eval, so that the two forms agree bit for bit;
+        //  Q.rot.y = 0, -1, +1 selects)
+        const v2 hw = bc2(-0.5f) * wra;
+        const v2 jw = swp(wra) * jh3;
+        nu = Q.rot.y == 0.f ? wra : (Q.rot.y < 0.f ? hw - jw : hw + jw);
+    }
     nx = bc2(P.KiG) * y.u;
     const float ppv = ppv_of(P, S.pv1, Vdc);
-    const float ReS = 0.25f * Vdc * Pt;
-    const float dVdc = (ppv - ReS) * Math<float>::rcp(Vdc) * P.iC;
+    const float dVdc = __builtin_fmaf(-0.25f * Vdc, Pt, ppv) * Math<float>::rcp(Vdc) * P.iC;
     float dxDC = P.KiDC * (vdcref - Vdc);
     float dxQ = -P.KiQ * qerr;
-    if (iarR * iarR + iarI * iarI > P.ilim2) {
+    if (__builtin_fmaf(iarI, iarI, iarR * iarR) > P.ilim2) {
         dxDC = (dxDC * xDC > 0.f) ? 0.f : dxDC;
         dxQ = (dxQ * xQ > 0.f) ? 0.f : dxQ;
     }
     n0 = mk2(dVdc, dxDC);
     n1 = mk2(dxQ, P.KiP * vd);
     n2 = mk2(dw, 0.f);
-    const v2 mm = m * m;
-    return mm.x + mm.y;
+    return dot2(m, m);
 }
 
 // the model's sign tests on dx_p/dt at a stage state, and the frozen rows of N_u (the lane's phase; `mode`: its two bits)
@@ -1061,6 +1068,99 @@ __device__ __forceinline__ float etd_switched_step3(const ModelK<float> &P, cons
     return quad_max3(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
 }
 
+// The env transition of the quads named by (e_quad, mine) on the phase-per-lane form; Msw: the staged operator sets;
+// LP: per-lane parameters (lane_par); stats / stats_fresh as epilogue takes them; act / out: the step's action row and
+// output block.  Lane 0 of a quad is the env for everything outside the integration (epilogue).
+template <bool LP>
+__device__ __forceinline__ void etd_tail3(const EtdArgs &A, const float *Msw, int e_quad, bool mine, const float *__restrict__ lane_par,
+                                          float *stats, int stats_fresh, const uint8_t *__restrict__ action, float *__restrict__ out) {
+    using namespace pvder;
+    const StepK<float> &C = A.C;
+    const EtdK &Ec = A.Ec;
+    const int n_env = A.n_env;
+    const size_t N = (size_t)n_env;
+    constexpr int NS = 23;
+    const int ph = threadIdx.x & 3;                      // 0, 1, 2: phases a, b, c; 3: mirrors phase a (left out of every sum)
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(C, A.fstate, A.istate, action, n_env, L, ys, 0, e_quad);
+    L.live = L.live && mine;
+    L.run = L.run && mine;
+    ModelK<float> Pl = A.P;
+    if constexpr (LP) {
+        const float *__restrict__ lp = lane_par + L.ec;
+        Pl.iC = lp[(size_t)PVDER_LPF_IC * N];
+        Pl.KpDC = lp[(size_t)PVDER_LPF_KP_DC * N]; Pl.KiDC = lp[(size_t)PVDER_LPF_KI_DC * N];
+        Pl.KpQ = lp[(size_t)PVDER_LPF_KP_Q * N];   Pl.KiQ = lp[(size_t)PVDER_LPF_KI_Q * N];
+        Pl.pvA = lp[(size_t)PVDER_LPF_PVA * N];    Pl.pvB = lp[(size_t)PVDER_LPF_PVB * N];
+    }
+    const ModelK<float> &P = LP ? Pl : A.P;
+    if (__any((int)L.run)) {                             // (every lane of a quad runs or none: no DPP partner is ever masked off)
+        const int p3 = ph == 3 ? 0 : ph;
+        Phase3 y;
+        y.i = mk2(p3 == 0 ? ys[0] : (p3 == 1 ? ys[6] : ys[12]), p3 == 0 ? ys[1] : (p3 == 1 ? ys[7] : ys[13]));
+        y.x = mk2(p3 == 0 ? ys[2] : (p3 == 1 ? ys[8] : ys[14]), p3 == 0 ? ys[3] : (p3 == 1 ? ys[9] : ys[15]));
+        y.u = mk2(p3 == 0 ? ys[4] : (p3 == 1 ? ys[10] : ys[16]), p3 == 0 ? ys[5] : (p3 == 1 ? ys[11] : ys[17]));
+        y.s0 = mk2(ys[18], ys[19]); y.s1 = mk2(ys[20], ys[21]); y.s2 = mk2(ys[22], 0.f);
+        v2 comp[4] = {bc2(0.f), bc2(0.f), bc2(0.f), bc2(0.f)};
+        const PkConst K = make_pkconst(P);
+        PhaseK Q;
+        Q.rot = p3 == 0 ? mk2(1.f, 0.f) : (p3 == 1 ? mk2(-0.5f, -1.f) : mk2(-0.5f, 1.f));      // (.y: which of phases a / b / c)
+        SubPk S;
+        bool fail = false;
+        int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
+        for (int s = 0; s < C.n_sub; ++s) {
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            const bool input_jump = row != prev_row;
+            prev_row = row;
+            const bool lane_fine = (s == 0) || input_jump;        // two-rate schedule, per env (etdrk4_full_tail)
+            make_sub_pk(P, A.ev_vg[(size_t)row * N + L.ec], A.ev_si[(size_t)row * N + L.ec], S);
+            Q.Asw = p3 == 0 ? S.Asw[0] : (p3 == 1 ? S.Asw[1] : S.Asw[2]);
+            Q.D = p3 == 0 ? S.D[0] : (p3 == 1 ? S.D[1] : S.D[2]);
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool fine = pass == 0;
+                // (a quad's lanes share their env's schedule; the lanes of a wave whose envs take the other pass sit this one out
+                //  TOGETHER with their quad: the DPP exchanges stay inside quads)
+                if (!__builtin_amdgcn_readfirstlane(__any((int)(lane_fine == fine)))) continue;
+                const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
+                float t0 = 0.f;
+                for (int j = 0; j < nst; ++j) {
+                    const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
+                    const float h = set == 0 ? Ec.hset[0] : (set == 1 ? Ec.hset[1] : Ec.hset[2]);
+                    const float tq = 120.f * h;
+                    const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
+                    const lds_v4 *Ms = (const lds_v4 *)Msw + (kSwModes * kMatCount * 4) * set;
+                    Phase3 yn = y;
+                    v2 cn[4] = {comp[0], comp[1], comp[2], comp[3]};
+                    const float mm2 = etd_switched_step3(P, K, Ec, S, Q, yn, cn, Ms, h, t0, tq, L.qref, L.vdcref);
+                    if (lane_fine == fine) {
+                        y = yn;
+                        comp[0] = cn[0]; comp[1] = cn[1]; comp[2] = cn[2]; comp[3] = cn[3];
+                        if (mm2 > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) fail = true;
+                    }
+                    t0 += tq;
+                }
+            }
+        }
+        // the env's 23 states back in the order of the state rows (every lane of the quad holds them; lane 0 stores)
+        const v2 ib = quad_bcast2<1>(y.i), xb = quad_bcast2<1>(y.x), ub = quad_bcast2<1>(y.u);
+        const v2 ic = quad_bcast2<2>(y.i), xc = quad_bcast2<2>(y.x), uc = quad_bcast2<2>(y.u);
+        const v2 ia = quad_bcast2<0>(y.i), xa = quad_bcast2<0>(y.x), ua = quad_bcast2<0>(y.u);
+        if (L.run) {
+            ys[0] = ia.x; ys[1] = ia.y; ys[2] = xa.x; ys[3] = xa.y; ys[4] = ua.x; ys[5] = ua.y;
+            ys[6] = ib.x; ys[7] = ib.y; ys[8] = xb.x; ys[9] = xb.y; ys[10] = ub.x; ys[11] = ub.y;
+            ys[12] = ic.x; ys[13] = ic.y; ys[14] = xc.x; ys[15] = xc.y; ys[16] = uc.x; ys[17] = uc.y;
+            ys[18] = y.s0.x; ys[19] = y.s0.y; ys[20] = y.s1.x; ys[21] = y.s1.y; ys[22] = y.s2.x;
+            L.ksub += C.n_sub;
+            L.steps += 1;
+            L.fail = fail;
+        }
+    }
+    L.live = L.live && ph == 0;
+    L.run = L.run && ph == 0;
+    epilogue<float, 3>(P, C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, out, stats, n_env, stats_fresh);
+}
+
 // The 23-state ETDRK4 path, the tail of step_etdrk4_bal_kernel<3>: its workgroups run it for the lanes
 // they must defer (`defer`; their state in memory is untouched, every other lane of the workgroup is
 // finished).  It takes a LAUNDERED copy of the kernarg address and re-reads every argument through
@@ -1127,6 +1227,25 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     int n_def = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) n_def += wave_cnt[w];
+#ifdef PVDER_TAIL3_IN_STEP
+    // NOT BUILT BY DEFAULT (round 4, measured): the phase-per-lane form (etd_tail3) for the step kernels' deferred envs, 64 per
+    // pass.  -DPVDER_TAIL3_IN_STEP=1: for workgroups with at most 64 of them, the lane-per-env form below for the others -- one env
+    // at the duty-cycle limit among 65 536 costs the batch 54 instead of 85 us per step, the action-4 ramp 60-93 instead of 74-124
+    // us per step while it approaches the limit, unchanged once most envs are there -- and the step kernel, 256 VGPRs before,
+    // spills 16 of them INTO ITS ENTRY BLOCK: 7.65 -> 8.16 us per batched step of the standard path.  =2: every workgroup by
+    // passes of 64 (221 VGPRs, no spill on the standard path): the same gains, and 193 instead of 97 us with every env at the limit.
+    // The two forms agree bit for bit (tools/lane_forms_bitwise.py), so which one advances an env is a question of time only.
+    if constexpr (!LP) {
+        if (PVDER_TAIL3_IN_STEP == 2 || n_def <= kBlock / 4) {
+            for (int base = 0; base < n_def; base += kBlock / 4) {          // (64 envs per pass: a quad of lanes each)
+                const int q = base + (int)(threadIdx.x >> 2);
+                etd_tail3<false>(A, Msw, (int)(blockIdx.x * kBlock) + (q < n_def ? packed[q] : (int)threadIdx.x), q < n_def, nullptr, stats,
+                                 stats_fresh, action, out);
+            }
+            return;
+        }
+    }
+#endif
     const bool mine = (int)threadIdx.x < n_def;
     PVDER_TRACE_COLD_MAX(13, true);
     Lane<float> L;
@@ -1605,12 +1724,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1))) voi
 // wins a lone wave's latency loses the batch's throughput: launch_plan picks by batch size.
 constexpr int kLane3MaxEnvs = 32768;
 __global__ __launch_bounds__(kBlock) void step_etdrk4_lane3_kernel(const EtdArgs A, const float *lane_par) {
-    using namespace pvder;
-    const StepK<float> &C = A.C;
-    const EtdK &Ec = A.Ec;
-    const int n_env = A.n_env;
-    const size_t N = (size_t)n_env;
-    constexpr int NS = 23;
     __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // (as etdrk4_full_tail stages them)
     __shared__ __attribute__((aligned(16))) float wstats[4 * (kBlock / 64)];
     for (int k = threadIdx.x; k < kSwFloats; k += kBlock) {
@@ -1618,87 +1731,9 @@ __global__ __launch_bounds__(kBlock) void step_etdrk4_lane3_kernel(const EtdArgs
         Msw[((((set * kMatCount + mat) * 4 + j) * kSwModes + mode) << 2) + c] = A.coef[kCoefFloats + k];
     }
     __syncthreads();
-    const int ph = threadIdx.x & 3;                      // 0, 1, 2: phases a, b, c; 3: mirrors phase a (left out of every sum)
-    const int e_quad = (int)((blockIdx.x * (unsigned)kBlock + threadIdx.x) >> 2);
-    Lane<float> L;
-    float ys[NS];
-    prologue<float, NS>(C, A.fstate, A.istate, A.action, n_env, L, ys, 0, e_quad);
-    ModelK<float> P = A.P;
-    {
-        const float *__restrict__ lp = lane_par + L.ec;
-        P.iC = lp[(size_t)PVDER_LPF_IC * N];
-        P.KpDC = lp[(size_t)PVDER_LPF_KP_DC * N]; P.KiDC = lp[(size_t)PVDER_LPF_KI_DC * N];
-        P.KpQ = lp[(size_t)PVDER_LPF_KP_Q * N];   P.KiQ = lp[(size_t)PVDER_LPF_KI_Q * N];
-        P.pvA = lp[(size_t)PVDER_LPF_PVA * N];    P.pvB = lp[(size_t)PVDER_LPF_PVB * N];
-    }
-    if (__any((int)L.run)) {                             // (every lane of a quad runs or none: no DPP partner is ever masked off)
-        const int p3 = ph == 3 ? 0 : ph;
-        Phase3 y;
-        y.i = mk2(p3 == 0 ? ys[0] : (p3 == 1 ? ys[6] : ys[12]), p3 == 0 ? ys[1] : (p3 == 1 ? ys[7] : ys[13]));
-        y.x = mk2(p3 == 0 ? ys[2] : (p3 == 1 ? ys[8] : ys[14]), p3 == 0 ? ys[3] : (p3 == 1 ? ys[9] : ys[15]));
-        y.u = mk2(p3 == 0 ? ys[4] : (p3 == 1 ? ys[10] : ys[16]), p3 == 0 ? ys[5] : (p3 == 1 ? ys[11] : ys[17]));
-        y.s0 = mk2(ys[18], ys[19]); y.s1 = mk2(ys[20], ys[21]); y.s2 = mk2(ys[22], 0.f);
-        v2 comp[4] = {bc2(0.f), bc2(0.f), bc2(0.f), bc2(0.f)};
-        const PkConst K = make_pkconst(P);
-        PhaseK Q;
-        Q.rot = p3 == 0 ? mk2(1.f, 0.f) : (p3 == 1 ? mk2(-0.5f, -kHalfSqrt3) : mk2(-0.5f, kHalfSqrt3));
-        SubPk S;
-        bool fail = false;
-        int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
-        for (int s = 0; s < C.n_sub; ++s) {
-            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
-            const bool input_jump = row != prev_row;
-            prev_row = row;
-            const bool lane_fine = (s == 0) || input_jump;        // two-rate schedule, per env (etdrk4_full_tail)
-            make_sub_pk(P, A.ev_vg[(size_t)row * N + L.ec], A.ev_si[(size_t)row * N + L.ec], S);
-            Q.Asw = p3 == 0 ? S.Asw[0] : (p3 == 1 ? S.Asw[1] : S.Asw[2]);
-            Q.D = p3 == 0 ? S.D[0] : (p3 == 1 ? S.D[1] : S.D[2]);
-            for (int pass = 0; pass < 2; ++pass) {
-                const bool fine = pass == 0;
-                // (a quad's lanes share their env's schedule; the lanes of a wave whose envs take the other pass sit this one out
-                //  TOGETHER with their quad: the DPP exchanges stay inside quads)
-                if (!__builtin_amdgcn_readfirstlane(__any((int)(lane_fine == fine)))) continue;
-                const int nst = fine ? (C.graded ? 2 : C.micro) : C.micro2;
-                float t0 = 0.f;
-                for (int j = 0; j < nst; ++j) {
-                    const int set = fine ? ((C.graded && j > 0) ? 2 : 0) : 1;
-                    const float h = set == 0 ? Ec.hset[0] : (set == 1 ? Ec.hset[1] : Ec.hset[2]);
-                    const float tq = 120.f * h;
-                    const float guard = (j == 0 && input_jump) ? Ec.sat2_event : Ec.sat2_smooth;
-                    const lds_v4 *Ms = (const lds_v4 *)Msw + (kSwModes * kMatCount * 4) * set;
-                    Phase3 yn = y;
-                    v2 cn[4] = {comp[0], comp[1], comp[2], comp[3]};
-                    const float mm2 = etd_switched_step3(P, K, Ec, S, Q, yn, cn, Ms, h, t0, tq, L.qref, L.vdcref);
-                    if (lane_fine == fine) {
-                        y = yn;
-                        comp[0] = cn[0]; comp[1] = cn[1]; comp[2] = cn[2]; comp[3] = cn[3];
-                        if (mm2 > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) fail = true;
-                    }
-                    t0 += tq;
-                }
-            }
-        }
-        // the env's 23 states back in the order of the state rows (every lane of the quad holds them; lane 0 stores)
-        const v2 ib = quad_bcast2<1>(y.i), xb = quad_bcast2<1>(y.x), ub = quad_bcast2<1>(y.u);
-        const v2 ic = quad_bcast2<2>(y.i), xc = quad_bcast2<2>(y.x), uc = quad_bcast2<2>(y.u);
-        const v2 ia = quad_bcast2<0>(y.i), xa = quad_bcast2<0>(y.x), ua = quad_bcast2<0>(y.u);
-        if (L.run) {
-            ys[0] = ia.x; ys[1] = ia.y; ys[2] = xa.x; ys[3] = xa.y; ys[4] = ua.x; ys[5] = ua.y;
-            ys[6] = ib.x; ys[7] = ib.y; ys[8] = xb.x; ys[9] = xb.y; ys[10] = ub.x; ys[11] = ub.y;
-            ys[12] = ic.x; ys[13] = ic.y; ys[14] = xc.x; ys[15] = xc.y; ys[16] = uc.x; ys[17] = uc.y;
-            ys[18] = y.s0.x; ys[19] = y.s0.y; ys[20] = y.s1.x; ys[21] = y.s1.y; ys[22] = y.s2.x;
-            L.ksub += C.n_sub;
-            L.steps += 1;
-            L.fail = fail;
-        }
-    }
-    // lane 0 of each quad is the env: reward / done / (auto-)reset / stores / statistics as everywhere (epilogue); the wave's
-    // statistics go to LDS first -- the caller's slots are per 64 envs (include/pvder_hip.h), a workgroup here
-    L.live = L.live && ph == 0;
-    L.run = L.run && ph == 0;
-    float *wst = (A.stats ? (float *)wstats : nullptr);
-    epilogue<float, 3>(P, C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out,
-                       wst ? wst - (size_t)blockIdx.x * (kBlock / 64) * 4 : nullptr, n_env, 1);
+    // the wave's statistics go to LDS first -- the caller's slots are per 64 envs (include/pvder_hip.h): a workgroup here
+    float *wst = A.stats ? (float *)wstats - (size_t)blockIdx.x * (kBlock / 64) * 4 : nullptr;
+    etd_tail3<true>(A, Msw, (int)((blockIdx.x * (unsigned)kBlock + threadIdx.x) >> 2), true, lane_par, wst, 1, A.action, A.out);
     if (A.stats) {
         __syncthreads();
         if (threadIdx.x == 0) {

@@ -74,6 +74,12 @@ def test_both_kernel_forms_of_the_override_vs_the_bridge(gpu_device):
     blocks = got[:, :, :10].reshape(steps, reps, c["N"], 10)
     assert rel_l2(blocks[:, 0], want, axis=2).max() < 1e-4
     assert np.array_equal(blocks, np.broadcast_to(blocks[:, :1], blocks.shape))     # a lane's result does not depend on where it sits
+    # ... nor on which of the two kernel forms advanced it: the 64-env batch (a phase per lane) gives the same bits
+    small = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4",
+                     lane_params=sets)
+    small.reset()
+    got64 = _replay(small, acts[:steps], gpu_device)
+    assert np.array_equal(got64[:, :, :10], blocks[:, 0])
     assert np.array_equal(got[:, :c["N"], 11], g["reward"][:steps])
     assert env.step_stats()["n_nonfinite"] == 0
 
