@@ -1172,7 +1172,7 @@ typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
 // LP (step_etdrk4_lane_kernel): every env with its OWN values of the parameters that stay outside the exponential operator
 // (lane_par: [PVDER_LPF_ROWS][n_env] folded constants, pvder_fold_lane_params) -- the lane's ModelK is the launch's with
 // those seven fields replaced (VGPRs instead of SGPRs); stats_fresh: this pass starts the step's statistics.
-template <bool LP = false>
+template <bool LP = false, bool T3 = false>
 __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, const uint8_t *act = nullptr,
                                                  long long out_off = 0, const float *__restrict__ lane_par = nullptr,
                                                  int stats_fresh = 0) {
@@ -1227,25 +1227,23 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     int n_def = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) n_def += wave_cnt[w];
-#ifdef PVDER_TAIL3_IN_STEP
-    // NOT BUILT BY DEFAULT (round 4, measured): the phase-per-lane form (etd_tail3) for the step kernels' deferred envs, 64 per
-    // pass.  -DPVDER_TAIL3_IN_STEP=1: for workgroups with at most 64 of them, the lane-per-env form below for the others -- one env
-    // at the duty-cycle limit among 65 536 costs the batch 54 instead of 85 us per step, the action-4 ramp 60-93 instead of 74-124
-    // us per step while it approaches the limit, unchanged once most envs are there -- and the step kernel, 256 VGPRs before,
-    // spills 16 of them INTO ITS ENTRY BLOCK: 7.65 -> 8.16 us per batched step of the standard path.  =2: every workgroup by
-    // passes of 64 (221 VGPRs, no spill on the standard path): the same gains, and 193 instead of 97 us with every env at the limit.
-    // The two forms agree bit for bit (tools/lane_forms_bitwise.py), so which one advances an env is a question of time only.
-    if constexpr (!LP) {
-        if (PVDER_TAIL3_IN_STEP == 2 || n_def <= kBlock / 4) {
-            for (int base = 0; base < n_def; base += kBlock / 4) {          // (64 envs per pass: a quad of lanes each)
-                const int q = base + (int)(threadIdx.x >> 2);
-                etd_tail3<false>(A, Msw, (int)(blockIdx.x * kBlock) + (q < n_def ? packed[q] : (int)threadIdx.x), q < n_def, nullptr, stats,
-                                 stats_fresh, action, out);
-            }
+    // T3 (step_etdlin_kernel_w1: the step kernel of batches that give a SIMD one wave): a workgroup with at most 64 deferred envs
+    // -- one env at the duty-cycle limit among 65 536, a Vdc_ref ramp approaching the limit, an env behind an event -- takes them
+    // through the phase-per-lane form (etd_tail3: a quad of lanes per env, 0.6 x the instructions of the wave the batch waits
+    // for): that env costs the batch 54 instead of 85 us per step, the action-4 ramp 60-93 instead of 74-124 us while it
+    // approaches the limit; more than 64: the lane-per-env form below (the throughput form, 97 against 193 us with every env at
+    // the limit).  The two forms agree bit for bit (tools/lane_forms_bitwise.py): which one advances an env is a question of
+    // time only.  (Side by side they need 16 registers more than the 256 two waves per SIMD leave each -- spilled into the
+    // kernel's entry block, 7.65 -> 8.16 us on the standard path: hence a kernel of its own, one wave per SIMD, where they
+    // sit in AGPRs: profiles/r04_ab_tail3_in_step_kernel.txt.)
+    if constexpr (T3 && !LP) {
+        if (n_def <= kBlock / 4) {
+            const int q = (int)(threadIdx.x >> 2);
+            etd_tail3<false>(A, Msw, (int)(blockIdx.x * kBlock) + (q < n_def ? packed[q] : (int)threadIdx.x), q < n_def, nullptr, stats,
+                             stats_fresh, action, out);
             return;
         }
     }
-#endif
     const bool mine = (int)threadIdx.x < n_def;
     PVDER_TRACE_COLD_MAX(13, true);
     Lane<float> L;
@@ -2548,7 +2546,7 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
 // register file (hipcc then spills SGPRs and gives the kernel a private segment).
 // KOFF: byte offset of G in the kernel-argument segment; fstate / istate / n_env: the copies the caller
 // holds (step_etdlin_kernel: preloaded into SGPRs by the dispatcher, see there).
-template <int PH, int KOFF>
+template <int PH, int KOFF, bool T3 = false>
 __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinRegs &R,
                                               const uint8_t *__restrict__ act, long long out_off, int stats_fresh,
                                               const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env,
@@ -2657,7 +2655,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
             KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
             asm volatile("" : "+s"(kb));
             PVDER_TRACE_COLD_AT(11);
-            if constexpr (PH == 3) etdrk4_full_tail(*(const EtdArgs *)kb, defer, act, out_off);
+            if constexpr (PH == 3) etdrk4_full_tail<false, T3>(*(const EtdArgs *)kb, defer, act, out_off);
             else rk4_tail_1ph(*(const EtdArgs *)kb, defer, act, out_off);
             PVDER_TRACE_COLD_AT(12);
         }
@@ -2758,9 +2756,9 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
     return leave;
 }
 
-template <int PH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
-                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
+template <int PH, bool T3>
+__device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate, const uint8_t *action, const float *lcoef, int n_env,
+                                                  int ksub_word, const float *k4coef, const LinArgs &G) {
     using namespace pvder;
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
@@ -2784,7 +2782,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         PVDER_TRACE_DEP(19, R.At[0] + R.Ac[5][2]);       // (... the coefficient registers are loaded)
     }
 #ifdef PVDER_NO_LEAN
-    lin_step_body<PH, kLinHeadBytes>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
+    lin_step_body<PH, kLinHeadBytes, T3>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
 #else
     const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, R, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
     if (__syncthreads_or((int)leave)) {
@@ -2797,10 +2795,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         const LinArgs &Gc = *(const LinArgs *)kc;
         LinRegs Rc;                      // (its coefficient registers too: loaded where the pass needs them)
         Rc.at_ok = false; Rc.cur = 0; Rc.k4_ok = false;
-        lin_step_body<PH, kLinHeadBytes>(Gc, lane, Rc, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
+        lin_step_body<PH, kLinHeadBytes, T3>(Gc, lane, Rc, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
     }
 #endif
 }
+
+// Two kernels, one body.  step_etdlin_kernel: two waves per SIMD (256 VGPRs) -- the batches beyond 65 536 envs live on that.
+// step_etdlin_kernel_w1: ONE wave per SIMD, which is all a batch of up to 65 536 envs (1024 waves) gives the chip anyway -- the
+// register file of the second wave holds what the two forms of the 23-state tail need side by side (T3: etdrk4_full_tail).
+// launch_plan picks by batch size; same arithmetic, same results.
+template <int PH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
+    step_etdlin_entry<PH, false>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G);
+}
+template <int PH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_etdlin_kernel_w1(float *fstate, int32_t *istate, const uint8_t *action,
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
+    step_etdlin_entry<PH, PH == 3>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G);
+}
+constexpr int kOneWavePerSimdEnvs = 65536;       // 256 CUs x 4 SIMDs x 64 lanes (MI355X)
 
 // =============================================================================================
 // Open-loop rollouts (pvder_plan_rollout_fused; etdlin, three-phase): n_steps env steps in ONE launch, the
@@ -3981,7 +3995,10 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         // micro-steps, 8192 per 1/60 s (single phase: the "balanced" kernel IS the model) for the envs they must defer
         // (none in PVDER-v0 rollouts).
         if (p.integrator == PVDER_INT_ETDLIN) {
-            if (p.ph == 3)
+            static const bool no_w1 = []() { const char *v = getenv("PVDER_NO_W1"); return v && v[0] == '1'; }();      // (A/B)
+            if (p.ph == 3 && n_env <= kOneWavePerSimdEnvs && !no_w1)
+                hipLaunchKernelGGL(step_etdlin_kernel_w1<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G);
+            else if (p.ph == 3)
                 hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G);
             else
                 hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G);

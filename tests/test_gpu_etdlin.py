@@ -785,3 +785,43 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
             assert e_all[last:][sel].max() < 2e-2, e_all[last:][sel].max()
 
 
+
+
+def test_the_two_step_kernels_and_the_two_tail_forms_agree_bit_for_bit(gpu_device, tmp_path):
+    """step_etdlin_kernel_w1 (batches that give a SIMD one wave: a workgroup's few deferred envs on the phase-per-lane form of
+    the 23-state step) against step_etdlin_kernel (two waves per SIMD, every deferred env on the lane-per-env form;
+    PVDER_NO_W1=1 selects it): the action-4 ramp to the duty-cycle limit and beyond, 1024 envs, every output and state word
+    of every step -- which kernel and which form advanced an env is a question of time only.  (Two child processes: the
+    switch is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path[:0] = %r
+from gym_PVDER_amd.vec_env import PVDERVec
+from helpers import both_events_spec
+dev = torch.device("cuda:0")
+N = 1024
+env = PVDERVec(N, device=dev, seed=2024, auto_reset=False, events_spec=both_events_spec())
+env.reset()
+a = torch.full((N,), 4, dtype=torch.uint8, device=dev)
+out, tails = [], 0
+for t in range(150):
+    env.step(a, return_tensors=False)
+    out.append(torch.cat([env.out.flatten(), env.fstate.flatten()]).cpu().numpy().copy())
+f = env.fstate
+m = (torch.complex(f[2], f[3]) + 6000.0 * torch.complex(f[4], f[5])).abs()
+np.save(sys.argv[1], np.stack(out))
+print("max |m_a| at the end", float(m.max()))
+''' % ([p for p in sys.path if p],)
+    files = []
+    for k, extra in enumerate(({}, {"PVDER_NO_W1": "1"})):
+        f = str(tmp_path / ("k%d.npy" % k))
+        env = dict(os.environ); env.pop("PVDER_NO_W1", None); env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert float(r.stdout.strip().split()[-1]) > 0.999          # the batch does reach the duty-cycle limit (23-state tail)
+        files.append(f)
+    a, b = np.load(files[0]), np.load(files[1])
+    assert a.shape == b.shape and np.array_equal(a.view(np.int32), b.view(np.int32))

@@ -204,7 +204,14 @@ def test_no_step_kernel_reads_the_dispatch_packet(tmp_path):
         if "etdlin64" in name:
             assert not props & 0x2, (name, "ENABLE_SGPR_DISPATCH_PTR")
             continue            # the fp64 tolerance-match kernel calls its step as a real function (0.5 ms kernel: not latency-bound)
-        assert private_seg <= 32, (name, "uses scratch", private_seg)
+        if private_seg > 32:
+            # (step_etdlin_kernel_w1: 68 bytes of frame objects behind SGPR spills that ended up in VGPR lanes / AGPRs) -- the
+            # ISA of the kernel must not hold a single scratch access
+            body = subprocess.check_output([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", "--disassemble-symbols=" + name[:-3],
+                                            str(tmp_path / ("lib%d.co" % n))], text=True)
+            assert "v_mfma" in body or "v_fma" in body or "v_pk_fma" in body, (name, "disassembly self-check")
+            assert not re.search(r"\b(scratch_|buffer_load|buffer_store)", body), (name, "uses scratch", private_seg)
+            assert private_seg <= 128, (name, private_seg)
         assert not props & 0x2, (name, "ENABLE_SGPR_DISPATCH_PTR")
 
 
