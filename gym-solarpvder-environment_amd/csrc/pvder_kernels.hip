@@ -3051,7 +3051,7 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
         }
         LinRegs R;
         R.at_ok = false; R.cur = 0; R.k4_ok = false;       // (loaded where the step needs them)
-        lin_step_body<PH, 0>(G, lane, R, AG ? Rk.ag_action : Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1,
+        lin_step_body<PH, 0, PH == 3>(G, lane, R, AG ? Rk.ag_action : Rk.actions + (size_t)k * G.A.n_env, k * Rk.out_stride, 1,
                              G.A.fstate, G.A.istate, G.A.n_env);
         if constexpr (AG) {
             // the agent step behind this env step, from the output block the step has just written (this lane's own
