@@ -319,7 +319,26 @@ def fixed_policy_leg(torch, dev, N, n_sub):
                                   "worst_10_step_block_us_per_step": max(blocks),
                                   "us_per_step_by_10_step_block": [round(b, 1) for b in blocks],
                                   "n_nonfinite": st["n_nonfinite"], "Q_ref_end": float(env.Q_ref[0]), "Vdc_ref_end": float(env.Vdc_ref[0])}
-    out["mean_us_per_step_all_four"] = sum(v["mean_us_per_step"] for v in out.values()) / 4.0
+    out["mean_us_per_step_all_four"] = sum(v["mean_us_per_step"] for v in out.values() if isinstance(v, dict) and "mean_us_per_step" in v) / 4.0
+    # ... and what ONE env at the duty-cycle limit (Vdc_ref -9 %) costs the other N - 1, which run on random actions: a launch
+    # lasts as long as its slowest workgroup (tools/one_saturated_env.py; round 2: 55 ms, round 3: 75 us)
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2, events_spec=events_on_spec(), auto_reset=False)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    acts = torch.randint(0, 5, (40, N), generator=gen, device=dev, dtype=torch.uint8)
+    acts[:, 0] = 0
+    env.fstate[env.ns + 1, 0] = float(env.Vdc_ref[0]) * (1.0 - 0.09)
+    env.rollout(acts, fused=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record(); env.rollout(acts, fused=False); e1.record()
+    torch.cuda.synchronize(dev)
+    f = env.fstate
+    out["one_saturated_env"] = {"us_per_step": e0.elapsed_time(e1) * 1e3 / 40, "steps": 40,
+                                "m_abs_of_that_env": float((torch.complex(f[2, 0], f[3, 0]) + 6000.0 * torch.complex(f[4, 0], f[5, 0])).abs()),
+                                "workload": "%d envs on random actions, env 0 held at Vdc_ref -9 %% (duty cycle at its limit)" % N,
+                                "n_nonfinite": env.step_stats()["n_nonfinite"]}
     out["note"] = ("%d envs, off_range='integrate' (the default: nothing terminates); parity of these ramps against the converged "
                    "bridge: tests/test_gpu_etdlin.py::test_fixed_action_ramps_vs_converged_bridge" % N)
     return out
