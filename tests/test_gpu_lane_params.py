@@ -100,6 +100,30 @@ def test_lanes_left_at_the_sets_values_match_the_plain_integrator(gpu_device):
     assert np.array_equal(ga[:, :, 11], gb[:, :, 11])
 
 
+@pytest.mark.parametrize("N", [192, 33000])
+def test_lane_params_through_episode_ends_with_auto_reset(gpu_device, N):
+    """Both kernel forms (192 envs: a phase per lane; 33 000: a lane per env, a batch that is no multiple of anything) through
+    two episode ends with same-step auto-reset: every env finishes and restarts exactly twice, nothing non-finite, statistics
+    = plain sums over the output block."""
+    rng = np.random.default_rng(5)
+    env = make_vec(N, gpu_device, seed=7, auto_reset=True, integrator="etdrk4",
+                   lane_params={"Np": rng.integers(10, 12, N).astype(np.float64), "C_actual": 300e-6 * rng.uniform(0.8, 1.3, N)})
+    env.reset()
+    done_count = torch.zeros(N, device=gpu_device)
+    for t in range(330):
+        a = torch.randint(0, 5, (N,), device=gpu_device, dtype=torch.uint8)
+        obs, rew, done, _ = env.step(a)
+        done_count += done.float()
+        if t % 80 == 79 or t in (159, 160, 319, 320):
+            st = env.step_stats()
+            assert st["n_nonfinite"] == 0
+            assert st["n_done"] == int(done.sum().item())
+            assert abs(st["reward_sum"] - float(rew.sum().item())) < 1e-3 * max(1.0, abs(float(rew.sum().item())))
+    assert bool((done_count == 2).all())
+    assert bool((env.steps == 330 - 320).all())
+    assert bool(torch.isfinite(env.fstate).all())
+
+
 def test_lane_params_are_refused_where_they_cannot_apply(gpu_device):
     with pytest.raises(ValueError):
         make_vec(8, gpu_device, lane_params={"Np": np.full(8, 10.0)})                      # the default integrator: per-set tables
