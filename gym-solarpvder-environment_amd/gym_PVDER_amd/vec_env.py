@@ -169,13 +169,13 @@ class PVDERVec(EnvSpecMixin):
         ``lane_params``: per-ENV values (domain randomisation) of the parameters outside the exponential operator --
         ``{"C_actual": [N], "Kp_DC": [N], "Ki_DC": [N], "Kp_Q": [N], "Ki_Q": [N], "Np": [N], "Sinsol_scale": [N]}``, any subset,
         NaN = the set's value -- with ``integrator="etdrk4"`` (three-phase model): every env then steps on the 23-state
-        ETDRK4 path with its own constants (include/pvder_hip.h pvder_plan_lane_params; ~0.1 ms per batched step).  reset()
+        ETDRK4 path with its own constants (include/pvder_hip.h pvder_plan_lane_params; 45-75 us per batched step).  reset()
         starts every env from the SET's steady state, from where it settles at its own operating point.
         ``off_range``: an env driven out of the range the fast fp32 integrators cover (duty cycle / current
         reference at their limits: e.g. Vdc_ref walked down 6 %) is ``"integrate"``d through as the reference
         does -- on the 23-state path, its steps at the duty-cycle limit on the operator sets of the anti-windup modes:
-        ~0.1 ms per env step for the WHOLE batch while one env is there (a launch lasts as long as its slowest
-        workgroup; bench.py `fixed_policy`) -- or its episode ``"terminate"``s (done, reward -100, the reference's
+        ~55 us per env step for the WHOLE batch while one env is there, ~0.1 ms once most are (a launch lasts as long as
+        its slowest workgroup; bench.py `fixed_policy`) -- or its episode ``"terminate"``s (done, reward -100, the reference's
         failure branch PVDER_env.py:169-172).  Envs at the CURRENT limit are not off range: they stay on the
         matrix-core path (careful pass) and are never terminated."""
         if off_range not in ("integrate", "terminate"):

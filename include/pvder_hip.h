@@ -125,8 +125,8 @@ typedef struct pvder_step_cfg {
                              the matrix-core path, careful pass, and never terminates it):
                              PVDER_OFF_RANGE_INTEGRATE (0, default): it is integrated through, as the reference
                              does -- the 23-state path on the operator sets of the anti-windup modes (the mode of a
-                             phase is found at the START of an integrator step and held over it, up to 1/60 s), ~0.1 ms
-                             per env step for the launch while an env is there;  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
+                             phase is found at the START of an integrator step and held over it, up to 1/60 s), ~55 us
+                             per env step for the launch while an env is there (~0.1 ms once most envs are);  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
                              (status 2, done, reward -100: the reference's failure branch, :169-172) -- for
                              training runs that must not stall on a saturated converter.  fp32 exponential
                              integrators only (etdlin, ETDRK4). */
