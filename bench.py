@@ -424,6 +424,40 @@ def single_env_leg(steps=1000):
                         "episode end; one launch and one host read-back (obs, reward, done as Python objects) per step"}
 
 
+def lane_params_leg(torch, dev, n_sub, sizes=(16384, 65536), steps=40):
+    """The per-env parameter override (domain randomisation over C, the outer-loop gains, the PV array size and the
+    insolation scale; PVDERVec(integrator="etdrk4", lane_params=...)): every env of the batch with its OWN set on the 23-state
+    ETDRK4 path, one launch per env step -- the phase-per-lane kernel up to 32 768 envs, the lane-per-env kernel beyond."""
+    import numpy as np
+    from gym_PVDER_amd import der_model
+    from gym_PVDER_amd.vec_env import PVDERVec
+    out = {}
+    for N in sizes:
+        rng = np.random.default_rng(1)
+        base = der_model.DER_CONFIG["50"]
+        sets = {"C_actual": base["C_actual"] * rng.uniform(0.7, 1.4, N), "Kp_DC": base["Kp_DC"] * rng.uniform(0.8, 1.25, N),
+                "Ki_DC": base["Ki_DC"] * rng.uniform(0.8, 1.25, N), "Kp_Q": base["Kp_Q"] * rng.uniform(0.8, 1.25, N),
+                "Ki_Q": base["Ki_Q"] * rng.uniform(0.8, 1.25, N), "Np": rng.integers(10, 12, N).astype(np.float64),
+                "Sinsol_scale": rng.uniform(0.9, 1.0, N)}
+        env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2, events_spec=events_on_spec(), auto_reset=True,
+                       integrator="etdrk4", lane_params=sets)
+        env.reset()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(9)
+        a = torch.randint(0, 5, (steps, N), generator=gen, device=dev, dtype=torch.uint8)
+        env.rollout(a, fused=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record(); env.rollout(a, fused=False); e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        out["envs_%d" % N] = {"us_per_step": us, "value": N / us * 1e6, "unit": "env-steps/s", "distinct_parameter_sets": N,
+                              "kernel": "step_etdrk4_lane3_kernel" if N <= 32768 else "step_etdrk4_lane_kernel",
+                              "n_nonfinite": env.step_stats()["n_nonfinite"]}
+    out["parity"] = "tests/test_gpu_lane_params.py (64 sets vs the bridge integrating each: 3.4e-5; the two kernels bit for bit)"
+    return out
+
+
 def large_batch_leg(torch, dev, n_sub, N=1 << 20, steps=300, warm=60):
     """The same workload, kernel and launch-per-env-step at 1 048 576 envs per GPU: sixteen waves per SIMD's worth of envs
     instead of one -- the batch at which the step kernel's loads, arithmetic and stores overlap across waves."""
@@ -969,6 +1003,7 @@ def run_rank(args):
                     out["single_env"] = single_env_leg(args.single_env_steps)
                 if args.fixed_policy:
                     out["fixed_policy"] = fixed_policy_leg(torch, dev, N, args.n_sub)
+                    out["lane_params"] = lane_params_leg(torch, dev, args.n_sub)
                 if args.rk45_steps > 0:
                     out["rk45"] = rk45_leg(torch, dev, N, args.n_sub, args.rk45_steps)
                     out["etdlin64"] = etdlin64_leg(torch, dev, N, args.n_sub)
