@@ -2017,10 +2017,15 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
 // committed episodes: 7.0 -> 4.7 right-hand sides per env step of a PVDER-v0 rollout at unchanged accuracy).  Same guards as
 // lin_etd3rk: |m| at the start, the two middle stages, the c = 1 stage and the end; |iref| at the start and the middle (the
 // careful pass's threshold); embedded indicator y+ against the stage value U4.
-template <int PH>
+// EARLY (the second pass of the step kernels; `mine`: the lanes the step is for): when ALL of them are beyond the careful
+// pass's thresholds at the START of the step -- a batch held at a limit; the single-phase unit whenever Q_ref moves -- the step
+// is cut short behind its first right-hand side (`cut`, wave-uniform; Yn is then meaningless): the careful pass redoes those
+// lanes whatever the other three right-hand sides would say.  (Not in the lean first pass: a ballot and a branch between the
+// first right-hand side and its products cost the standard path 0.18 us, profiles/r04_ab_k4_early_out.txt.)
+template <int PH, bool EARLY>
 __device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs &Ak, const pvder::v4f (&Y)[3],
                                        const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
-                                       float msc, pvder::v4f (&Yn)[3], bool &near_ilim) {
+                                       float msc, pvder::v4f (&Yn)[3], bool &near_ilim, bool mine, bool &cut) {
     using namespace pvder;
     const ModelK<float> &P = G.A.P;
     const EtdK &Ec = G.A.Ec;
@@ -2029,6 +2034,15 @@ __device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs 
     float m2a, ir2a, m2x, ir2x, m2y, ir2y, m2b, ir2b;
     lin_pairs(Y, yp);
     bal_f<PH>(P, K, S, yp, qref, vdcref, kpo, kio, F, m2a, ir2a);
+    cut = false;
+    if constexpr (EARLY) {
+        const bool flagged = ir2a > irg || msc * m2a > Ec.sat2_smooth;
+        if (__builtin_amdgcn_readfirstlane(!__any((int)(mine && !flagged)))) {
+            near_ilim = flagged;
+            cut = true;
+            return msc * m2a > G.Lk.sat2_hard;
+        }
+    }
     v4f acc4[4][3] = {{Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}, {Y[0], Y[1], Y[2]}};
     {
         const int m4[4] = {KM21, KM31, KM41, KB1};
@@ -2143,11 +2157,11 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
         if (trace_step == 0) PVDER_TRACE_AT(3);
         make_sub_pk(P, sg.in_vg, sg.in_si, S);
         v4f Yn[3];
-        bool near;
-        const bool trip = lin_k4<PH>(G, R.Ak, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, near);
+        bool near, cut;
+        const bool trip = lin_k4<PH, SPLIT>(G, R.Ak, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, near, run_all && !defer && quiet, cut);
         if (run_all && quiet) {
             if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
-            Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
+            if (!cut) { Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2]; }
         }
     }
 #endif
@@ -2784,6 +2798,12 @@ __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate
 #ifdef PVDER_NO_LEAN
     lin_step_body<PH, kLinHeadBytes, T3>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
 #else
+    // (single phase: the 10 kVA unit of model_1 sits within 5 % of its current limit as soon as Q_ref moves -- its env steps ARE
+    //  careful-pass steps, and a lean first pass in front of them is 8 us of 42 spent on results nobody uses: the body at once)
+    if constexpr (PH == 1) {
+        lin_step_body<PH, kLinHeadBytes, T3>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
+        return;
+    }
     const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, R, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
     if (__syncthreads_or((int)leave)) {
         // (rare: every argument again through a laundered copy of the kernarg pointer -- nothing of this pass stays
