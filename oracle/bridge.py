@@ -26,7 +26,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(HERE, f) for f in ("pvder_bridge.c", "pvder_bridge_impl.h", "Makefile")]
+    srcs = [os.path.join(HERE, f) for f in ("pvder_bridge.c", "pvder_bridge_impl.h", "pvder_bridge_filippov.h", "Makefile")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB
@@ -115,6 +115,37 @@ def rk45_batch(m: pm.DERModel, Y: np.ndarray, t0, T: float, rtol: float, atol: f
                                       *[_p(x, C.c_double) for x in a], _p(nacc, C.c_long),
                                       _p(nrej, C.c_long))
     return Y, hs, nacc, nrej
+
+
+def filippov_batch(m: pm.DERModel, Y: np.ndarray, t0, T: float, rtol: float, atol: float, hstep, vg, si, qref, vdcref,
+                   region: np.ndarray):
+    """Event-locating DP5(4) over [t0, t0+T] following the sliding (Filippov) solution at the duty-cycle limit
+    (pvder_bridge_filippov.h).  ``region``: [N, 3] int32, updated IN PLACE.  Returns (Y, hstep, nacc, nrej, nev)."""
+    par = pack_params(m)
+    Y = np.ascontiguousarray(Y, dtype=np.float64).copy()
+    N = Y.shape[0]
+    assert region.dtype == np.int32 and region.shape == (N, 3) and region.flags.c_contiguous
+    t0 = _vec(t0, N, np.float64)
+    hs = _vec(hstep, N, np.float64).copy()
+    a = [_vec(x, N, np.float64) for x in (vg, si, qref, vdcref)]
+    nacc, nrej, nev = (np.zeros(N, dtype=np.int64) for _ in range(3))
+    lib().pvder_bridge_filippov_batch_f64(_p(par, C.c_double), C.c_int(N), _p(Y, C.c_double), _p(t0, C.c_double),
+                                          C.c_double(T), C.c_double(rtol), C.c_double(atol), _p(hs, C.c_double),
+                                          *[_p(x, C.c_double) for x in a], _p(region, C.c_int), _p(nacc, C.c_long),
+                                          _p(nrej, C.c_long), _p(nev, C.c_long))
+    return Y, hs, nacc, nrej, nev
+
+
+def filippov_evaluate(m: pm.DERModel, y: np.ndarray, t: float, vg: float, si: float, qref: float, vdcref: float, region):
+    """(dy, aux[3 phases][s, N, D]) of the event-locating integrator's right-hand side with the given regions."""
+    par = pack_params(m)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    reg = np.ascontiguousarray(region, dtype=np.int32)
+    dy, aux = np.zeros(m.n_states), np.zeros(9)
+    lib().pvder_bridge_filippov_eval_f64(_p(par, C.c_double), _p(y, C.c_double), C.c_double(t), C.c_double(vg), C.c_double(si),
+                                         C.c_double(qref), C.c_double(vdcref), _p(reg, C.c_int), _p(dy, C.c_double),
+                                         _p(aux, C.c_double))
+    return dy, aux.reshape(3, 3)
 
 
 def evaluate(m: pm.DERModel, y: np.ndarray, t: float, vg: float, si: float, qref: float,

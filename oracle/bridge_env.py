@@ -46,6 +46,8 @@ class BridgeVecEnv:
         self.steps = np.zeros(self.N, dtype=np.int64)
         self.done = np.zeros(self.N, dtype=bool)
         self.hstep = np.full(self.N, 1e-6)
+        self.region = np.zeros((self.N, 3), dtype=np.int32)      # method "filippov": IN / OUT / SLIDE per phase
+        self.n_events = np.zeros(self.N, dtype=np.int64)
         self.vg_t, self.si_t = np.asarray(vg_table, dtype=np.float64), np.asarray(si_table, dtype=np.float64)
         self.ev_s0, self.ev_ds = ev_s0, ev_ds
         self.reward = np.zeros(self.N)
@@ -83,6 +85,14 @@ class BridgeVecEnv:
                                          dtype=self.dtype, comp=comp)
                     if comp is not None:
                         self.comp[idx] = comp
+                elif self.method == "filippov":
+                    reg = np.ascontiguousarray(self.region[idx])
+                    Y, hs, _, _, nev = bridge.filippov_batch(self.model, self.Y[idx], t0, SIM_TIME_STEP, self.rtol, self.atol,
+                                                             self.hstep[idx], vg[idx], si[idx], self.qref[idx],
+                                                             self.vdcref[idx], reg)
+                    self.region[idx] = reg
+                    self.n_events[idx] += nev
+                    self.hstep[idx] = hs
                 else:
                     Y, hs, _, _ = bridge.rk45_batch(self.model, self.Y[idx], t0, SIM_TIME_STEP, self.rtol,
                                                     self.atol, self.hstep[idx], vg[idx], si[idx],

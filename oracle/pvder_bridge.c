@@ -11,6 +11,8 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 enum {
     PAR_PHASES = 0, PAR_RF, PAR_LF, PAR_C, PAR_KVG_RE, PAR_KVG_IM, PAR_KVI_RE, PAR_KVI_IM,
@@ -32,6 +34,7 @@ static inline double cos__f64(double x) { return cos(x); }
 static inline double sin__f64(double x) { return sin(x); }
 static inline double sqrt__f64(double x) { return sqrt(x); }
 #include "pvder_bridge_impl.h"
+#include "pvder_bridge_filippov.h"      /* event-locating / sliding-mode integrator (fp64 only) */
 #undef REAL
 #undef SUF
 
@@ -88,6 +91,40 @@ void pvder_bridge_rk45_batch_f64(const double *par, int N, double *Y, const doub
         if (nacc) nacc[e] = na;
         if (nrej) nrej[e] = rj;
     }
+}
+
+/* The event-locating integrator of pvder_bridge_filippov.h.  region: [N][3] int (in/out, 0 at reset); nev out. */
+void pvder_bridge_filippov_batch_f64(const double *par, int N, double *Y, const double *t0, double T,
+                                     double rtol, double atol, double *hstep, const double *vg,
+                                     const double *si, const double *qref, const double *vdcref,
+                                     int *region, long *nacc, long *nrej, long *nev) {
+    const int ns = 6 * (int)par[PAR_PHASES] + 5;
+#pragma omp parallel for schedule(dynamic)
+    for (int e = 0; e < N; ++e) {
+        long rj = 0, ev = 0;
+        double hl = hstep[e];
+        long na = fil_integrate(par, Y + (size_t)e * ns, t0[e], T, rtol, atol, &hl, vg[e], si[e], qref[e], vdcref[e],
+                                region + 3 * (size_t)e, &ev, &rj);
+        hstep[e] = hl;
+        if (nacc) nacc[e] = na;
+        if (nrej) nrej[e] = rj;
+        if (nev) nev[e] = ev;
+    }
+}
+
+/* the event-locating integrator's right-hand side at one state with the given regions (0 IN, 1 OUT, 2 SLIDE per phase):
+ * dy and aux[3p + 0..2] = s_p, N_p, D_p */
+void pvder_bridge_filippov_eval_f64(const double *par, const double *y, double t, double vg, double si, double qref,
+                                    double vdcref, const int *region, double *dy, double *aux) {
+    fil_ctx c;
+    c.par = par;
+    memcpy(c.par_free, par, sizeof c.par_free);
+    c.par_free[PAR_M_LIMIT] = 1e150;
+    c.vgm = vg; c.sinsol = si; c.qref = qref; c.vdcref = vdcref;
+    c.P = (int)par[PAR_PHASES];
+    c.n_events = 0; c.n_evals = 0;
+    for (int p = 0; p < 3; ++p) { c.region[p] = region[p]; for (int k = 0; k < 4; ++k) c.sgn0[p][k] = 0; }
+    fil_rhs(&c, y, th2_of_f64(par, t), dy, aux);
 }
 
 /* dy and the 16 algebraic outputs at one state */

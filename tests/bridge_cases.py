@@ -1,4 +1,5 @@
-"""Named episodes of the converged fp64 bridge (oracle/pvder_bridge.c, RK45 at rtol 1e-8) that the -m gpu tests
+"""Named episodes of the converged fp64 bridge (oracle/pvder_bridge.c, RK45 at rtol 1e-8; the event-locating integrator of
+oracle/pvder_bridge_filippov.h where the duty cycle saturates) that the -m gpu tests
 replay on the device: the case definitions live here, ``tests/golden/make_bridge_goldens.py`` integrates them on
 the CPU (minutes each) and commits ``tests/golden/bridge_<name>.npz``, the tests load them -- the GPU suite no longer
 spends its time in the checker.  Event tables come from the oracle's counter generator, which the device generator
@@ -24,10 +25,14 @@ _SAMPLE_IDS = tuple(int(i) for i in np.sort(np.random.default_rng(77).choice(655
 
 CASES = {
     "ramp_a1": _ramp(1), "ramp_a2": _ramp(2), "ramp_a3": _ramp(3),
-    # action 4 SATURATES the duty cycle from env step ~116: there the bridge's RK45 is a chattering approximation of the sliding
-    # solution whose error falls like tol^0.2 only (profiles/r04_saturation_convergence.txt: 6e-3 / 3e-3 per env step at rtol
-    # 1e-8 / 1e-10 against 1e-12) -- the golden is the 1e-12 run and carries the 1e-10 run beside it (obs_coarser): its OWN spread
-    "ramp_a4": dict(_ramp(4), rtol=1e-12),
+    # action 4 SATURATES the duty cycle from env step ~116: there the right-hand side is discontinuous across |m_p| = m_limit and
+    # the solution SLIDES along that surface.  RK45 on the raw right-hand side only chatters around it (error ~ tol^0.17: 6e-3 /
+    # 3.5e-3 / 2.3e-3 per env step at rtol 1e-8 / 1e-10 / 1e-12, profiles/r04_saturation_convergence.txt); round 5: the golden is
+    # the EVENT-LOCATING integrator's run (oracle/pvder_bridge_filippov.h: regions IN / OUT / SLIDE per phase, switching instants
+    # located, Filippov's equivalent dynamics while sliding) at rtol 1e-12, atol 1e-19 (u_p ~ 1e-6 carries the duty cycle through
+    # Kp_GCC = 6000: the absolute tolerance has to sit below rtol |u|), and carries the rtol 1e-9 run beside it (obs_coarser): its
+    # OWN spread, 5.1e-6 per env step at worst over all 160 steps (profiles/r05_filippov_convergence.txt)
+    "ramp_a4": dict(_ramp(4), rtol=1e-12, atol_ratio=1e-7, method="filippov", rtol_coarser=1e-9),
     # four envs of the 65 536-env action-1 ramp (seed 3) in which the +2 % voltage event of env step 121 takes the duty
     # cycle -- |m| = 0.97 by then -- across its limit for a moment: one env step on the 23-state path (switched operator
     # sets), a 1e-3 imbalance in the current controller's integrators behind it that takes the rest of the episode to die
