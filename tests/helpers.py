@@ -72,3 +72,28 @@ def assert_discrete_rewards(got_r, want_r, want_obs, goal="voltage_regulation", 
     assert dist.max() < tol, "%s: %d discrete reward(s) differ away from a threshold (distance %.2e, errors %s)" % (
         what, int(bad.sum()), dist.max(), err[:5])
     return int(bad.sum())
+
+
+OBS_NAMES = ("ia.real", "ia.imag", "va.real", "va.imag", "P_PCC", "Q_PCC", "Vdc", "Ppv", "Vdc_ref", "Q_ref", "t/max")   # PVDER_env.py:44-49
+
+
+def per_observation_error(got, want, floor=0.05):
+    """|got - want| / max(|want|, floor) of the EIGHT dynamic observations (PVDER_env.py:531-542: entries 0-7; 8-10 are the
+    set points and the clock, bookkeeping that is never wrong and carries half of the 11-vector's norm): [..., 8].  The
+    floor keeps the entries that sit near zero (ia.imag, va.imag, Q_PCC ~ 0.01 pu) from dividing by nothing: for them the
+    bound is absolute, rel * floor."""
+    got, want = np.asarray(got, dtype=np.float64)[..., :8], np.asarray(want, dtype=np.float64)[..., :8]
+    return np.abs(got - want) / np.maximum(np.abs(want), floor)
+
+
+def assert_per_observation(got, want, rel=1e-4, floor=0.05, what=""):
+    """a bound on EVERY dynamic observation by itself -- the rel-L2 over the 11-vector hides Q_PCC (what
+    Q_regulation rewards, PVDER_env.py:263-275) and ia.imag behind entries of norm 1.  Names the worst entry when it fails."""
+    e = per_observation_error(got, want, floor)
+    flat = e.reshape(-1, 8)
+    k = int(flat.max(axis=0).argmax())
+    where = np.unravel_index(int(e[..., k].argmax()), e[..., k].shape)
+    assert flat.max() <= rel, "%s: observation %d (%s) off by %.3e of max(|want|, %g) at %s (got %.8g, want %.8g); worst per entry %s" % (
+        what, k, OBS_NAMES[k], flat.max(), floor, where, np.asarray(got)[..., k][where], np.asarray(want)[..., k][where],
+        " ".join("%.1e" % v for v in flat.max(axis=0)))
+    return flat.max(axis=0)
