@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -29,7 +29,8 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
-           "pvder_fold_lane_params", "pvder_plan_lane_params"]
+           "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32"]
+LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
 
 INTEGRATOR_IDS = {"etdlin": 0, "etdrk4": 1, "rk4": 2, "rk45": 3, "etdlin64": 4}       # enum pvder_integrator
@@ -139,6 +140,8 @@ def lib() -> C.CDLL:
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.pvder_reset_masked_lanes_f32.restype = i32
+    L.pvder_reset_masked_lanes_f32.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.pvder_step_rk4_f32.restype = i32
     L.pvder_step_rk4_f32.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.pvder_step_etdrk4_f32.restype = i32

@@ -12,6 +12,7 @@ CPU tests.  No collective sits on the data path of the integration itself.
 from __future__ import annotations
 
 import ctypes as C
+import operator
 import os
 from typing import Optional, Tuple
 
@@ -55,7 +56,12 @@ def check_payload(payload: str, every: int = 1) -> None:
     disagree about it."""
     if payload not in PAYLOADS:
         raise ValueError("payload must be one of %s" % (PAYLOADS,))
-    if payload == "full_every_k" and (not isinstance(every, int) or every < 2):
+    if payload == "full_every_k":
+        try:
+            every = operator.index(every)             # (numpy / torch integer scalars are integers too: ADVICE r4)
+        except TypeError:
+            every = 0
+    if payload == "full_every_k" and every < 2:
         raise ValueError("payload 'full_every_k' needs gather_every >= 2 (got %r); use payload='full' for every step" % (every,))
 
 

@@ -169,8 +169,9 @@ class PVDERVec(EnvSpecMixin):
         ``lane_params``: per-ENV values (domain randomisation) of the parameters outside the exponential operator --
         ``{"C_actual": [N], "Kp_DC": [N], "Ki_DC": [N], "Kp_Q": [N], "Ki_Q": [N], "Np": [N], "Sinsol_scale": [N]}``, any subset,
         NaN = the set's value -- with ``integrator="etdrk4"`` (three-phase model): every env then steps on the 23-state
-        ETDRK4 path with its own constants (include/pvder_hip.h pvder_plan_lane_params; 45-75 us per batched step).  reset()
-        starts every env from the SET's steady state, from where it settles at its own operating point.
+        ETDRK4 path with its own constants (include/pvder_hip.h pvder_plan_lane_params; 45-75 us per batched step).  reset() and
+        the same-step auto-reset start every env from ITS OWN steady state (a Newton root per env, folded on the host: the
+        reference builds each DER with steadyStateInitialization=True, PVDER_env.py:374-378).
         ``off_range``: an env driven out of the range the fast fp32 integrators cover (duty cycle / current
         reference at their limits: e.g. Vdc_ref walked down 6 %) is ``"integrate"``d through as the reference
         does -- on the 23-state path, its steps at the duty-cycle limit on the operator sets of the anti-windup modes:
@@ -280,7 +281,7 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("lane_params need integrator='etdrk4' and the three-phase model (the default integrator's "
                              "tables belong to ONE parameter set: see param_groups.PVDERVecGroups)")
         rows = np.ascontiguousarray(der_model.lane_param_rows(lane_params, self.num_envs))
-        folded = np.empty((7, self.num_envs), dtype=np.float32)
+        folded = np.empty((_native.LPF_ROWS, self.num_envs), dtype=np.float32)
         _native.check(self._lib.pvder_fold_lane_params(self._par_c, rows.ctypes.data, self.num_envs, folded.ctypes.data),
                       "pvder_fold_lane_params")
         object.__setattr__(self, "_lane_folded", torch.from_numpy(folded).to(self.device))
@@ -544,13 +545,13 @@ class PVDERVec(EnvSpecMixin):
         lc.sched, lc.n_sched_rows, lc.est_guard = None, 0, 1.0
         return lc
 
-    def _plan_fingerprint(self) -> str:
-        """What a plan folds in that can be edited IN PLACE behind the env's back (the spec dicts; attribute assignments drop
-        the plan at once): reset() / load_state_dict() rebuild the plan only when this changes (~0.6 ms of host work saved
-        per episode of a training loop -- as much as a 160-step fused episode takes on the GPU)."""
-        g = self._goals_list[0]
-        return repr((self.env_events_spec, self.env_reward_spec.get('reference_values'), self.env_goal_spec[g]['reward'],
-                     self.est_guard, self._debug_knob))
+    def _plan_fingerprint(self) -> bytes:
+        """What a plan folds in, as the FOLDED structs themselves (a hand-picked list of attributes missed _delQref,
+        the event grid, _keep_events ...): the bytes of ``pvder_step_cfg`` and ``pvder_autoreset`` as the next launch would
+        pass them, the parameter vector and the etdlin guard.  reset() / load_state_dict() rebuild the plan only when this
+        changes -- specs edited IN PLACE behind the env's back (attribute assignments drop the plan at once) -- so the reset
+        launch and the step plan can never disagree about the configuration."""
+        return bytes(self._cfg()) + bytes(self._autoreset(self.auto_reset)) + self.par.tobytes() + repr(self.est_guard).encode()
 
     def _make_plan(self):
         """Fold cfg / reset block / coefficients into a C-side plan (include/pvder_hip.h "plans")."""
@@ -618,6 +619,16 @@ class PVDERVec(EnvSpecMixin):
     def _reset_launch(self, mask: Optional[torch.Tensor]):
         fn = self._lib.pvder_reset_masked_f32 if self.fdtype == torch.float32 else self._lib.pvder_reset_masked_f64
         cfg, ar = self._cfg(), self._autoreset(True)
+        lanes = self.__dict__.get("_lane_folded")
+        if lanes is not None:
+            # per-lane parameters: every env restarts from ITS OWN steady state (PVDER_env.py:374-378) and its reset observation
+            # carries its own Ppv -- the same observation the same-step auto-reset of the lane kernels returns
+            rc = self._lib.pvder_reset_masked_lanes_f32(self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(),
+                                                        self.istate.data_ptr(), self.ev_vg.data_ptr(), self.ev_si.data_ptr(),
+                                                        mask.data_ptr() if mask is not None else None, self.out.data_ptr(),
+                                                        self.num_envs, lanes.data_ptr(), self._stream())
+            _native.check(rc, "pvder_reset_masked_lanes_f32")
+            return
         rc = fn(self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
                 self.ev_vg.data_ptr(), self.ev_si.data_ptr(), mask.data_ptr() if mask is not None else None,
                 self.out.data_ptr(), self.num_envs, self._stream())

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 14
+#define PVDER_ABI_VERSION 15
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -172,6 +172,11 @@ int pvder_block_size(void);
 int pvder_reset_masked_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
                            float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                            const uint8_t *mask, float *out, int n_env, void *stream);
+/* ... with per-LANE parameters (pvder_plan_lane_params below): lane_folded = DEVICE float[PVDER_LPF_ROWS][n_env]; every reset env
+ * starts from ITS OWN steady state and its reset observation (Ppv) uses its own PV constants.  NULL: pvder_reset_masked_f32. */
+int pvder_reset_masked_lanes_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
+                                 float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                                 const uint8_t *mask, float *out, int n_env, const float *lane_folded, void *stream);
 int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
                            double *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                            const uint8_t *mask, double *out, int n_env, void *stream);
@@ -331,7 +336,13 @@ enum {
 };
 /*   folded rows (what the kernel reads; float32): 1/C, the four gains, and the two constants of the PV array model
  *   pv1 = pvA * Sinsol + pvB (pvder_model.hpp ModelK; pvA carries Np and the insolation scale, pvB Np). */
-enum { PVDER_LPF_IC = 0, PVDER_LPF_KP_DC, PVDER_LPF_KI_DC, PVDER_LPF_KP_Q, PVDER_LPF_KI_Q, PVDER_LPF_PVA, PVDER_LPF_PVB, PVDER_LPF_ROWS };
+/*   ... and (ABI 15) the env's OWN steady state -- the reference builds every DER with steadyStateInitialization=True
+ *   (PVDER_env.py:374-378), so an env with its own PV array starts at ITS operating point: phase a's current i_a and duty cycle
+ *   m_a (Newton root of  Re S = Ppv(Vdc_ref0; Np, scale),  Im S_PCC = 0,  di/dt = 0, solved per env in fp64 by the fold);
+ *   the other entries of y0 follow from them (i_b,c = i_a e^{-/+j120}, x_p = m_p, u_p = 0, xDC + j xQ = i_a) or do not depend
+ *   on the lane's parameters (Vdc = Vdc_ref0, xPLL = 0, delta). */
+enum { PVDER_LPF_IC = 0, PVDER_LPF_KP_DC, PVDER_LPF_KI_DC, PVDER_LPF_KP_Q, PVDER_LPF_KI_Q, PVDER_LPF_PVA, PVDER_LPF_PVB,
+       PVDER_LPF_IA_RE, PVDER_LPF_IA_IM, PVDER_LPF_MA_RE, PVDER_LPF_MA_IM, PVDER_LPF_ROWS };
 /* pvder_fold_lane_params (host, no GPU): lane[PVDER_LP_ROWS][n_env] doubles -> folded[PVDER_LPF_ROWS][n_env] floats, by
  * the SAME folding as the plan's own constants (model option PVDER_PAR_PPV_AT_MPP included).  PVDER_EINVAL for a
  * non-positive C, a negative Np or scale, or a non-finite value. */
@@ -340,8 +351,8 @@ int pvder_fold_lane_params(const double *par, const double *lane, int n_env, flo
  * NULL returns the plan to its own constants).  While set, pvder_plan_step / pvder_plan_rollout advance EVERY env on the
  * 23-state path (no balanced reduction: an env with its own PV array is not at the group's operating point) -- batches up to
  * 32 768 envs with an env's three phases on three lanes (step_etdrk4_lane3_kernel: 45-65 us per batched step), larger ones
- * with a lane per env (step_etdrk4_lane_kernel: 72 us at 65 536 envs); same scheme, results within fp32 rounding of each other.  Reset and same-step auto-reset restart an env from the GROUP's steady state (ResetK.y0), from where
- * it settles at its own operating point; the observation's Ppv and the reward use the env's own constants.
+ * with a lane per env (step_etdrk4_lane_kernel: 72 us at 65 536 envs); same scheme, results within fp32 rounding of each other.  The same-step auto-reset restarts an env from ITS OWN steady state (rows PVDER_LPF_IA_RE ..), and so does
+ * pvder_reset_masked_lanes_f32; the observation's Ppv and the reward use the env's own constants.
  * PVDER_EINVAL unless the plan is a three-phase PVDER_INT_ETDRK4 plan. */
 int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded);
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,

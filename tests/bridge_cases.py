@@ -47,9 +47,9 @@ CASES = {
     # a complete PVDER-v0 episode, random actions (tests of drift: etdlin and ETDRK4 replay it)
     "episode_random": dict(N=8, seed=1234, spec="both", n=15, steps=160, actions=("random", 2718)),
     # 64 envs, each with its OWN DC-link capacitance, outer-loop gains, PV array size and insolation scale (lane_param_sets:
-    # the per-lane override of the ETDRK4 integrator), random actions; every env starts from the DEFAULT set's
-    # steady state (what reset() gives a batch with lane parameters) and settles at its own operating point.  The bridge
-    # integrates each env with a model built from its own config block.
+    # the per-lane override of the ETDRK4 integrator), random actions; every env starts from ITS OWN steady
+    # state (round 5; the reference builds each DER with steadyStateInitialization=True, PVDER_env.py:374-378).  The bridge
+    # integrates each env with a model built from its own config block; obs_reset = its reset observation.
     "lane_params": dict(N=64, seed=21, spec="both", n=15, steps=40, actions=("random", 99), lane_seed=5),
 }
 
@@ -62,9 +62,8 @@ def lane_param_sets(name):
     N, base = c["N"], DER_CONFIG["50"]
     sets = {k: base[k] * rng.uniform(lo, hi, N) for k, (lo, hi) in
             (("C_actual", (0.7, 1.4)), ("Kp_DC", (0.8, 1.25)), ("Ki_DC", (0.8, 1.25)), ("Kp_Q", (0.8, 1.25)), ("Ki_Q", (0.8, 1.25)))}
-    # (the envs start from the DEFAULT set's steady state: an array much smaller than the reference's 11 strings lets the
-    #  DC link sag into the duty-cycle limit before the outer loops catch up -- |m| = 1.00004 with 9 strings at 80 % -- where
-    #  no two integrators agree to 1e-4: tests/test_gpu_etdlin.py, action 4)
+    # (10 or 11 strings at 90-100 % insolation: the operating points stay clear of the duty-cycle limit -- |m| = 1.00004 with 9
+    #  strings at 80 % --, where the device's switched steps are 1e-2 off: tests/test_gpu_etdlin.py, action 4)
     sets["Np"] = rng.integers(10, 12, N).astype(np.float64)           # 10 or 11 parallel strings (11: the reference's)
     sets["Sinsol_scale"] = rng.uniform(0.9, 1.0, N)
     return sets

@@ -34,18 +34,19 @@ def run_env(job):
     rtol = c["rtol_coarser"] if coarser else c.get("rtol", 1e-8)
     method, atol = c.get("method", "rk45"), rtol * c.get("atol_ratio", 1e-3)
     if "lane_seed" in c:
-        # an env with its own parameter set: a model from its own config block, the insolation it sees scaled, started
-        # from the DEFAULT set's steady state
+        # an env with its own parameter set: a model from its own config block, the insolation it sees scaled, started from
+        # ITS OWN steady state (the reference builds each DER with steadyStateInitialization=True, PVDER_env.py:374-378)
         sets = bridge_cases.lane_param_sets(name)
         ref = BridgeVecEnv(1, n=c["n"], method=method, rtol=rtol, atol=atol,
                            overrides={k: float(v[e]) for k, v in sets.items() if k != "Sinsol_scale"})
         ref.reset(vg[:, e:e + 1], si[:, e:e + 1] * sets["Sinsol_scale"][e], ev_s0=60, ev_ds=60)
         from oracle import bridge
-        ref.Y[0] = bridge.to_delta(pm.steady_state(pm.build_model("50")), 0.0)
+        ref.Y[0] = bridge.to_delta(pm.steady_state(ref.model, Sinsol=ref.model.Sinsol0 * sets["Sinsol_scale"][e]), 0.0)
     else:
         ref = BridgeVecEnv(1, n=c["n"], method=method, rtol=rtol, atol=atol)
         ref.reset(vg[:, e:e + 1], si[:, e:e + 1], ev_s0=60, ev_ds=60)
     m = ref.model
+    obs0 = ref.observe()[0].copy()
     obs, rew, done, mabs, iabs = [], [], [], [], []
     for a in acts[:, e]:
         o, r, d = ref.step(np.array([a]))
@@ -53,6 +54,8 @@ def run_env(job):
         Y = ref.Y[0]
         mabs.append(abs(complex(Y[2] + m.Kp_GCC * Y[4], Y[3] + m.Kp_GCC * Y[5])))
         iabs.append(float(np.hypot(Y[19] + m.Kp_DC * (ref.vdcref[0] - Y[18]), Y[20] - m.Kp_Q * (ref.qref[0] - o[0, 5]))))
+    if "lane_seed" in c:
+        obs = [obs0] + obs                    # (row 0: the reset observation at the env's own operating point)
     return name, e, np.array(obs), np.array(rew), np.array(done), np.array(mabs), np.array(iabs), coarser
 
 
@@ -114,8 +117,11 @@ def main():
         if "rtol_coarser" in c:          # the same case at a coarser tolerance: the golden's OWN spread travels with it
             co = sorted([r for r in res if r[0] == n and r[7]], key=lambda r: r[1])
             extra = dict(obs_coarser=np.stack([r[2] for r in co], axis=1), rtol_coarser=c["rtol_coarser"])
+        obs_all = np.stack([r[2] for r in mine], axis=1)
+        if "lane_seed" in c:
+            extra["obs_reset"], obs_all = obs_all[0], obs_all[1:]
         np.savez_compressed(bridge_cases.path(n), vgrid=vg, sinsol=si, actions=acts,
-                            obs=np.stack([r[2] for r in mine], axis=1), reward=np.stack([r[3] for r in mine], axis=1),
+                            obs=obs_all, reward=np.stack([r[3] for r in mine], axis=1),
                             done=np.stack([r[4] for r in mine], axis=1), m_abs=np.stack([r[5] for r in mine], axis=1),
                             iref_abs=np.stack([r[6] for r in mine], axis=1), ev_s0=60, ev_ds=60, n=c["n"],
                             rtol=c.get("rtol", 1e-8), atol=c.get("rtol", 1e-8) * c.get("atol_ratio", 1e-3),

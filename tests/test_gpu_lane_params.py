@@ -50,6 +50,38 @@ def test_64_distinct_parameter_sets_in_one_launch_vs_the_bridge(gpu_device):
     assert rel_l2(plain[:, :, :10], want[:, :, :10], axis=2).max() > 1e-2
 
 
+def test_every_env_starts_at_its_own_steady_state(gpu_device):
+    """VERDICT r4 #5 / ADVICE r4 #1 (PVDER_env.py:374-378: each DER is built with steadyStateInitialization=True; config_der.json:2-21):
+    with 64 distinct parameter sets the reset observation equals the bridge's per-set steady state to 1e-6; the first env step
+    under action 0 before any event shows NO transient (|d obs| <= 1e-5); and reset() returns the very observation the same-step
+    auto-reset of the lane kernels returns for the same env."""
+    import bridge_cases
+    name = "lane_params"
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    sets = bridge_cases.lane_param_sets(name)
+    N = c["N"]
+    env = make_vec(N, gpu_device, seed=c["seed"], auto_reset=True, events_spec=cc["spec_dict"], integrator="etdrk4", lane_params=sets,
+                   max_sim_time=1.0)                                   # (4 env steps per episode: the auto-reset comes at once)
+    obs0 = env.reset().cpu().numpy().astype(np.float64).copy()
+    want0 = g["obs_reset"]
+    assert np.abs(obs0[:, :10] - want0[:, :10]).max() < 1e-6, np.abs(obs0[:, :10] - want0[:, :10]).max()
+    assert np.ptp(obs0[:, 0]) > 0.05 and np.ptp(obs0[:, 7]) > 0.05       # the operating points DO differ (Np 10 / 11, 90-100 % insolation)
+    zero = torch.zeros(N, dtype=torch.uint8, device=gpu_device)
+    obs1, _, _, _ = env.step(zero)
+    d = np.abs(obs1.cpu().numpy().astype(np.float64)[:, :8] - obs0[:, :8])
+    assert d.max() < 1e-5, d.max()                                      # (from the group's steady state: 3e-2 in Vdc within one env step)
+    for _ in range(3):
+        obs, rew, done, _ = env.step(zero)
+    assert bool(done.all())                                             # the step that ended the episode returns the RESET observation
+    auto = obs.cpu().numpy().astype(np.float64)
+    env2 = make_vec(N, gpu_device, seed=c["seed"], auto_reset=True, events_spec=cc["spec_dict"], integrator="etdrk4", lane_params=sets,
+                    max_sim_time=1.0)
+    env2.reset(); again = env2.reset().cpu().numpy().astype(np.float64)     # (episode 2's tables, as the auto-reset drew them)
+    assert np.array_equal(auto[:, :10], again[:, :10])
+
+
 def test_both_kernel_forms_of_the_override_vs_the_bridge(gpu_device):
     """The override has two kernels -- a PHASE per lane (the latency form, batches up to 32 768 envs: what the 64-env test above
     runs) and a LANE per env (the throughput form beyond): a 49 152-env batch that tiles the golden's 64 parameter sets, event

@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol():
     assert agent == sorted(_native.AGENT_SYMBOLS)
     for sym in agent:
         assert hasattr(L, sym), sym
-    assert L.pvder_version() == _native.ABI_VERSION == 14
+    assert L.pvder_version() == _native.ABI_VERSION == 15
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
     assert L.pvder_block_size() % 64 == 0
@@ -382,7 +382,7 @@ def test_lane_parameter_folding_on_the_host():
     assert rows.shape == (7, N) and np.isnan(rows[2]).all() and np.isnan(rows[5, 2])
     for opts in (None, {"ppv_at_mpp": True}):
         par = der_model.param_vector("50", None, opts)
-        out = np.empty((7, N), dtype=np.float32)
+        out = np.empty((_native.LPF_ROWS, N), dtype=np.float32)
         assert L.pvder_fold_lane_params((C.c_double * len(par))(*par), rows.ctypes.data, N, out.ctypes.data) == 0
         for e in range(N):
             ov = {k: float(v[e]) for k, v in sets.items() if k != "Sinsol_scale" and not np.isnan(v[e])}
@@ -391,12 +391,20 @@ def test_lane_parameter_folding_on_the_host():
             want = [c["iC"], c["KpDC"], c["KiDC"], c["KpQ"], c["KiQ"]]
             np.testing.assert_allclose(out[:5, e], want, rtol=2e-7)
             if not opts:
-                np.testing.assert_allclose(out[5:, e], [c["pvA"] * sc, c["pvB"]], rtol=2e-7)
+                np.testing.assert_allclose(out[5:7, e], [c["pvA"] * sc, c["pvB"]], rtol=2e-7)
             else:       # model option U5: pv1 = pvA * Sinsol + pvB = -Ppv(Vdcmpp0) -- linear in the photo current, hence in the scale
                 v0, e0 = c["vdc0"], np.exp(c["pvK"] * c["vdc0"])
-                np.testing.assert_allclose(out[5:, e], [-v0 * c["pvA"] * sc, -v0 * c["pvB"] * (1.0 - e0)], rtol=2e-6)
+                np.testing.assert_allclose(out[5:7, e], [-v0 * c["pvA"] * sc, -v0 * c["pvB"] * (1.0 - e0)], rtol=2e-6)
+            # rows 7-10 (ABI 15): the env's OWN steady state -- the Newton root of der_model.steady_state for its config block
+            # at the insolation it sees (the reference: steadyStateInitialization=True, PVDER_env.py:374-378)
+            pe = der_model.param_vector("50", ov, opts)
+            pe[der_model.IDX["SINSOL0"]] *= sc
+            y0 = der_model.steady_state(pe, "50")
+            np.testing.assert_allclose(out[7:, e], y0[:4], rtol=1e-6)
     bad = rows.copy(); bad[0, 1] = 0.0
-    out = np.empty((7, N), dtype=np.float32)
+    out = np.empty((_native.LPF_ROWS, N), dtype=np.float32)
+    assert L.pvder_fold_lane_params((C.c_double * len(par))(*par), bad.ctypes.data, N, out.ctypes.data) == _native.EINVAL
+    bad = rows.copy(); bad[6, 0] = np.inf                        # (an infinite insolation scale: non-finite PV constants)
     assert L.pvder_fold_lane_params((C.c_double * len(par))(*par), bad.ctypes.data, N, out.ctypes.data) == _native.EINVAL
     with pytest.raises(ValueError):
         der_model.lane_param_rows({"Rf_actual": np.ones(N)}, N)
