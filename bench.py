@@ -78,6 +78,8 @@ def parse(argv=None):
     ap.add_argument("--fixed-policy", type=int, default=1, help="1: time the four fixed-action ramps of calc_returns' kind (0 = skip)")
     ap.add_argument("--rk45-steps", type=int, default=2, help="fp64 RK45 steps (BASELINE configs[4]) timed beside the main run (0 = skip)")
     ap.add_argument("--large-batch", type=int, default=1 << 20, help="envs of the large_batch leg (same kernel, one launch per env step; 0 = skip)")
+    ap.add_argument("--side-legs", type=int, default=1, help="1: the configs1 (4096 envs, n = 4: etdlin and classic RK4) and desynchronised "
+                                                             "(episode phases spread) legs (0 = skip)")
     ap.add_argument("--single-env-steps", type=int, default=1000, help="steps of the single_env leg: make('PVDER-v0'), random agent (0 = skip)")
     ap.add_argument("--time-every", type=int, default=64,
                     help="bracket every K-th step kernel with HIP events (clamped so that even a short run gets samples); 0 = none")
@@ -94,7 +96,7 @@ def parse(argv=None):
     ap.add_argument("--fused-steps", type=int, default=160, help="env steps per fused launch in that leg")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: all-gather issued directly into RCCL (default) or through torch.distributed")
-    ap.add_argument("--payload", default="full", choices=["full", "reward_done", "full_every_k"],
+    ap.add_argument("--payload", default="full", choices=["full", "reward_done", "full_every_k", "obs8"],
                     help="N > 1: what a step collates -- the whole [13, N_local] block (default: what BASELINE configs[3] "
                          "names), (reward, done) only, or (reward, done) with the whole block every --gather-every steps")
     ap.add_argument("--gather-every", type=int, default=8)
@@ -170,7 +172,21 @@ def launch_ranks(n: int, argv) -> int:
 
 def payload_rows_per_step(payload: str, gather_every: int) -> float:
     """Rows of the [13, N_local] block a step collates on average."""
-    return {"full": 13.0, "reward_done": 2.0}.get(payload, 2.0 + 11.0 / max(gather_every, 2))
+    return {"full": 13.0, "reward_done": 2.0, "obs8": 10.0}.get(payload, 2.0 + 11.0 / max(gather_every, 2))
+
+
+def expected_payload_efficiency(world: int, n_local: int, kernel_s: float, gather_every: int) -> dict:
+    """What xGMI allows each payload BEFORE anything is measured (a single 8-GPU driver run should explain itself):
+    a peer's block of `rows` rows crosses ONE link direction (76.5 GB/s, fully connected mesh, all peers in parallel), the
+    gather of step t overlaps the kernel of step t+1, so a step cannot take less than max(kernel, link time): expected weak-
+    scaling efficiency = kernel / max(kernel, link)."""
+    out = {}
+    for pl in ("full", "obs8", "reward_done", "full_every_k"):
+        rows = payload_rows_per_step(pl, gather_every)
+        link_s = rows * n_local * 4 / 76.5e9 if world > 1 else 0.0
+        out[pl] = {"rows_per_step": rows, "link_us_per_step": 1e6 * link_s, "kernel_us_per_step": 1e6 * kernel_s,
+                   "expected_efficiency": finite(kernel_s / max(kernel_s, link_s)) if kernel_s > 0 else None}
+    return out
 
 
 def xgmi_roofline(world: int, n_local: int, rows: float, sec_per_step: float) -> dict:
@@ -209,7 +225,7 @@ def selftest_rank():
     n_local, steps = 256, 4
     blk = torch.full((13, n_local), float(rank))
     legs = {}
-    for name in ("compute_only", "full", "reward_done"):
+    for name in ("compute_only", "full", "obs8", "reward_done"):
         dist.barrier()
         t0 = time.perf_counter()
         for k in range(steps):
@@ -221,7 +237,8 @@ def selftest_rank():
         legs[name] = ({"value": world * n_local * steps / el, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * el / steps}
                       if name == "compute_only" else payload_leg(world, n_local, steps, el, name, 1))
     if rank == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.sum()), "payload_legs": legs}))
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.sum()), "payload_legs": legs,
+                          "expected_payload_efficiency": expected_payload_efficiency(world, 65536, 8e-6, 8)}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -456,6 +473,85 @@ def lane_params_leg(torch, dev, n_sub, sizes=(16384, 65536), steps=40):
                               "n_nonfinite": env.step_stats()["n_nonfinite"]}
     out["parity"] = "tests/test_gpu_lane_params.py (64 sets vs the bridge integrating each: 3.4e-5; the two kernels bit for bit)"
     return out
+
+
+def configs1_leg(torch, dev, steps=400, classic_steps=2):
+    """BASELINE configs[1]: 4 096 parallel envs, n = 4 sim time steps per env step, the requested max_sim_time of 40 s clamped by
+    the reference to 500 * n / 60 = 33.33 s (PVDER_env.py:569-571: 500 steps per episode, the TimeLimit of gym_PVDER/__init__.py:10),
+    default events (voltage only, :60-61), random actions, auto-reset -- the default step path (etdlin) and the literal
+    "fixed-step RK4 fp32" of that config line (3750 micro-steps per 1/60 s) side by side."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    N, n_sub = 4096, 4
+    out = {"workload": "BASELINE configs[1]: 4096 envs, n=4, max_sim_time 40 -> 33.33 s (500 env steps per episode), voltage events, "
+                       "random actions, auto-reset, one launch per env step"}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(41)
+    acts = torch.randint(0, 5, (steps, N), generator=gen, device=dev, dtype=torch.uint8)
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, max_sim_time=40.0, seed=2024, auto_reset=True)
+    assert abs(env.max_sim_time - 500 * n_sub / 60.0) < 1e-9
+    env.reset()
+    env.rollout(acts[:100], fused=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    e0.record(); env.rollout(acts, fused=False); e1.record()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    out["etdlin"] = {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "us_per_step": 1e6 * el / steps,
+                     "region_us_per_step": e0.elapsed_time(e1) * 1e3 / steps, "kernel": KERNEL_NAME["etdlin"],
+                     "n_nonfinite": env.step_stats()["n_nonfinite"], "max_sim_time": env.max_sim_time}
+    del env
+    rk = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, max_sim_time=40.0, integrator="rk4", micro_steps=3750, seed=2024,
+                  auto_reset=True)
+    rk.reset()
+    rk.step(acts[0], return_tensors=False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(1, classic_steps + 1):
+        rk.step(acts[i], return_tensors=False)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    out["classic_rk4"] = {"value": N * classic_steps / el, "unit": "env-steps/s", "steps": classic_steps, "micro_steps": 3750,
+                          "us_per_step": 1e6 * el / classic_steps, "region_us_per_step": e0.elapsed_time(e1) * 1e3 / classic_steps,
+                          "kernel": KERNEL_NAME["rk4"], "n_nonfinite": rk.step_stats()["n_nonfinite"],
+                          "note": "4096 envs are 16 workgroups on 256 CUs: a latency figure (the 65 536-env rate is the classic_rk4 key)"}
+    return out
+
+
+def desynchronised_leg(torch, dev, N, n_sub, steps=640, warm=160):
+    """The headline's workload with the envs' episode phases SPREAD: staggered masked resets leave env e at
+    clock (e * 7919 mod 160) env steps into its episode, so that every wave mixes quiet lanes with lanes at an event row, one
+    env in 160 ends its episode in any step, and the launch's clock hint (pvder_plan_hint: where a batch in lockstep IS)
+    names the clock of 1 env in 160.  The per-lane schedule is tested for correctness
+    (tests/test_gpu_etdlin.py::test_etdlin_schedule_is_per_lane); this is what it costs."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2024, events_spec=events_on_spec(), auto_reset=True)
+    env.reset()
+    ep = int(round(env.max_sim_time * 60 / n_sub))                    # env steps per episode (160)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    acts = torch.randint(0, 5, (max(steps, ep), N), generator=gen, device=dev, dtype=torch.uint8)
+    phase = (torch.arange(N, device=dev, dtype=torch.int64) * 7919) % ep
+    for k in range(ep):               # after these ep steps env e is (ep - 1 - phase[e]) steps behind its last masked reset
+        env.step(acts[k], return_tensors=False)
+        env.reset(phase == k)
+    env.rollout(acts[:warm], fused=False)
+    spread = int(torch.unique(env.istate[0]).numel())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    e0.record(); env.rollout(acts[:steps], fused=False); e1.record()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    per = e0.elapsed_time(e1) * 1e-3 / steps
+    return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "us_per_step": 1e6 * el / steps,
+            "region_us_per_step": per * 1e6, "distinct_clocks_in_the_batch": spread, "episode_steps": ep,
+            "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK, "kernel": KERNEL_NAME["etdlin"],
+            "n_nonfinite": env.step_stats()["n_nonfinite"],
+            "workload": "%d envs, events on, random actions, auto-reset, episode phases spread over all %d clocks by staggered masked "
+                        "resets: waves mix quiet and event lanes, the clock hint misses, a few envs end their episode in every step" % (N, ep)}
 
 
 def large_batch_leg(torch, dev, n_sub, N=1 << 20, steps=300, warm=60):
@@ -848,7 +944,7 @@ def run_rank(args):
         # `value` stays the payload of the command line (default "full": what BASELINE configs[3] names)
         if native is not None:
             main_payload = args.payload
-            for pl in ("full", "reward_done"):
+            for pl in ("full", "obs8", "reward_done"):
                 if pl == main_payload:
                     continue
                 native.payload = pl
@@ -987,6 +1083,8 @@ def run_rank(args):
             legs = dict(payload_legs)
             legs[args.payload if native is not None else "full"] = main
             out["payload_legs"] = {"compute_only": compute_only, **{k: legs[k] for k in sorted(legs)}}
+            kc = (compute_only or {}).get("kernel_avg_ms") or (compute_only or {}).get("ms_per_step")
+            out["expected_payload_efficiency"] = expected_payload_efficiency(world, N, (kc or 0.0) * 1e-3, args.gather_every)
             out["xgmi_bound"] = {"bytes_received_per_step_per_gpu": (world - 1) * blk,
                                  "link_GBps_one_direction": 76.5,
                                  "min_us_per_step": blk / 76.5e9 * 1e6 if world > 1 else 0.0,
@@ -1001,6 +1099,9 @@ def run_rank(args):
                     out["large_batch"] = large_batch_leg(torch, dev, args.n_sub, N=args.large_batch)
                 if args.single_env_steps > 0:
                     out["single_env"] = single_env_leg(args.single_env_steps)
+                if args.side_legs:
+                    out["configs1"] = configs1_leg(torch, dev)
+                    out["desynchronised"] = desynchronised_leg(torch, dev, N, args.n_sub)
                 if args.fixed_policy:
                     out["fixed_policy"] = fixed_policy_leg(torch, dev, N, args.n_sub)
                     out["lane_params"] = lane_params_leg(torch, dev, args.n_sub)

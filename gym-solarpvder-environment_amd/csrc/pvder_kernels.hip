@@ -4389,7 +4389,20 @@ struct pvder_gather {
     hipStream_t stream;
     hipEvent_t ready[2], done[2];
     bool pending[2];
+    float *stage[2];         // "obs8" payload: the ten rows a step sends, packed (allocated at the first such call)
+    int stage_envs;
 };
+
+// the "obs8" payload (PVDER_GATHER_OBS8): rows 0-7 (the dynamic observations) and 11-12 (reward, done) of an output block side
+// by side -- rows 8-10 (Vdc_ref, Q_ref, t / max_sim_time) follow from the actions and the step count, which whoever chose the
+// actions holds already (PVDER_env.py:198-229, :540): 10 of 13 rows on the links
+__global__ __launch_bounds__(kBlock) void pack_obs8_kernel(const float *__restrict__ out, float *__restrict__ stage, int n_env) {
+    const size_t N = (size_t)n_env;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (size_t)PVDER_GATHER_OBS8_ROWS * N) return;
+    const size_t r = i / N, e = i - r * N;
+    stage[i] = out[(r < 8 ? r : r + 3) * N + e];
+}
 
 int pvder_gather_create(pvder_gather **out, void *nccl_all_gather, void *comm) {
     if (!out || !nccl_all_gather || !comm) return PVDER_EINVAL;
@@ -4399,6 +4412,8 @@ int pvder_gather_create(pvder_gather **out, void *nccl_all_gather, void *comm) {
     g->all_gather = (nccl_all_gather_fn)nccl_all_gather;
     g->comm = comm;
     g->pending[0] = g->pending[1] = false;
+    g->stage[0] = g->stage[1] = nullptr;
+    g->stage_envs = 0;
     g->stream = nullptr;
     g->ready[0] = g->ready[1] = g->done[0] = g->done[1] = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
@@ -4424,6 +4439,7 @@ void pvder_gather_destroy(pvder_gather *g) {
     (void)hipStreamSynchronize(g->stream);
     for (int b = 0; b < 2; ++b) { (void)hipEventDestroy(g->ready[b]); (void)hipEventDestroy(g->done[b]); }
     (void)hipStreamDestroy(g->stream);
+    for (int b = 0; b < 2; ++b) if (g->stage[b]) (void)hipFree(g->stage[b]);
     delete g;
 }
 
@@ -4459,7 +4475,17 @@ int pvder_plan_rollout_gather_rows(const pvder_plan *plan, pvder_gather *g, void
                                    int n_rows, int full_every, long long step_index0) {
     if (!plan || !g || n_steps < 0 || !actions || !out0 || !out1 || !recv0 || !recv1) return PVDER_EINVAL;
     if (plan->integrator >= PVDER_INT_RK45) return PVDER_EINVAL;     // (fp32 blocks only)
-    if (row0 < 0 || n_rows < 1 || row0 + n_rows > PVDER_OROWS) return PVDER_EINVAL;
+    const bool obs8 = row0 == PVDER_GATHER_OBS8;
+    if (!obs8 && (row0 < 0 || n_rows < 1 || row0 + n_rows > PVDER_OROWS)) return PVDER_EINVAL;
+    if (obs8 && g->stage_envs != plan->n_env) {        // (first obs8 call, or another batch: the staging blocks; not under capture)
+        for (int b = 0; b < 2; ++b) {
+            if (g->stage[b]) (void)hipFree(g->stage[b]);
+            g->stage[b] = nullptr;
+            const hipError_t e = hipMalloc((void **)&g->stage[b], sizeof(float) * PVDER_GATHER_OBS8_ROWS * (size_t)plan->n_env);
+            if (e != hipSuccess) { g->stage_envs = 0; return hip_rc(e); }
+        }
+        g->stage_envs = plan->n_env;
+    }
     hipStream_t st = (hipStream_t)stream;
     float *outs[2] = {out0, out1}, *recvs[2] = {recv0, recv1};
     for (int k = 0; k < n_steps; ++k) {
@@ -4474,9 +4500,15 @@ int pvder_plan_rollout_gather_rows(const pvder_plan *plan, pvder_gather *g, void
         if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->ready[b], 0);
         if (e != hipSuccess) return hip_rc(e);
         const bool full = full_every > 1 && (step_index0 + k + 1) % full_every == 0;
-        const int r0 = full ? 0 : row0, nr = full ? PVDER_OROWS : n_rows;
+        const int r0 = full ? 0 : row0, nr = full ? PVDER_OROWS : (obs8 ? PVDER_GATHER_OBS8_ROWS : n_rows);
         const size_t count = (size_t)nr * plan->n_env;
-        const int nrc = g->all_gather(outs[b] + (size_t)r0 * plan->n_env, recvs[b], count, 7 /* ncclFloat32 */, g->comm, g->stream);
+        const float *send = outs[b] + (size_t)(obs8 && !full ? 0 : r0) * plan->n_env;
+        if (obs8 && !full) {                          // pack on the gather's own stream: off the step kernels' critical path
+            hipLaunchKernelGGL(pack_obs8_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, g->stream,
+                               outs[b], g->stage[b], plan->n_env);
+            send = g->stage[b];
+        }
+        const int nrc = g->all_gather(send, recvs[b], count, 7 /* ncclFloat32 */, g->comm, g->stream);
         if (nrc != 0) return -20000 - nrc;
         e = hipEventRecord(g->done[b], g->stream);
         if (e != hipSuccess) return hip_rc(e);

@@ -46,8 +46,13 @@ def gather_outputs(out_local: torch.Tensor, buf: Optional[torch.Tensor] = None, 
 #   "full"         rows 0..12 every step
 #   "reward_done"  rows 11, 12 (reward, done) every step: 0.5 MB per peer
 #   "full_every_k" (reward, done) every step, the whole block every k-th step
-PAYLOADS = ("full", "reward_done", "full_every_k")
+#   "obs8"         rows 0-7 (the eight dynamic observations) + 11, 12 every step: rows 8-10 -- Vdc_ref, Q_ref, tStart / max_sim_time
+#                  -- follow from the actions and the step count (PVDER_env.py:198-229, :540; `bookkeeping_rows` below), which a
+#                  consumer that chose the actions holds already: 10 of 13 rows, 23 % less on the links
+PAYLOADS = ("full", "reward_done", "full_every_k", "obs8")
 REWARD_ROW = 11
+OBS8 = -8                      # include/pvder_hip.h PVDER_GATHER_OBS8: (first row, rows) = (OBS8, 10)
+OBS8_ROWS = 10
 
 
 def check_payload(payload: str, every: int = 1) -> None:
@@ -70,12 +75,48 @@ def payload_rows(payload: str, step_index: int, every: int = 1) -> Tuple[int, in
     check_payload(payload, every)
     if payload == "full" or (payload == "full_every_k" and (step_index + 1) % every == 0):
         return 0, 13
+    if payload == "obs8":
+        return OBS8, OBS8_ROWS
     return REWARD_ROW, 2
+
+
+def pack_obs8(out_local: torch.Tensor) -> torch.Tensor:
+    """[13, N] output block -> the [10, N] block the "obs8" payload sends (rows 0-7, 11, 12)."""
+    return torch.cat([out_local[:8], out_local[REWARD_ROW:REWARD_ROW + 2]], dim=0)
+
+
+def bookkeeping_rows(prev: torch.Tensor, actions: torch.Tensor, done: torch.Tensor, del_qref: float, del_vdcref: float,
+                     vdc_ref0: float, n_sub: int, inv_max_sim_time: float, auto_reset: bool = True,
+                     prev_done: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rows 8-10 of the output block -- Vdc_ref, Q_ref, tStart / max_sim_time -- after the step that took ``actions`` from a
+    state whose rows 8-10 were ``prev`` ([3, N] fp32), recomputed where the actions were chosen instead of shipped ("obs8"):
+    action_calc (PVDER_env.py:198-229) in the kernels' fp32 arithmetic (del_qref / del_vdcref: pvder_step_cfg, per unit), the
+    clock in sim time steps (:155-160, :540) and, with ``auto_reset``, the same-step restart of the envs whose ``done`` flag
+    the step returned (Vdc_ref0, 0, 0).  Without auto-reset pass ``prev_done``: a finished env returns the stale tuple
+    (:145-152).  Bit-identical to what the kernel wrote (tests/test_distributed.py)."""
+    f32, dev = torch.float32, prev.device
+    c = lambda x: torch.tensor(x, dtype=f32, device=dev)
+    zero = torch.zeros((), dtype=f32, device=dev)
+    a = actions.to(device=dev, dtype=torch.int64)
+    q = prev[1] + torch.where(a == 1, c(del_qref), zero) - torch.where(a == 2, c(del_qref), zero)
+    vdc = prev[0] + torch.where(a == 3, c(del_vdcref), zero) - torch.where(a == 4, c(del_vdcref), zero)
+    # the clock: prev[2] = fp32(ksub / 60 * inv_tmax) -> ksub back (exact: ksub <= 30 000), advanced by n_sub
+    ksub = torch.round(prev[2].double() * 60.0 / inv_max_sim_time).to(torch.int64) + n_sub
+    t = (ksub.to(f32) * c(1.0 / 60.0)) * c(inv_max_sim_time)
+    if auto_reset:
+        d = done.to(dev).bool()
+        vdc, q, t = torch.where(d, c(vdc_ref0), vdc), torch.where(d, zero, q), torch.where(d, zero, t)
+    elif prev_done is not None:
+        s_ = prev_done.to(dev).bool()
+        vdc, q, t = torch.where(s_, prev[0], vdc), torch.where(s_, prev[1], q), torch.where(s_, prev[2], t)
+    return torch.stack([vdc, q, t])
 
 
 def gather_payload(out_local: torch.Tensor, step_index: int, payload: str = "full", every: int = 1, group=None):
     """One step's collective with a payload choice: returns (gathered [world, rows, N_local], first row, rows)."""
     r0, nr = payload_rows(payload, step_index, every)
+    if r0 == OBS8:
+        return gather_outputs(pack_obs8(out_local), None, group), r0, nr
     return gather_outputs(out_local[r0:r0 + nr], None, group), r0, nr
 
 
@@ -95,7 +136,8 @@ class ShardedPVDERVec:
     def __init__(self, total_envs: int, device, group=None, payload: str = "full", gather_every: int = 1, **env_kwargs):
         """``payload`` / ``gather_every``: what a step collates (PAYLOADS).  With "reward_done" / "full_every_k" a step
         returns the GLOBAL reward and done and, on the steps without the whole block, ``None`` for the observation
-        (the local shard's is ``self.env.obs``)."""
+        (the local shard's is ``self.env.obs``); with "obs8" the [N_total, 8] DYNAMIC observations (entries 0-7: the set
+        points and the clock follow from the actions, `bookkeeping_rows`)."""
         from .vec_env import PVDERVec
         check_payload(payload, gather_every)
         self.payload, self.gather_every, self._step_index = payload, int(gather_every), 0
@@ -122,6 +164,10 @@ class ShardedPVDERVec:
         r0, nr = payload_rows(self.payload, k, self.gather_every)
         if nr == 13:
             return self._collate() + ({},)
+        if r0 == OBS8:
+            # the eight dynamic observations + reward + done of every env; rows 8-10: `bookkeeping_rows` where the actions are
+            g = global_view(gather_outputs(pack_obs8(self.env.out), None, self.group))     # [N_total, 10]
+            return g[:, :8], g[:, 8], g[:, 9] != 0, {}
         g = global_view(gather_outputs(self.env.out[r0:r0 + nr], None, self.group))       # [N_total, 2]
         return None, g[:, 0], g[:, 1] != 0, {}
 

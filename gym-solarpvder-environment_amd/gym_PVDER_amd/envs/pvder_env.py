@@ -121,7 +121,10 @@ class PVDER(EnvSpecMixin):
                              env_id_base=PVDER.count - 1, **kw)
         self.max_sim_time_user = max_sim_time
         self._actions = [torch.full((1,), a, dtype=torch.uint8, device=self._vec.device) for a in range(5)]
-        self._pack = torch.zeros(17, dtype=torch.float64, device=self._vec.device)
+        # host mirrors of the output block and the counters: pinned, filled by two asynchronous copies behind the launch
+        self._pin_out = torch.zeros(13, dtype=self._vec.fdtype).pin_memory()
+        self._pin_ist = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._rb_done = torch.cuda.Event()
         self._host_out, self._host_ist = [0.0] * 13, [0] * 4
         if record_trajectory:      # the reference always keeps the solution rows (self.results, :389)
             self._vec.record_trajectory(self._vec.max_episode_steps + 1)
@@ -147,13 +150,16 @@ class PVDER(EnvSpecMixin):
     env = property(lambda s: s)            # examples use env.env.sim (gym TimeLimit wrapper idiom)
 
     def _read_back(self):
-        """One device-to-host copy of the env's output block and counters (17 words) into the host
-        mirrors every accessor below reads -- instead of one synchronising read per attribute."""
+        """The env's output block and counters (17 words) into the host mirrors every accessor below reads: two asynchronous
+        copies into PINNED memory behind the step launch and ONE event wait -- no pack kernels, no pageable staging copy, no
+        synchronising read per attribute (round 4: two device copies + a blocking .tolist(): 58 us per step)."""
         v = self._vec
-        self._pack[:13].copy_(v.out[:, 0])
-        self._pack[13:].copy_(v.istate[:, 0])                        # int32 -> fp64: exact
-        h = self._pack.tolist()
-        self._host_out, self._host_ist = h[:13], [int(x) for x in h[13:]]
+        with torch.cuda.device(v.device):
+            self._pin_out.copy_(v.out.reshape(-1), non_blocking=True)
+            self._pin_ist.copy_(v.istate.reshape(-1), non_blocking=True)
+            self._rb_done.record()
+            self._rb_done.synchronize()
+        self._host_out, self._host_ist = self._pin_out.tolist(), self._pin_ist.tolist()
 
     @property
     def steps(self):                                                 # env_utilities.py:48-52

@@ -241,9 +241,11 @@ class PVDERVec(EnvSpecMixin):
         self.fdtype = torch.float64 if integrator in ("rk45", "etdlin64") else torch.float32
         N = num_envs
         self._alloc_event_tables()
-        self.fstate = torch.zeros((self.ns + 2, N), dtype=self.fdtype, device=self.device)
+        # state rows and output block are the two halves of ONE allocation: a trajectory snapshot is then one device copy
+        self._state_and_out = torch.zeros((self.ns + 2 + 13, N), dtype=self.fdtype, device=self.device)
+        self.fstate = self._state_and_out[:self.ns + 2]
         self.istate = torch.zeros((4, N), dtype=torch.int32, device=self.device)
-        self.out = torch.zeros((13, N), dtype=self.fdtype, device=self.device)
+        self.out = self._state_and_out[self.ns + 2:]
         # per-workgroup partial statistics of the last step ([n_wg, 4]; summed on demand by step_stats)
         n_wg = (num_envs + self._lib.pvder_block_size() - 1) // self._lib.pvder_block_size()
         self.stats = torch.zeros((n_wg * (self._lib.pvder_block_size() // 64), 4), dtype=torch.float32,
@@ -852,8 +854,11 @@ class PVDERVec(EnvSpecMixin):
         ids, ns = self._traj_ids, self.ns
         slot = self._traj[self._traj_n % self._traj.shape[0]]
         if ids is None:
-            slot[: ns + 2].copy_(self.fstate)
-            slot[ns + 2: ns + 15].copy_(self.out)
+            if self.out.data_ptr() == self._state_and_out[ns + 2:].data_ptr():
+                slot[: ns + 15].copy_(self._state_and_out)           # (the env's own output block: one copy for both)
+            else:
+                slot[: ns + 2].copy_(self.fstate)
+                slot[ns + 2: ns + 15].copy_(self.out)
             slot[ns + 15].copy_(self.istate[0])                      # int32 -> float: exact
         else:
             slot[: ns + 2].copy_(self.fstate.index_select(1, ids))

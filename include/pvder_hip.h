@@ -397,6 +397,13 @@ int pvder_plan_rollout_gather(const pvder_plan *plan, pvder_gather *g, void *fst
  * (full_every <= 1: never).  A partial gather fills the first world * n_rows rows of its recv block.  The consumer
  * decides what it needs every step: a policy evaluated where its env lives needs the peers' rewards and dones (for
  * the return statistics / the episode bookkeeping), not their observations. */
+/* row0 = PVDER_GATHER_OBS8 (n_rows ignored): the "obs8" payload -- rows 0-7 (the eight DYNAMIC observations) and 11-12 (reward,
+ * done), packed side by side by a small kernel on the gather's stream and collated as [world * 10, n_env]: rows 8-10 (Vdc_ref,
+ * Q_ref, tStart / max_sim_time) follow from the actions and the step count (PVDER_env.py:198-229, :540), which a consumer that
+ * chose the actions holds already -- 10 of 13 rows, 23 % less on the links than "full".  The staging blocks (2 x 10 x n_env
+ * floats) are allocated at the first such call (not under stream capture). */
+#define PVDER_GATHER_OBS8 (-8)
+#define PVDER_GATHER_OBS8_ROWS 10
 int pvder_plan_rollout_gather_rows(const pvder_plan *plan, pvder_gather *g, void *fstate, int32_t *istate, float *ev_vg,
                                    float *ev_si, const uint8_t *actions, int n_steps, float *out0, float *out1, float *recv0,
                                    float *recv1, float *stats, void *stream, int first_block, int sync_each, int row0,

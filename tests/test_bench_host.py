@@ -25,9 +25,14 @@ def test_launcher_starts_n_ranks_by_itself():
     # ONE N > 1 run carries the three legs -- no collation, the whole block, (reward, done) -- each payload
     # with its own xGMI fraction (here: gloo on the CPU, the structure of the line)
     legs = d["payload_legs"]
-    assert set(legs) == {"compute_only", "full", "reward_done"}
-    assert legs["full"]["rows_per_step"] == 13.0 and legs["reward_done"]["rows_per_step"] == 2.0
-    for k in ("full", "reward_done"):
+    assert set(legs) == {"compute_only", "full", "obs8", "reward_done"}
+    assert legs["full"]["rows_per_step"] == 13.0 and legs["reward_done"]["rows_per_step"] == 2.0 and legs["obs8"]["rows_per_step"] == 10.0
+    # ... and what xGMI allows each payload before anything is measured: kernel / max(kernel, link time of one block)
+    exp = d["expected_payload_efficiency"]
+    assert set(exp) == {"full", "obs8", "reward_done", "full_every_k"}
+    assert abs(exp["full"]["link_us_per_step"] - 13 * 65536 * 4 / 76.5e9 * 1e6) < 1e-6
+    assert exp["full"]["expected_efficiency"] < exp["obs8"]["expected_efficiency"] < exp["reward_done"]["expected_efficiency"] <= 1.0
+    for k in ("full", "obs8", "reward_done"):
         x = legs[k]["xgmi_roofline"]
         assert x["bound"] == "xgmi" and x["bytes_received_per_step_per_gpu"] == 256 * 4 * legs[k]["rows_per_step"] and x["frac"] > 0
     assert all(v["value"] > 0 for v in legs.values())

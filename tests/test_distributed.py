@@ -42,6 +42,11 @@ def _worker(rank, world, port, total, q):
             ok = ok and nr == want_rows[k] and (r0, nr) == payload_rows(payload, k, every) and gp.shape == (world, nr, n_local)
             gv = global_view(gp)                                           # [total, nr]
             ok = ok and torch.equal(gv, want[:, r0:r0 + nr])
+    # "obs8" (VERDICT r4 #8): rows 0-7 + 11, 12 in ONE collective -- what cannot be recomputed from the actions
+    from gym_PVDER_amd.distributed import OBS8, OBS8_ROWS
+    gp, r0, nr = gather_payload(out_local, 0, "obs8")
+    ok = ok and (r0, nr) == (OBS8, OBS8_ROWS) == payload_rows("obs8", 5) and gp.shape == (world, 10, n_local)
+    ok = ok and torch.equal(global_view(gp), want[:, [0, 1, 2, 3, 4, 5, 6, 7, 11, 12]])
     try:                                        # ONE validator on every layer: a period below 2 is rejected, not reinterpreted
         payload_rows("full_every_k", 0, 1)
         ok = False
@@ -73,3 +78,28 @@ def test_shard_range():
     assert [shard_range(64, r, 4) for r in range(4)] == [(0, 16), (16, 16), (32, 16), (48, 16)]
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+def test_bookkeeping_rows_recompute_the_rows_obs8_leaves_out():
+    """distributed.bookkeeping_rows: Vdc_ref / Q_ref / clock of the next step from the actions alone -- action_calc
+    (PVDER_env.py:198-229) in fp32, the clock in sim time steps (:540), the same-step auto-reset, the stale tuple (:145-152)."""
+    sys.path.insert(0, os.path.join(ROOT, "gym-solarpvder-environment_amd"))
+    from gym_PVDER_amd.distributed import bookkeeping_rows, check_payload
+    f = np.float32
+    dq, dv, v0, n, inv = 25.0 * 15 / 50e3, 0.02 * 15 / 500.0, 1.1, 15, 1.0 / 40.0
+    prev = torch.tensor([[1.1, 1.1, 1.1, 1.1, 1.1, 1.0], [0.0, 0.0, 0.0, 0.0, 0.0, 0.3],
+                         [0.0, 0.0, 0.0, 0.0, 0.0, float(f(2385) * f(1.0 / 60.0) * f(inv))]], dtype=torch.float32)
+    acts = torch.tensor([0, 1, 2, 3, 4, 1])
+    done = torch.tensor([0, 0, 0, 0, 0, 1])
+    got = bookkeeping_rows(prev, acts, done, dq, dv, v0, n, inv).numpy()
+    t1 = f(15) * f(1.0 / 60.0) * f(inv)
+    assert np.array_equal(got[0], np.array([1.1, 1.1, 1.1, f(1.1) + f(dv), f(1.1) - f(dv), 1.1], dtype=f))
+    assert np.array_equal(got[1], np.array([0, f(dq), -f(dq), 0, 0, 0], dtype=f))          # (env 5 finished: restarted)
+    assert np.array_equal(got[2], np.array([t1, t1, t1, t1, t1, 0], dtype=f))
+    stale = bookkeeping_rows(prev, acts, done, dq, dv, v0, n, inv, auto_reset=False, prev_done=torch.tensor([0, 0, 0, 0, 0, 1])).numpy()
+    assert np.array_equal(stale[:, 5], prev[:, 5].numpy()) and np.array_equal(stale[:, :5], got[:, :5])
+    last = bookkeeping_rows(prev, acts, done, dq, dv, v0, n, inv, auto_reset=False).numpy()  # the step that ENDS an episode: advanced
+    assert last[1, 5] == f(0.3) + f(dq) and last[2, 5] == f(2400) * f(1.0 / 60.0) * f(inv)
+    check_payload("obs8"); check_payload("full_every_k", np.int64(4))
+    with pytest.raises(ValueError):
+        check_payload("full_every_k", 1.5)

@@ -541,6 +541,25 @@ def test_native_step_gather_world1(gpu_device):
             else:
                 assert torch.equal(nat.last()[:2], a.out[11:13]), (payload, k)
             assert torch.equal(b.out, a.out)
+    # "obs8" (VERDICT r4 #8): rows 0-7 + 11, 12 collated; rows 8-10 recomputed from the actions (distributed.bookkeeping_rows), bit
+    # for bit, through an episode end with same-step auto-reset (max_sim_time 1.5 s: six env steps per episode)
+    from gym_PVDER_amd.distributed import bookkeeping_rows
+    from gym_PVDER_amd import der_model
+    nat.payload, nat.gather_every = "obs8", 1
+    cfg = a._cfg()
+    rows = a.out[8:11].clone()
+    ends = 0
+    for k in range(K):
+        a.step(acts[k], return_tensors=False)
+        nat.rollout(acts[k:k + 1])
+        nat.drain()
+        torch.cuda.synchronize()
+        assert torch.equal(nat.last()[:8], a.out[:8]) and torch.equal(nat.last()[8:10], a.out[11:13]), k
+        rows = bookkeeping_rows(rows, acts[k], nat.last()[9], cfg.del_qref, cfg.del_vdcref, float(a.par[der_model.IDX["VDC_REF0"]]),
+                                cfg.n_sub, cfg.inv_max_sim_time, auto_reset=True)
+        assert torch.equal(rows, a.out[8:11]), k
+        ends += int(a.out[12].sum().item())
+    assert ends >= N                                # every env ended an episode on the way
     nat.close()
     rc.close()
     dist.destroy_process_group()
