@@ -3296,23 +3296,24 @@ __global__ __launch_bounds__(kBlock) void step_rk45_kernel(
 // etdlin64 -- the tolerance-match path that is not stability-bound (BASELINE configs[4]).
 // The explicit RK45 pair above resolves the stiff current loop: 62 000 accepted steps per env step, 0.55 s per batched
 // step.  This kernel runs the etdlin scheme in DOUBLE on the balanced 11-state reduction -- the exponential carries the
-// stiff loop exactly -- with STEP DOUBLING on a dyadic menu as its error control: level j takes an ETD3RK tick behind
-// the input jump and 2^(j+1) equal ETD3RK steps over the rest of the env step; the result of level j is accepted
+// stiff loop exactly -- with STEP DOUBLING on a dyadic menu as its error control: level j takes a Krogstad ETDRK4 tick behind
+// the input jump and 2^(j+1) equal Krogstad steps over the rest of the env step; the result of level j is accepted
 // when it differs from that of level j-1 by less than the tolerance in the RK45 kernel's norm.  PER LANE: a wave climbs the menu until
 // each of its lanes has accepted; a lane's result depends on its own values only.  PVDER-v0 steps resolve at level 1
-// (tick + 2, tick + 4 steps), the step behind an event at 16-32 steps, the step behind a reset -- the PLL swings a
-// quarter turn into lock -- at 256.
+// (tick + 2, tick + 4 steps), a few per cent at level 2, the step behind a reset -- the PLL swings a quarter turn into lock -- at 128.
 // Envs the reduction does not cover -- off balance, near the duty-cycle or current limit, an event inside the env
 // step, nothing accepted at the finest pair -- are marked kDeferred and taken by step_rk45_kernel in the follow-up
-// launch.  Dense 11x11 products on the fp64 VALU, operands broadcast from LDS (10 sets x 6 matrices: 62 KB).
+// launch.  Dense 11x11 products on the fp64 VALU in ROLLED column loops, operands broadcast from LDS (8 sets x 10 matrices:
+// 84 KB, dynamic), the lane's right-hand side staged in LDS beside them: 256 VGPRs + 66 AGPRs, NO scratch.
 // fp64 prototype on the goldens (etd_linear.lin64_reference_step): <= 1.5e-6 of the converged solution.
+// Round 5: 2.83 -> 0.20 ms per batched step at 65 536 envs (worst step 6.1 -> 0.33 ms), 1.03e-6 of the bridge
+// (profiles/r05_l64_accept_sweep.txt): Krogstad steps (the tail of the level distribution is what a launch waits for) and the
+// rolled products (14 us per step of four right-hand sides and ten products; round 4: 30 us per ETD3RK step, 99 spilled VGPRs).
 // =============================================================================================
-constexpr int kL64Cols = 12, kL64Mat = 11 * kL64Cols, kL64Set = 6 * kL64Mat, kL64MaxLevels = 9;
-// acceptance: two consecutive levels agree to kL64Accept x the tolerance.  Richardson would allow 7 if the scheme
-// converged at its classical order 3 -- it does between events, but the env step behind a grid-voltage / insolation
-// event converges at order ONE (stiff order reduction on the slaved current loop: true error, in units of the
-// tolerance, 3.9 2.5 1.5 0.73 0.35 for 2 .. 32 steps), where the error IS the difference: factor 1
-// (65 536 envs x 14 steps against the converged bridge: 3.7e-6 with 7, 8e-7 with 1)
+constexpr int kL64Cols = 12, kL64Mat = 11 * kL64Cols, kL64Set = 10 * kL64Mat, kL64MaxLevels = 9;
+// acceptance: two consecutive levels agree to kL64Accept x the tolerance -- no Richardson credit: behind an input jump the
+// schemes lose order on the slaved current loop (ETD3RK to ONE: true error, in units of the tolerance, 3.9 2.5 1.5 0.73 0.35
+// for 2 .. 32 steps; Krogstad to ~3), where the error is close to the difference: factor 1
 constexpr double kL64Accept = 1.0;
 constexpr int kL64MinLevel = 1;
 struct Lin64K {
@@ -3323,47 +3324,32 @@ struct Lin64K {
     double sat2, ir2_guard;          // hand-over guards: |m|^2, |iref|^2
 };
 
-// acc[j] += M_mat[j] f.  A matrix sits in LDS COLUMN by column ([11 columns][12 doubles]: column k = the 11 entries
-// that multiply f[k], read as six broadcast 16-byte words); one column per matrix is in flight while the previous
-// one is multiplied -- left to itself hipcc hoists all 121 x NM operand reads above the arithmetic and spills 1500
-// registers (the sched_barrier pins the pipeline to depth one).
+// acc[j] += M_mat[j] f  for NM matrices of one set at once.  A matrix sits in LDS COLUMN by column ([11 columns][12 doubles]:
+// column k = the 11 entries that multiply f[k], read as six broadcast 16-byte words); the lane's f sits in LDS too
+// (Fl[k * kBlock]: written by the caller behind each right-hand side).  Round 5: a ROLLED loop over the columns -- the body is
+// 6 NM operand reads, one read of f[k] and 11 NM fused multiply-adds with static register indices; nothing for hipcc to hoist
+// (round 4 unrolled the 121 x NM products and pinned a depth-one pipeline with scheduling barriers: 24 operand registers in
+// flight, and still 99 spilled registers around it).
 template <int NM>
-__device__ __forceinline__ void mv64(const double *__restrict__ Mset_, const int (&mat)[NM], const double (&f)[11],
+__device__ __forceinline__ void mv64(const double *__restrict__ Mset, const int (&mat)[NM], const double *__restrict__ Fl,
                                      double (&acc)[NM][11]) {
-    // an opaque copy of the set's address per product: the operands are loop invariants of the step loop, and
-    // hoisted out of it they are 792 doubles per set (the fp32 ETDRK4 kernels play the same trick on their LDS block)
-    const double *Mset = Mset_;
-    asm volatile("" : "+v"(Mset));
-    double2 cur[NM][6], nxt[NM][6];
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-        const double2 *col = (const double2 *)(Mset + mat[j] * kL64Mat);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) cur[j][q] = col[q];
-    }
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 11; ++k) {
-        if (k + 1 < 11) {
+        double2 col[NM][6];
 #pragma unroll
-            for (int j = 0; j < NM; ++j) {
-                const double2 *col = (const double2 *)(Mset + mat[j] * kL64Mat + (k + 1) * kL64Cols);
+        for (int j = 0; j < NM; ++j) {
+            const double2 *c = (const double2 *)(Mset + mat[j] * kL64Mat + k * kL64Cols);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) nxt[j][q] = col[q];
-            }
+            for (int q = 0; q < 6; ++q) col[j][q] = c[q];
         }
-        const double fk = f[k];
+        const double fk = Fl[k * kBlock];
 #pragma unroll
         for (int j = 0; j < NM; ++j)
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                acc[j][2 * q] = fma(cur[j][q].x, fk, acc[j][2 * q]);
-                if (2 * q + 1 < 11) acc[j][2 * q + 1] = fma(cur[j][q].y, fk, acc[j][2 * q + 1]);
+                acc[j][2 * q] = fma(col[j][q].x, fk, acc[j][2 * q]);
+                if (2 * q + 1 < 11) acc[j][2 * q + 1] = fma(col[j][q].y, fk, acc[j][2 * q + 1]);
             }
-#pragma unroll
-        for (int j = 0; j < NM; ++j)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) cur[j][q] = nxt[j][q];
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // |m_a|^2 and |iref_a|^2 at a balanced state
@@ -3376,42 +3362,68 @@ __device__ __forceinline__ void guards64(const ModelK<double> &P, const SubK<dou
     const double rR = y[7] + P.KpDC * (vdcref - y[6]), rI = y[8] - P.KpQ * (qref - Q);
     ir2 = rR * rR + rI * rI;
 }
-// (a real function: inlined at its two call sites the step kept 1100 values alive and spilled 600 of them -- 1.18 ms
-// per batched step against 0.51 ms with the call; this kernel is not launch-latency-bound, its scratch frame is harmless)
-#ifdef PVDER_L64_INLINE
-#define L64_INLINE __forceinline__
-#else
-#define L64_INLINE __noinline__
-#endif
-// one ETD3RK step in f-form (one matrix at a time: 24 operand registers in flight); returns max |m|^2 over its start
-// and end, |iref|^2 at its start
-__device__ __forceinline__ void mv64_one(const double *__restrict__ Mset, int mat, const double (&f)[11], double (&acc)[11]) {
-    const int m1[1] = {mat};
-    double a1[1][11];
-#pragma unroll
-    for (int i = 0; i < 11; ++i) a1[0][i] = acc[i];
-    mv64<1>(Mset, m1, f, a1);
-#pragma unroll
-    for (int i = 0; i < 11; ++i) acc[i] = a1[0][i];
-}
-__device__ L64_INLINE void step64(const ModelK<double> &P, const SubK<double, 1> &S, const double *__restrict__ Mset,
-                                       const double (&y)[11], double qref, double vdcref, double (&yn)[11], double &m2max,
-                                       double &ir2) {
-    double F[11], a[11], b[11], m2a, m2b, irb;
-    guards64(P, S, y, qref, vdcref, m2a, ir2);
+// `nsteps` Krogstad ETDRK4 steps in f-form (etd_linear.k4_step; matrices KM21 ... KB4 of pvder_etdlin.hpp: four right-hand sides,
+// ten products, one matrix at a time) from u, in place; trip: a guard (|m|^2, |iref|^2) was met on the way.
+// Inlined at its ONE call site: the kernel runs the tick and every level through the same loop nest (round 4 had the step as a
+// real function, called per step, its array arguments in scratch memory: 784 B per lane; inlined at TWO call sites -- tick and
+// level loop -- the body kept 1100 values alive and spilled 600 of them).
+__device__ __forceinline__ void rhs_to_lds(const ModelK<double> &P, const SubK<double, 1> &S, const double (&y)[11], double qref,
+                                           double vdcref, double *__restrict__ Fl) {
+    double F[11];
     pvder::rhs<double, 1, 3>(P, S, y, 0.0, qref, vdcref, F);
 #pragma unroll
-    for (int i = 0; i < 11; ++i) { a[i] = y[i]; b[i] = y[i]; yn[i] = y[i]; }
-    mv64_one(Mset, pvder::LM21, F, a);
-    mv64_one(Mset, pvder::LM31, F, b);
-    mv64_one(Mset, pvder::LM41, F, yn);
-    pvder::rhs<double, 1, 3>(P, S, a, 0.0, qref, vdcref, F);
-    mv64_one(Mset, pvder::LM32, F, b);
-    mv64_one(Mset, pvder::LM42, F, yn);
-    pvder::rhs<double, 1, 3>(P, S, b, 0.0, qref, vdcref, F);
-    mv64_one(Mset, pvder::LM43, F, yn);
-    guards64(P, S, yn, qref, vdcref, m2b, irb);
-    m2max = fmax(m2a, m2b);
+    for (int i = 0; i < 11; ++i) Fl[i * kBlock] = F[i];
+}
+__device__ __forceinline__ bool run64(const ModelK<double> &P, const SubK<double, 1> &S, const double *__restrict__ Mset, int nsteps,
+                                      double (&u)[11], double qref, double vdcref, double sat2, double ir2_guard,
+                                      double *__restrict__ Fl) {
+    bool trip = false;
+#pragma unroll 1
+    for (int st = 0; st < nsteps; ++st) {
+        double m2a, m2b, ir2, irb;
+        guards64(P, S, u, qref, vdcref, m2a, ir2);
+        // stage values as running sums  w[0] = U2, w[1] = U3, w[2] = U4, w[3] = y+  (all start from y)
+        double w[4][11];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 11; ++i) w[j][i] = u[i];
+        rhs_to_lds(P, S, u, qref, vdcref, Fl);                                    // F1
+        { const int m[4] = {pvder::KM21, pvder::KM31, pvder::KM41, pvder::KB1}; mv64<4>(Mset, m, Fl, w); }
+        rhs_to_lds(P, S, w[0], qref, vdcref, Fl);                                 // F2 = f(U2)
+        {
+            const int m[3] = {pvder::KM32, pvder::KM42, pvder::KB2};
+            double v[3][11];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) { v[0][i] = w[1][i]; v[1][i] = w[2][i]; v[2][i] = w[3][i]; }
+            mv64<3>(Mset, m, Fl, v);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) { w[1][i] = v[0][i]; w[2][i] = v[1][i]; w[3][i] = v[2][i]; }
+        }
+        rhs_to_lds(P, S, w[1], qref, vdcref, Fl);                                 // F3 = f(U3)
+        {
+            const int m[2] = {pvder::KM43, pvder::KB3};
+            double v[2][11];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) { v[0][i] = w[2][i]; v[1][i] = w[3][i]; }
+            mv64<2>(Mset, m, Fl, v);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) { w[2][i] = v[0][i]; w[3][i] = v[1][i]; }
+        }
+        rhs_to_lds(P, S, w[2], qref, vdcref, Fl);                                 // F4 = f(U4)
+        {
+            const int m[1] = {pvder::KB4};
+            double v[1][11];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) v[0][i] = w[3][i];
+            mv64<1>(Mset, m, Fl, v);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) u[i] = v[0][i];
+        }
+        guards64(P, S, u, qref, vdcref, m2b, irb);
+        trip |= fmax(m2a, m2b) > sat2 || ir2 > ir2_guard;
+    }
+    return trip;
 }
 
 __global__ __launch_bounds__(kBlock) void step_etdlin64_kernel(
@@ -3420,8 +3432,9 @@ __global__ __launch_bounds__(kBlock) void step_etdlin64_kernel(
     double *__restrict__ out, float *__restrict__ stats, int n_env, int stats_fresh) {
     constexpr int NS = 23;
     const size_t N = (size_t)n_env;
-    __shared__ __attribute__((aligned(16))) double Ms[(1 + kL64MaxLevels) * kL64Set];
+    extern __shared__ __attribute__((aligned(16))) double Ms[];       // (1 + levels) x kL64Set doubles + 11 x kBlock (launch_plan sizes it)
     for (int k = threadIdx.x; k < (1 + K.levels) * kL64Set; k += kBlock) Ms[k] = K.coef[k];
+    double *Fl = Ms + (size_t)(1 + K.levels) * kL64Set + threadIdx.x;     // this lane's right-hand side: Fl[k * kBlock]
     __syncthreads();
     Lane<double> L;
     double ys[NS];
@@ -3464,24 +3477,23 @@ __global__ __launch_bounds__(kBlock) void step_etdlin64_kernel(
     double y0[11] = {ys[0], ys[1], ys[2], ys[3], ys[4], ys[5], ys[18], ys[19], ys[20], ys[21], ys[22]};
     bool active = L.run && !defer;
     if (__syncthreads_or((int)active)) {           // (workgroup-uniform; every lane of an entering wave computes)
-        double yt[11], m2, ir2;
-        step64(P, S, Ms, y0, L.qref, L.vdcref, yt, m2, ir2);              // the tick (set 0)
-        defer |= active && (m2 > K.sat2 || ir2 > K.ir2_guard);
-        double prev[11], u[11];
+        double yt[11], prev[11], u[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { yt[i] = y0[i]; prev[i] = y0[i]; }
         bool accepted = false;
-        for (int lvl = 0; lvl < K.levels; ++lvl) {
+        // lvl = -1: the tick (set 0, one step, from y0); lvl >= 0: 2^(lvl+1) steps from the tick's result -- ONE loop nest, so
+        // that the step body exists once
+        for (int lvl = -1; lvl < K.levels; ++lvl) {
             if (!__builtin_amdgcn_readfirstlane(__any((int)(active && !defer && !accepted)))) break;
             const double *Mset = Ms + (size_t)(1 + lvl) * kL64Set;
 #pragma unroll
             for (int i = 0; i < 11; ++i) u[i] = yt[i];
-            bool trip = false;
-            for (int st = 0; st < (2 << lvl); ++st) {
-                double un[11];
-                step64(P, S, Mset, u, L.qref, L.vdcref, un, m2, ir2);
-                trip |= m2 > K.sat2 || ir2 > K.ir2_guard;
+            const bool trip = run64(P, S, Mset, lvl < 0 ? 1 : (2 << lvl), u, L.qref, L.vdcref, K.sat2, K.ir2_guard, Fl);
+            if (lvl < 0) {
 #pragma unroll
-                for (int i = 0; i < 11; ++i) u[i] = un[i];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 11; ++i) yt[i] = u[i];
+                defer |= active && trip;
+                continue;
             }
             bool ok = false;
             if (lvl >= K.min_level) {
@@ -4094,7 +4106,14 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         int rk_fresh = fresh, rk_status = 0;
         if (p.integrator == PVDER_INT_ETDLIN64) {
             // the tolerance-match path on the balanced reduction; the RK45 kernel behind it takes the envs it hands over
-            hipLaunchKernelGGL(step_etdlin64_kernel, grid, block, 0, st, p.Pd, p.Cd, p.R, p.l64, (double *)fstate, istate, ev_vg,
+            const size_t lds = sizeof(double) * ((size_t)(1 + p.l64.levels) * kL64Set + 11 * (size_t)kBlock);
+            static size_t lds_allowed = 0;       // (beyond 64 KB of dynamic LDS the kernel has to be told: once per size)
+            if (lds > lds_allowed) {
+                const hipError_t e = hipFuncSetAttribute((const void *)step_etdlin64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return hip_rc(e);
+                lds_allowed = lds;
+            }
+            hipLaunchKernelGGL(step_etdlin64_kernel, grid, block, lds, st, p.Pd, p.Cd, p.R, p.l64, (double *)fstate, istate, ev_vg,
                                ev_si, action, (double *)out, stats, n_env, fresh);
             rk_fresh = 0;
             rk_status = (int)kDeferred;
@@ -4143,6 +4162,20 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
                            double *fstate, int32_t *istate, float *ev_vg, float *ev_si, const uint8_t *mask,
                            double *out, int n_env, void *stream) {
     return reset_impl<double>(par, cfg, ar, fstate, istate, ev_vg, ev_si, mask, out, n_env, stream);
+}
+
+int pvder_fetch_env(const void *out, const int32_t *istate, int n_env, int env, int fp64, void *host_out, int32_t *host_ist,
+                    void *stream) {
+    if (!out || !istate || !host_out || !host_ist || n_env < 1 || env < 0 || env >= n_env) return PVDER_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = fp64 ? sizeof(double) : sizeof(float);
+    hipError_t e = hipMemcpy2DAsync(host_out, es, (const char *)out + (size_t)env * es, (size_t)n_env * es, es, PVDER_OROWS,
+                                    hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(host_ist, sizeof(int32_t), istate + env, (size_t)n_env * sizeof(int32_t), sizeof(int32_t), 4,
+                             hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return hip_rc(e);
 }
 
 int pvder_etdrk4_coef_count(void) { return kCoefTotal; }

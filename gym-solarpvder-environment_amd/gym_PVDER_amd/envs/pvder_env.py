@@ -20,7 +20,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from .. import der_model
+from .. import _native, der_model
 from ..spaces import make_spaces
 from ..vec_env import EnvSpecMixin, PVDERVec, SIM_TIME_STEP, OBSERVED_QUANTITIES
 
@@ -124,7 +124,6 @@ class PVDER(EnvSpecMixin):
         # host mirrors of the output block and the counters: pinned, filled by two asynchronous copies behind the launch
         self._pin_out = torch.zeros(13, dtype=self._vec.fdtype).pin_memory()
         self._pin_ist = torch.zeros(4, dtype=torch.int32).pin_memory()
-        self._rb_done = torch.cuda.Event()
         self._host_out, self._host_ist = [0.0] * 13, [0] * 4
         if record_trajectory:      # the reference always keeps the solution rows (self.results, :389)
             self._vec.record_trajectory(self._vec.max_episode_steps + 1)
@@ -151,14 +150,12 @@ class PVDER(EnvSpecMixin):
 
     def _read_back(self):
         """The env's output block and counters (17 words) into the host mirrors every accessor below reads: two asynchronous
-        copies into PINNED memory behind the step launch and ONE event wait -- no pack kernels, no pageable staging copy, no
-        synchronising read per attribute (round 4: two device copies + a blocking .tolist(): 58 us per step)."""
+        copies into PINNED memory behind the step launch and ONE stream wait, enqueued from C (pvder_fetch_env) -- no pack kernels,
+        no pageable staging copy, no synchronising read per attribute (round 4: two device copies + a blocking .tolist(): 58 us
+        per step)."""
         v = self._vec
-        with torch.cuda.device(v.device):
-            self._pin_out.copy_(v.out.reshape(-1), non_blocking=True)
-            self._pin_ist.copy_(v.istate.reshape(-1), non_blocking=True)
-            self._rb_done.record()
-            self._rb_done.synchronize()
+        _native.check(v._lib.pvder_fetch_env(v.out.data_ptr(), v.istate.data_ptr(), 1, 0, 1 if v.fdtype == torch.float64 else 0,
+                                             self._pin_out.data_ptr(), self._pin_ist.data_ptr(), v._stream()), "pvder_fetch_env")
         self._host_out, self._host_ist = self._pin_out.tolist(), self._pin_ist.tolist()
 
     @property

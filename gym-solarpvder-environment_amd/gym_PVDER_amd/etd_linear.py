@@ -674,16 +674,20 @@ def seq_accept(c, zp, zn, z0):
 # ---------------------------------------------------------------------------------------------------
 # etdlin64: the fp64 tolerance-match form (BASELINE configs[4]) -- step doubling on a dyadic menu
 # ---------------------------------------------------------------------------------------------------
-LIN64_LEVELS = 9          # level j: tick + 2^(j+1) equal ETD3RK steps per env step (2, 4, ..., 512)
+LIN64_LEVELS = 7          # level j: tick + 2^(j+1) equal Krogstad ETDRK4 steps per env step (2, 4, ..., 128)
 LIN64_COLS = 12           # matrices as [11][12] doubles (rows padded to a whole number of 16-byte reads)
-LIN64_SET = 6 * NB * LIN64_COLS       # doubles per set
+LIN64_MAT = NB * LIN64_COLS
+LIN64_SET = 10 * LIN64_MAT                     # doubles per set: the ten f-form matrices of a Krogstad step (set 0: the tick)
 
 
 def pack_block64(L: np.ndarray, n_sub: int, micro: int, levels: int = LIN64_LEVELS) -> np.ndarray:
-    """float64 coefficient block of the etdlin64 kernel: set 0 = ETD3RK over the tick h0 (here the tick is a full
-    third-order step: an exponential-Euler tick leaves 1.6e-4 in the PLL angle behind a reset, which no refinement of
-    the steps behind it removes), then per level j the set for h_j = (n_sub / 60 - h0) / 2^(j+1); a set = the six
-    f-form matrices M21, M31, M32, M41, M42, M43, each stored column by column ([11 columns][12])."""
+    """float64 coefficient block of the etdlin64 kernel: set 0 = one Krogstad ETDRK4 step over the tick h0 (a full-order
+    step: an exponential-Euler tick leaves 1.6e-4 in the PLL angle behind a reset, which no refinement of the steps behind it
+    removes), then per level j the set for h_j = (n_sub / 60 - h0) / 2^(j+1); a set = the TEN f-form matrices of a Krogstad
+    step (k4_f_matrices: KM21 ... KB4), each stored column by column ([11 columns][12]).  Round 5: Krogstad steps instead of ETD3RK ones behind the tick -- on PVDER-v0 steps the
+    third-order scheme's error falls like 1/K behind an input jump (stiff order reduction on the slaved current loop), the
+    fourth-order one's like 1/K^3: 93 % of the env steps of a random-action episode are accepted at K = 4, none beyond K = 16
+    (ETD3RK: up to K = 128), tools/l64_k4_sample.py."""
     tick = 1.0 / (60.0 * micro)
     h0 = tick_length(micro) * tick
     rest = n_sub / 60.0 - h0
@@ -692,37 +696,37 @@ def pack_block64(L: np.ndarray, n_sub: int, micro: int, levels: int = LIN64_LEVE
         out = np.zeros((NB, LIN64_COLS))
         out[:, :NB] = M.T
         return out.reshape(-1)
-    parts = [pad(M) for M in etd3rk_f_matrices(L, h0)]
+    parts = [pad(M) for M in k4_f_matrices(L, h0)]
     for j in range(levels):
-        parts += [pad(M) for M in etd3rk_f_matrices(L, rest / 2 ** (j + 1))]
+        parts += [pad(M) for M in k4_f_matrices(L, rest / 2 ** (j + 1))]
     return np.concatenate(parts)
 
 
 def lin64_reference_step(c, L: np.ndarray, y, inputs, n_sub: int, micro: int, rtol: float, atol: float,
                          levels: int = LIN64_LEVELS, cache: dict = None):
-    """numpy statement of one env step of the etdlin64 kernel (csrc step_etdlin64_kernel): ETD3RK tick + 2^(j+1) equal
-    ETD3RK steps at level j; the result of level j is accepted when it differs from level j-1 by less than the
-    tolerance in the RK45 kernel's norm (Richardson would allow 7 x: the kernel does not take that credit, so that the
-    global error of a rollout stays at the local tolerance's level).  Returns (y+, level) -- level = -1 if even the finest pair disagrees (the kernel then hands the env
-    to the RK45 kernel)."""
+    """numpy statement of one env step of the etdlin64 kernel (csrc step_etdlin64_kernel): a Krogstad ETDRK4 tick + 2^(j+1)
+    equal Krogstad steps at level j; the result of level j is accepted when it differs from level j-1 by less than the
+    tolerance in the RK45 kernel's norm (Richardson would allow more: the kernel does not take that credit, so that the
+    global error of a rollout stays at the local tolerance's level).  Returns (y+, level) -- level = -1 if even the finest
+    pair disagrees (the kernel then hands the env to the RK45 kernel)."""
     cache = {} if cache is None else cache
     tick = 1.0 / (60.0 * micro)
     h0 = tick_length(micro) * tick
     rest = n_sub / 60.0 - h0
 
-    def mats(h):
-        k = round(h * 1e13)
+    def mats(h, kind):
+        k = (kind, round(h * 1e13))
         if k not in cache:
-            cache[k] = etd3rk_f_matrices(L, h)
+            cache[k] = k4_f_matrices(L, h)
         return cache[k]
-    u0, _ = etd3rk_step(c, mats(h0), y, inputs)
+    u0, _ = k4_step(c, mats(h0, 4), y, inputs)
     prev = None
     for j in range(levels):
         K = 2 ** (j + 1)
-        M = mats(rest / K)
+        M = mats(rest / K, 4)
         u = u0
         for _ in range(K):
-            u, _ = etd3rk_step(c, M, u, inputs)
+            u, _ = k4_step(c, M, u, inputs)
         if prev is not None:
             sc = atol + rtol * np.maximum(np.abs(u), np.abs(prev))
             if np.sqrt(np.mean(((u - prev) / sc) ** 2)) <= 1.0:

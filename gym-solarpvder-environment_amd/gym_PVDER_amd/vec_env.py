@@ -847,7 +847,7 @@ class PVDERVec(EnvSpecMixin):
             return
         self._traj_ids = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device)
         m = self.num_envs if env_ids is None else int(self._traj_ids.numel())
-        self._traj = torch.zeros((int(capacity), self.ns + 2 + 13 + 1, m), dtype=self.fdtype, device=self.device)
+        self._traj = torch.zeros((int(capacity), self.ns + 2 + 13, m), dtype=self.fdtype, device=self.device)
         self._traj_n = 0
 
     def _traj_append(self):
@@ -855,15 +855,13 @@ class PVDERVec(EnvSpecMixin):
         slot = self._traj[self._traj_n % self._traj.shape[0]]
         if ids is None:
             if self.out.data_ptr() == self._state_and_out[ns + 2:].data_ptr():
-                slot[: ns + 15].copy_(self._state_and_out)           # (the env's own output block: one copy for both)
+                slot[: ns + 15].copy_(self._state_and_out)           # (the env's own output block: ONE copy for both)
             else:
                 slot[: ns + 2].copy_(self.fstate)
                 slot[ns + 2: ns + 15].copy_(self.out)
-            slot[ns + 15].copy_(self.istate[0])                      # int32 -> float: exact
         else:
             slot[: ns + 2].copy_(self.fstate.index_select(1, ids))
             slot[ns + 2: ns + 15].copy_(self.out.index_select(1, ids))
-            slot[ns + 15].copy_(self.istate[0].index_select(0, ids))
         self._traj_n += 1
 
     def trajectory(self, env: int = 0) -> Dict[str, np.ndarray]:
@@ -884,7 +882,9 @@ class PVDERVec(EnvSpecMixin):
         va = a[ns + 2 + 2] + 1j * a[ns + 2 + 3]
         vgrid = np.real((va - kvi * (a[0] + 1j * a[1])) / kvg)
         d = der_model.physical_outputs(self.par, a[:ns], vgrid, a[ns], a[ns + 1])
-        d["t"] = a[ns + 15] * SIM_TIME_STEP
+        # the clock from the observation's own time entry (row 10 = tStart / max_sim_time, PVDER_env.py:540), snapped to the
+        # sim-time-step grid: no separate copy of the counter row per snapshot
+        d["t"] = np.round(a[ns + 2 + 10] * self._max_sim_time / SIM_TIME_STEP) * SIM_TIME_STEP
         d["vgrid"] = vgrid                          # grid-voltage event magnitude in force [pu]
         d["Ppv"] = a[ns + 2 + 7] * der_model.SBASE
         d["reward"], d["done"] = a[ns + 2 + 11], a[ns + 2 + 12] != 0

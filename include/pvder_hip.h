@@ -215,6 +215,11 @@ int pvder_step_etdrk4_f32(const double *par, const pvder_step_cfg *cfg, const pv
  * to a device buffer and passes that buffer as `coef` to every pvder_step_etdrk4_f32() call with the
  * same par / micro / micro_coarse / graded (kept out of the kernel-argument segment, which every workgroup
  * re-reads at launch). */
+/* One env's output words and counters on the HOST -- what the reference's step() hands back as Python objects (PVDER_env.py:196):
+ * out[r * n_env + env] (r = 0..12, float or double) -> host_out[13], istate[k * n_env + env] (k = 0..3) -> host_ist[4], two
+ * asynchronous copies behind whatever `stream` holds, then ONE wait for the stream.  host_* should be pinned memory. */
+int pvder_fetch_env(const void *out, const int32_t *istate, int n_env, int env, int fp64, void *host_out, int32_t *host_ist,
+                    void *stream);
 int pvder_etdrk4_coef_count(void);
 int pvder_etdrk4_coefficients(const double *par, const pvder_step_cfg *cfg, float *coef_host);
 int pvder_step_rk4_f32(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar,
@@ -305,8 +310,8 @@ int pvder_step_etdlin_f32(const double *par, const pvder_step_cfg *cfg, const pv
 /* PVDER_INT_ETDLIN64 (plans only): the tolerance-match path of BASELINE configs[4] that is not stability-bound -- the
  * etdlin scheme in fp64 on the balanced reduction with step doubling on a dyadic menu as its error control (cfg->rtol /
  * cfg->atol in the RK45 kernel's norm), the adaptive RK45 kernel behind it for the envs the reduction does not cover
- * (fstate / out double, hstep as for RK45).  `lin->sets`: device DOUBLES, (1 + levels) sets of 6 x [11 columns][12] f-form
- * matrices (column by column) -- set 0 for the tick, set 1 + j for (n_sub / 60 - tick) / 2^(j+1) s (gym_PVDER_amd/etd_linear.py::
+ * (fstate / out double, hstep as for RK45).  `lin->sets`: device DOUBLES, (1 + levels) sets of 10 x [11 columns][12] f-form
+ * matrices of a Krogstad ETDRK4 step (KM21 ... KB4, column by column; ABI 15 -- ABI 14: six ETD3RK matrices) -- set 0 for the tick, set 1 + j for (n_sub / 60 - tick) / 2^(j+1) s (gym_PVDER_amd/etd_linear.py::
  * pack_block64); lin->n_sets = 1 + levels (3 .. 10); sched / len_ticks / est_guard unused.  Three-phase model, events on
  * env-step boundaries (PVDER_EINVAL otherwise). */
 enum pvder_integrator { PVDER_INT_ETDLIN = 0, PVDER_INT_ETDRK4 = 1, PVDER_INT_RK4 = 2, PVDER_INT_RK45 = 3, PVDER_INT_ETDLIN64 = 4 };

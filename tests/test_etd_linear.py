@@ -308,12 +308,13 @@ def test_etdlin64_step_doubling_reference_vs_golden(lin50):
         out.append(observe(y, vgt[rowof(ksub)], sit[rowof(ksub)], q, v))
     got, want = np.array(out), g["obs"][:len(out), :10]
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-6
-    assert levels[0] >= 6 and all(1 <= lv <= 4 for lv in levels[1:]), levels
+    # (round 5: Krogstad steps behind the tick -- the step behind the reset at K = 64-128, every other one at K = 4 or 8)
+    assert levels[0] >= 5 and all(1 <= lv <= 2 for lv in levels[1:]), levels
     blk = el.pack_block64(L, n, 32)
     assert blk.shape == ((1 + el.LIN64_LEVELS) * el.LIN64_SET,) and blk.dtype == np.float64
-    M43 = el.etd3rk_f_matrices(L, (n / 60.0 - 2 / 1920.0) / 4)[5]           # level 1, last matrix: stored column by column
-    got43 = blk[2 * el.LIN64_SET + 5 * 132: 2 * el.LIN64_SET + 6 * 132].reshape(11, 12)[:, :11]
-    assert np.array_equal(got43, M43.T)
+    KB4 = el.k4_f_matrices(L, (n / 60.0 - 2 / 1920.0) / 4)[9]              # level 1, last matrix: stored column by column
+    off = 2 * el.LIN64_SET + 9 * 132
+    assert np.array_equal(blk[off: off + 132].reshape(11, 12)[:, :11], KB4.T)
 
 
 def test_symmetrical_components_of_an_off_balance_env_vs_the_oracle_rhs(lin50):
