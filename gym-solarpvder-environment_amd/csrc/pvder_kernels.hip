@@ -2792,9 +2792,16 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
     return leave;
 }
 
-template <int PH, bool T3>
+// CHAIN (A/B experiment of round 5; PVDER_CHAIN=1): launches of consecutive env steps on two alternating streams,
+// ordered per WORKGROUP instead of per launch -- workgroup j of step t+1 reads only what workgroup j of step t wrote, so it may
+// load its kernel arguments and coefficient registers while step t is still running and waits (bounded) for chain[j] >= seq
+// before it touches the state; at its end it publishes chain[j] = seq + 1 (release, agent scope: the two workgroups may sit on
+// different XCDs).  A wait that times out sets chain[gridDim.x] (a flagged wrong answer, never a hung GPU).
+constexpr int kChainSpinLimit = 1 << 22;            // x ~0.1 us of s_sleep: ~0.4 s
+template <int PH, bool T3, bool CHAIN = false>
 __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate, const uint8_t *action, const float *lcoef, int n_env,
-                                                  int ksub_word, const float *k4coef, const LinArgs &G) {
+                                                  int ksub_word, const float *k4coef, const LinArgs &G, int32_t *chain = nullptr,
+                                                  int seq = 0) {
     using namespace pvder;
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
@@ -2816,6 +2823,21 @@ __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate
         lin_load_set(lcoef + kLinMatFloats, lane, R.Ac);
         R.k4_ok = false; R.at_ok = true; R.cur = 1;
         PVDER_TRACE_DEP(19, R.At[0] + R.Ac[5][2]);       // (... the coefficient registers are loaded)
+    }
+    if constexpr (CHAIN) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&chain[blockIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > kChainSpinLimit) { __hip_atomic_store(&chain[gridDim.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        // (the acquire of thread 0 invalidated the caches this workgroup reads through -- its CU's L1, its XCD's L2: one
+        //  invalidation per workgroup, not per wave -- PVDER_CHAIN_FENCE_ALL=1 at build time: every wave, +8 us per step)
+#ifdef PVDER_CHAIN_FENCE_ALL
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     }
 #ifdef PVDER_NO_LEAN
     lin_step_body<PH, kLinHeadBytes, T3>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
@@ -2840,6 +2862,15 @@ __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate
         lin_step_body<PH, kLinHeadBytes, T3>(Gc, lane, Rc, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
     }
 #endif
+    if constexpr (CHAIN) {
+#ifdef PVDER_CHAIN_FENCE_ALL
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // every wave: its rows are out before the workgroup says so
+#else
+        __builtin_amdgcn_s_waitcnt(0);                            // every wave: its stores have left the CU (one write-back per workgroup below)
+#endif
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&chain[blockIdx.x], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Two kernels, one body.  step_etdlin_kernel: two waves per SIMD (256 VGPRs) -- the batches beyond 65 536 envs live on that.
@@ -2856,6 +2887,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                                              const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
     step_etdlin_entry<PH, PH == 3>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G);
 }
+#ifdef PVDER_CHAIN_EXPERIMENT
+// (A/B, -DPVDER_CHAIN_EXPERIMENT builds + PVDER_CHAIN=1: see step_etdlin_entry; NOT in the shipped library -- measured and not kept,
+//  profiles/r05_ab_workgroup_chained_launches.txt) the two-waves-per-SIMD kernel, so that a workgroup of step t+1 finds room beside one of step t
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel_chain(float *fstate, int32_t *istate, const uint8_t *action,
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G,
+                                                             int32_t *chain, int seq) {
+    step_etdlin_entry<3, false, true>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G, chain, seq);
+}
+#endif
 constexpr int kOneWavePerSimdEnvs = 65536;       // 256 CUs x 4 SIMDs x 64 lanes (MI355X)
 
 // =============================================================================================
@@ -3919,6 +3959,16 @@ struct pvder_plan {
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
+    // A/B experiment (PVDER_CHAIN=1, pvder_plan_rollout): per-workgroup chained launches on two streams
+    mutable int32_t *chain = nullptr;          // device: int32[n_wg + 1] (progress per workgroup, [n_wg] = a wait timed out)
+    mutable hipStream_t chain_stream = nullptr;
+    mutable hipEvent_t chain_fork = nullptr, chain_join = nullptr;
+    ~pvder_plan() {
+        if (chain) (void)hipFree(chain);
+        if (chain_fork) (void)hipEventDestroy(chain_fork);
+        if (chain_join) (void)hipEventDestroy(chain_join);
+        if (chain_stream) (void)hipStreamDestroy(chain_stream);
+    }
 };
 
 namespace {
@@ -4303,6 +4353,15 @@ int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded) {
     return 0;
 }
 
+// (A/B experiment) 1 if a chained launch gave up waiting for its predecessor since the last chained rollout began (host sync)
+extern "C" int pvder_debug_chain_timeout(const pvder_plan *plan) {
+    if (!plan || !plan->chain) return 0;
+    int32_t v = 0;
+    const int n_wg = (plan->n_env + kBlock - 1) / kBlock;
+    if (hipMemcpy(&v, plan->chain + n_wg, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
+}
+
 int pvder_plan_hint(pvder_plan *plan, int ksub) {
     if (!plan) return -1;
     if (ksub >= -1) plan->ksub_hint = ksub;
@@ -4320,6 +4379,41 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
                        float *stats, void *stream) {
     if (!plan || n_steps < 0 || !actions || !out) return PVDER_EINVAL;
     const size_t esz = plan->integrator >= PVDER_INT_RK45 ? sizeof(double) : sizeof(float);
+#ifdef PVDER_CHAIN_EXPERIMENT
+    static const bool chained = []() { const char *v = getenv("PVDER_CHAIN"); return v && v[0] == '1'; }();
+    if (chained && plan->integrator == PVDER_INT_ETDLIN && plan->ph == 3 && plan->R.enabled && n_steps > 1) {
+        // ---- A/B experiment: consecutive steps on two alternating streams, ordered per workgroup (step_etdlin_entry)
+        const pvder_plan &p = *plan;
+        const int n_env = p.n_env, n_wg = (n_env + kBlock - 1) / kBlock;
+        hipStream_t sa = (hipStream_t)stream;
+        hipError_t e = hipSuccess;
+        if (!p.chain) {
+            e = hipMalloc((void **)&p.chain, sizeof(int32_t) * (size_t)(n_wg + 1));
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.chain_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p.chain_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p.chain_join, hipEventDisableTiming);
+            if (e != hipSuccess) return hip_rc(e);
+        }
+        e = hipMemsetAsync(p.chain, 0, sizeof(int32_t) * (size_t)(n_wg + 1), sa);
+        if (e == hipSuccess) e = hipEventRecord(p.chain_fork, sa);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p.chain_stream, p.chain_fork, 0);
+        if (e != hipSuccess) return hip_rc(e);
+        const dim3 grid(n_wg), block(kBlock);
+        for (int k = 0; k < n_steps; ++k) {
+            LinArgs G = p.lin;
+            EtdArgs &A = G.A;
+            A.fstate = (float *)fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
+            A.action = actions + (size_t)k * n_env; A.out = (float *)out + (size_t)k * out_step_stride; A.stats = stats; A.stats_fresh = 1;
+            static const bool one_stream = []() { const char *v = getenv("PVDER_CHAIN_ONE_STREAM"); return v && v[0] == '1'; }();
+            hipLaunchKernelGGL(step_etdlin_kernel_chain, grid, block, 0, ((k & 1) && !one_stream) ? p.chain_stream : sa, A.fstate, A.istate, A.action,
+                               G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G, p.chain, k);
+            advance_hint(p, 1);
+        }
+        e = hipEventRecord(p.chain_join, p.chain_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(sa, p.chain_join, 0);
+        return e != hipSuccess ? hip_rc(e) : hip_rc(hipGetLastError());
+    }
+#endif
     for (int k = 0; k < n_steps; ++k) {
         char *blk = (char *)out + (size_t)k * out_step_stride * esz;
         const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env, blk, hstep, stats, 1,
