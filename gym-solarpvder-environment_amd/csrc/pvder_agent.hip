@@ -29,15 +29,21 @@ __global__ __launch_bounds__(kAgentBlock) void qagent_step_kernel(const AgentK K
 extern "C" int pvder_qagent_step_f32(const pvder_qagent_cfg *cfg, float *q_table, const float *out, int64_t *state,
                                      uint8_t *action, uint8_t *alive, double *ep_reward, int n_env, void *stream) {
     if (!cfg || !q_table || !out || !state || !action || !alive || !ep_reward || n_env < 1) return kEinval;
-    if (cfg->bins < 1 || cfg->n_act < 1 || cfg->n_act > 255 || !(cfg->win > 0.0)) return kEinval;
-    double rows = 1.0;
-    for (int k = 0; k < kObs; ++k) rows *= cfg->bins;
-    if (rows * cfg->n_act > 4.0e12) return kEinval;                    // (a table nobody can allocate)
+    if (cfg->policy == PVDER_POLICY_QNET) {
+        if (cfg->n_act < 1 || cfg->n_act > pvder_agent::kQnetMaxAct || cfg->hidden < 1 || cfg->hidden > 1024) return kEinval;
+    } else {
+        if (cfg->policy != PVDER_POLICY_TABLE) return kEinval;
+        if (cfg->bins < 1 || cfg->n_act < 1 || cfg->n_act > 255 || !(cfg->win > 0.0)) return kEinval;
+        double rows = 1.0;
+        for (int k = 0; k < kObs; ++k) rows *= cfg->bins;
+        if (rows * cfg->n_act > 4.0e12) return kEinval;                    // (a table nobody can allocate)
+    }
     AgentK K;
     K.bins = cfg->bins; K.n_act = cfg->n_act; K.first = cfg->first; K.choose = cfg->choose;
     K.one_minus_lr = (float)(1.0 - (double)cfg->lr); K.lr = cfg->lr; K.gamma = cfg->gamma;
     K.epsilon = cfg->epsilon; K.q_done = cfg->q_done; K.low = cfg->low; K.win = cfg->win;
     K.seed = cfg->seed; K.counter = cfg->counter; K.env_id_base = cfg->env_id_base;
+    K.policy = cfg->policy; K.hidden = cfg->hidden;
     const dim3 grid((n_env + kAgentBlock - 1) / kAgentBlock), block(kAgentBlock);
     hipLaunchKernelGGL(qagent_step_kernel, grid, block, 0, (hipStream_t)stream, K, q_table, out, (long long *)state, action,
                        alive, ep_reward, n_env);

@@ -16,7 +16,34 @@ struct AgentK {
     double low, win;
     uint64_t seed, counter;
     long long env_id_base;
+    int policy, hidden;             // pvder_qagent_cfg.policy / .hidden (PVDER_POLICY_QNET: q = the network's weights)
 };
+constexpr int kQnetMaxAct = 8;
+
+// The Q-network of the reference's DQN demo (examples/gym_PVDER_environment_tf_agents_DQN_demo.ipynb cell 17: QNetwork with
+// fc_layer_params = (100,)) as the greedy action of one env: relu(W1 obs + b1) -> W2 h + b2 -> first maximum.  w: W1 [H][11],
+// b1 [H], W2 [A][H], b2 [A] -- the same for every lane (uniform addresses: scalar loads), H (11 + A) fused multiply-adds per env.
+__device__ __forceinline__ int qnet_greedy(const float *__restrict__ w, int H, int A, const float (&obs)[kObs], float (&qout)[kQnetMaxAct]) {
+    const float *__restrict__ W1 = w, *__restrict__ b1 = w + (size_t)H * kObs, *__restrict__ W2 = b1 + H,
+                *__restrict__ b2 = W2 + (size_t)A * H;
+#pragma unroll
+    for (int a = 0; a < kQnetMaxAct; ++a) qout[a] = a < A ? b2[a] : -3.0e38f;
+    for (int j = 0; j < H; ++j) {
+        float h = b1[j];
+#pragma unroll
+        for (int k = 0; k < kObs; ++k) h = __builtin_fmaf(W1[j * kObs + k], obs[k], h);
+        h = fmaxf(h, 0.f);
+#pragma unroll
+        for (int a = 0; a < kQnetMaxAct; ++a)
+            if (a < A) qout[a] = __builtin_fmaf(W2[a * H + j], h, qout[a]);
+    }
+    int best = 0;
+    float bq = qout[0];
+#pragma unroll
+    for (int a = 1; a < kQnetMaxAct; ++a)
+        if (a < A && qout[a] > bq) { bq = qout[a]; best = a; }
+    return best;
+}
 
 // counter-based generator of pvder_kernels.hip / oracle/pvder_model.py::counter_uniform (bit-identical)
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -51,6 +78,28 @@ __device__ __forceinline__ long long discretise(const AgentK &K, const float (&o
 __device__ __forceinline__ void agent_step(const AgentK &K, float *__restrict__ q, const float (&obs)[kObs], float r, bool done,
                                            long long gid, uint64_t counter, long long &state, int &action, bool &alive,
                                            double &ret) {
+    if (K.policy == 1) {
+        // PVDER_POLICY_QNET: the network chooses, nobody learns here (the trainer holds the weights); the episode
+        // bookkeeping of the tabular agent stays (return of the running episode, alive)
+        if (K.first) {
+            alive = true;
+            ret = 0.0;
+        } else if (alive) {
+            ret += (double)r;
+            alive = !done;
+        }
+        if (K.choose) {
+            float qv[kQnetMaxAct];
+            int best = qnet_greedy(q, K.hidden, K.n_act, obs, qv);
+            const float u = counter_uniform(K.seed, (uint64_t)gid, counter, 0, 0);
+            if (u <= K.epsilon) {
+                int a = (int)(counter_uniform(K.seed, (uint64_t)gid, counter, 0, 1) * (float)K.n_act);
+                best = a > K.n_act - 1 ? K.n_act - 1 : a;
+            }
+            action = best;
+        }
+        return;
+    }
     const long long s2 = discretise(K, obs);
     const float *row2 = q + (size_t)s2 * K.n_act;
     if (K.first) {

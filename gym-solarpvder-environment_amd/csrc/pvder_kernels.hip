@@ -4472,7 +4472,12 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
     if (!plan || n_steps < 0 || !out || !progress || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
     if (!cfg || !q_table || !state || !action || !alive || !ep_reward) return PVDER_EINVAL;
     if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->R.enabled) return PVDER_EINVAL;   // (episodes are the caller's)
-    if (cfg->bins < 1 || cfg->n_act < 1 || cfg->n_act > 5 || !(cfg->win > 0.0) || cfg->first || !cfg->choose) return PVDER_EINVAL;
+    if (cfg->n_act < 1 || cfg->n_act > 5 || cfg->first || !cfg->choose) return PVDER_EINVAL;
+    if (cfg->policy == PVDER_POLICY_QNET) {
+        if (cfg->hidden < 1 || cfg->hidden > 1024) return PVDER_EINVAL;
+    } else if (cfg->policy != PVDER_POLICY_TABLE || cfg->bins < 1 || !(cfg->win > 0.0)) {
+        return PVDER_EINVAL;
+    }
     if (n_steps == 0) return 0;
     const int n_env = plan->n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
@@ -4489,6 +4494,7 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
     K.one_minus_lr = (float)(1.0 - (double)cfg->lr); K.lr = cfg->lr; K.gamma = cfg->gamma;
     K.epsilon = cfg->epsilon; K.q_done = cfg->q_done; K.low = cfg->low; K.win = cfg->win;
     K.seed = cfg->seed; K.counter = cfg->counter; K.env_id_base = cfg->env_id_base;
+    K.policy = cfg->policy; K.hidden = cfg->hidden;
     Rk.q = q_table; Rk.ag_state = (long long *)state; Rk.ag_action = action; Rk.ag_alive = alive; Rk.ag_ret = ep_reward;
     const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
     const int pairs = n_steps / ep + 2;

@@ -66,7 +66,7 @@ class QAgentCfg(C.Structure):
     _fields_ = [("bins", C.c_int32), ("n_act", C.c_int32), ("first", C.c_int32), ("choose", C.c_int32),
                 ("lr", C.c_float), ("gamma", C.c_float), ("epsilon", C.c_float), ("q_done", C.c_float),
                 ("low", C.c_double), ("win", C.c_double), ("seed", C.c_uint64), ("counter", C.c_uint64),
-                ("env_id_base", C.c_int64)]
+                ("env_id_base", C.c_int64), ("policy", C.c_int32), ("hidden", C.c_int32)]
 
 
 class LinCoef(C.Structure):

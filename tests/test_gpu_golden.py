@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_discrete_rewards, rel_l2
+from helpers import assert_discrete_rewards, both_events_spec, rel_l2
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -610,3 +610,95 @@ def test_closed_loop_fused_training_statistics_at_many_workgroups(gpu_device):
 def both_events_spec_():
     from helpers import both_events_spec
     return both_events_spec()
+
+
+# ---- the Q-network policy on the device + the batched DQN loop (second half; the reference's
+#      examples/gym_PVDER_environment_tf_agents_DQN_demo.ipynb cells 12-28) ------------------------------------------------
+def test_qnet_policy_on_the_device_matches_a_torch_forward_pass(gpu_device):
+    """PVDER_POLICY_QNET (include/pvder_agent.h): observation(11) -> Dense(100, relu) -> Dense(5) evaluated inside the agent
+    launch for every env -- against the same network in torch fp32: the same greedy action wherever the two best outputs are
+    more than 1e-5 apart; with epsilon = 1 the actions are the exploration stream's (uniform over the five, reproducible)."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    from gym_PVDER_amd.agents import BatchedDQNAgent
+    N = 4096
+    env = PVDERVec(N, device=gpu_device, seed=5, events_spec=both_events_spec(), auto_reset=True)
+    ag = BatchedDQNAgent(env, seed=3)
+    with torch.no_grad():                                   # a network whose outputs differ visibly between envs
+        ag.q_net.flat.copy_(torch.randn(ag.q_net.flat.shape, generator=torch.Generator().manual_seed(1)).to(gpu_device) * 0.5)
+    env.reset()
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(2)
+    seen = set()
+    for t in range(12):
+        env.step(torch.randint(0, 5, (N,), generator=gen, device=gpu_device, dtype=torch.uint8), return_tensors=False)
+        if t >= 4:          # (PVDER-v0 observations of one batch differ in the third digit: spread them over the Box to see every action)
+            env.out[:11].copy_((torch.rand((11, N), generator=gen, device=gpu_device) * 2 - 1) * (0.5 * t))
+        ag.policy_step(first=(t == 0), epsilon=0.0)
+        obs = env.obs.clone()
+        q = ag.q_net(obs).detach()
+        top2 = q.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+        want = q.argmax(dim=1).to(torch.uint8)
+        assert clear.float().mean() > 0.99
+        assert torch.equal(ag.action[clear], want[clear]), t
+        seen |= set(ag.action.unique().tolist())
+    assert len(seen) >= 3                                   # (not a constant policy)
+    ag.policy_step(first=False, epsilon=1.0)
+    counts = torch.bincount(ag.action.long(), minlength=5).float() / N
+    assert counts.min() > 0.15 and counts.max() < 0.25
+    a1 = ag.action.clone()
+    ag._counter -= 1
+    ag.policy_step(first=False, epsilon=1.0)                # the same key: the same draw
+    assert torch.equal(a1, ag.action)
+
+
+def test_qnet_closed_loop_fused_episode_equals_the_two_launch_loop(gpu_device):
+    """A greedy evaluation episode with the Q-network as the action source INSIDE the fused rollout
+    (pvder_plan_rollout_fused_agent, PVDER_POLICY_QNET) against env launch + policy launch per step: returns, final state and
+    counters bit for bit (64 envs: one workgroup; nothing is learned on the device, so larger batches agree too)."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    from gym_PVDER_amd.agents import BatchedDQNAgent
+    for N in (64, 1000):
+        train_env = PVDERVec(N, device=gpu_device, seed=8, events_spec=both_events_spec(), auto_reset=True)
+        ag = BatchedDQNAgent(train_env, seed=4)
+        with torch.no_grad():
+            ag.q_net.flat.copy_(torch.randn(ag.q_net.flat.shape, generator=torch.Generator().manual_seed(7)).to(gpu_device) * 0.3)
+        res = {}
+        for fused in (False, True):
+            ev = PVDERVec(N, device=gpu_device, seed=9, events_spec=both_events_spec(), auto_reset=False, max_sim_time=10.0)
+            res[fused] = (ag.evaluate(ev, fused=fused), ev.fstate.clone(), ev.istate.clone(), ev.out.clone())
+        a, b = res[False], res[True]
+        assert a[0]["steps"] == 40 and torch.equal(a[0]["returns"], b[0]["returns"])
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert float(a[0]["returns"].abs().max()) > 0
+
+
+def test_batched_dqn_loop_trains_on_device_collected_transitions(gpu_device):
+    """The loop of the reference's DQN demo (cells 25-28: collect with the epsilon-greedy network, uniform replay, squared TD loss,
+    Adam 1e-3, batch 64) with collection on the device: the replay buffer holds what the env produced (rows equal the output
+    blocks), the loss is finite and falls on a fixed buffer, the weights the device policy reads are the ones torch trains."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    from gym_PVDER_amd.agents import BatchedDQNAgent
+    N = 512
+    env = PVDERVec(N, device=gpu_device, seed=11, events_spec=both_events_spec(), auto_reset=True, max_sim_time=5.0)
+    ag = BatchedDQNAgent(env, seed=1, replay_buffer_capacity=N * 64)
+    w0 = ag.q_net.flat.detach().clone()
+    losses = ag.train(num_iterations=60, initial_collect_steps=8)
+    assert ag.buf_n == min(ag.capacity, N * 68) and all(np.isfinite(losses))
+    assert not torch.equal(w0, ag.q_net.flat.detach())                      # trained ...
+    ag.policy_step(first=False, epsilon=0.0)
+    assert torch.equal(ag.action, ag.greedy_actions(env.obs)) or \
+        (ag.action != ag.greedy_actions(env.obs)).float().mean() < 0.01      # ... and the device policy follows the new weights
+    # the buffer's rows are real transitions: rewards in the discrete ladder, done flags at the episode ends (20 steps)
+    assert set(ag.buf_rew[:ag.buf_n].unique().tolist()) <= {1.0, -1.0, -5.0, -100.0}
+    assert 0.02 < float(ag.buf_done[:ag.buf_n].mean()) < 0.1
+    # a fixed buffer and a FIXED target network, more gradient steps: the squared TD error against that target falls (with the
+    # demo's target_update_period = 1 the target moves with every step and the loss follows the growing returns instead)
+    ag.spec['target_update_period'] = 10 ** 9
+    first = np.mean([ag.train_step() for _ in range(20)])
+    for _ in range(300):
+        ag.train_step()
+    last = np.mean([ag.train_step() for _ in range(20)])
+    assert last < first, (first, last)
+    ev = PVDERVec(256, device=gpu_device, seed=12, events_spec=both_events_spec(), auto_reset=False, max_sim_time=5.0)
+    r = ag.evaluate(ev)
+    assert np.isfinite(r["average_return"]) and r["steps"] == 20

@@ -71,8 +71,9 @@ def test_ctypes_structs_match_header_layout(tmp_path):
                    'printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(pvder_step_cfg, micro_coarse), offsetof(pvder_step_cfg, graded),'
                    'offsetof(pvder_step_cfg, extra_rewards), sizeof(pvder_lin_coef), offsetof(pvder_lin_coef, sched),'
                    'offsetof(pvder_lin_coef, est_guard));'
-                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(pvder_qagent_cfg), offsetof(pvder_qagent_cfg, lr), offsetof(pvder_qagent_cfg, low),'
-                   'offsetof(pvder_qagent_cfg, seed), offsetof(pvder_qagent_cfg, env_id_base));return 0;}')
+                   'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pvder_qagent_cfg), offsetof(pvder_qagent_cfg, lr), offsetof(pvder_qagent_cfg, low),'
+                   'offsetof(pvder_qagent_cfg, seed), offsetof(pvder_qagent_cfg, env_id_base), offsetof(pvder_qagent_cfg, policy),'
+                   'offsetof(pvder_qagent_cfg, hidden));return 0;}')
     exe = tmp_path / "lay"
     subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
@@ -83,7 +84,8 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     Lc = _native.LinCoef
     assert vals[13:17] == [S.extra_rewards.offset, ctypes.sizeof(Lc), Lc.sched.offset, Lc.est_guard.offset]
     Qc = _native.QAgentCfg
-    assert vals[17:22] == [ctypes.sizeof(Qc), Qc.lr.offset, Qc.low.offset, Qc.seed.offset, Qc.env_id_base.offset]
+    assert vals[17:24] == [ctypes.sizeof(Qc), Qc.lr.offset, Qc.low.offset, Qc.seed.offset, Qc.env_id_base.offset, Qc.policy.offset,
+                           Qc.hidden.offset]
     from gym_PVDER_amd import der_model
     assert vals[6] == len(der_model.PAR)
 
