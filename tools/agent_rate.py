@@ -30,3 +30,29 @@ for name, kw in (("train", {}), ("train_fused", {}), ("closed_loop", dict(closed
           % (name, N, bins, agent.q_table.numel() * 4 / 1e9, dt / steps * 1e6, N * steps / dt), flush=True)
     del agent, env
     torch.cuda.empty_cache()
+
+# ---- the Q-network policy (PVDER_POLICY_QNET: the QNetwork of the reference's DQN demo) as the action source: a greedy evaluation
+#      episode with env launch + policy launch per step, and inside the fused closed-loop rollout; one DQN iteration (collect 1 + train 1)
+from gym_PVDER_amd.agents import BatchedDQNAgent
+tenv = PVDERVec(N, device=dev, auto_reset=True, seed=3)
+ag = BatchedDQNAgent(tenv, seed=1, replay_buffer_capacity=N * 8)
+for fused in (False, True):
+    ev = PVDERVec(N, device=dev, auto_reset=False, seed=4)
+    ag.evaluate(ev, fused=fused)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r = ag.evaluate(ev, fused=fused)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-12s %d envs, Q-network 11 -> 100 -> 5 as the policy (%s): %.1f us per env step, %.3e env-steps/s"
+          % ("qnet_eval", N, "inside the fused rollout" if fused else "env launch + policy launch per step", dt / (3 * r["steps"]) * 1e6,
+             N * 3 * r["steps"] / dt), flush=True)
+ag.train(num_iterations=20, initial_collect_steps=4)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ag.train(num_iterations=200, initial_collect_steps=0)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("%-12s %d envs: one DQN iteration (collect one batched step under the device policy + one Adam step on 64 replayed rows): %.1f us"
+      % ("dqn_iter", N, dt / 200 * 1e6), flush=True)
