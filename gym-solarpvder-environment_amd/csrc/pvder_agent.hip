@@ -19,9 +19,14 @@ __global__ __launch_bounds__(kAgentBlock) void qagent_step_kernel(const AgentK K
                                                                    const float *__restrict__ out, long long *__restrict__ state,
                                                                    uint8_t *__restrict__ action, uint8_t *__restrict__ alive,
                                                                    double *__restrict__ ep_reward, int n_env) {
+    __shared__ __attribute__((aligned(16))) float qnet[pvder_agent::kQnetLdsFloats];
+    if (K.policy == 1) {             // (wave-uniform) the Q-network's weights: once per workgroup into LDS
+        pvder_agent::qnet_stage(q, K.hidden, K.n_act, qnet, (int)threadIdx.x, kAgentBlock);
+        __syncthreads();
+    }
     const int e = blockIdx.x * kAgentBlock + threadIdx.x;
     if (e >= n_env) return;
-    pvder_agent::agent_step_block(K, q, out, (size_t)n_env, e, K.counter, state, action, alive, ep_reward);
+    pvder_agent::agent_step_block(K, q, out, (size_t)n_env, e, K.counter, state, action, alive, ep_reward, qnet);
 }
 
 }  // namespace
@@ -30,7 +35,7 @@ extern "C" int pvder_qagent_step_f32(const pvder_qagent_cfg *cfg, float *q_table
                                      uint8_t *action, uint8_t *alive, double *ep_reward, int n_env, void *stream) {
     if (!cfg || !q_table || !out || !state || !action || !alive || !ep_reward || n_env < 1) return kEinval;
     if (cfg->policy == PVDER_POLICY_QNET) {
-        if (cfg->n_act < 1 || cfg->n_act > pvder_agent::kQnetMaxAct || cfg->hidden < 1 || cfg->hidden > 1024) return kEinval;
+        if (cfg->n_act < 1 || cfg->n_act > pvder_agent::kQnetMaxAct || cfg->hidden < 1 || cfg->hidden > pvder_agent::kQnetMaxHidden) return kEinval;
     } else {
         if (cfg->policy != PVDER_POLICY_TABLE) return kEinval;
         if (cfg->bins < 1 || cfg->n_act < 1 || cfg->n_act > 255 || !(cfg->win > 0.0)) return kEinval;

@@ -19,23 +19,44 @@ struct AgentK {
     int policy, hidden;             // pvder_qagent_cfg.policy / .hidden (PVDER_POLICY_QNET: q = the network's weights)
 };
 constexpr int kQnetMaxAct = 8;
+constexpr int kQnetMaxHidden = 128;
+// LDS image of the network (staged once per launch by qnet_stage): W1 rows padded to 12 floats, W2 TRANSPOSED with rows of 8
+// (three + two 16-byte broadcast reads per hidden unit), b1, b2 -- at fixed offsets
+constexpr int kQnetW1 = 0, kQnetW2 = kQnetMaxHidden * 12, kQnetB1 = kQnetW2 + kQnetMaxHidden * 8, kQnetB2 = kQnetB1 + kQnetMaxHidden,
+              kQnetLdsFloats = kQnetB2 + 8;
+
+// w (global, include/pvder_agent.h PVDER_POLICY_QNET): W1 [H][11], b1 [H], W2 [A][H], b2 [A]  ->  the LDS image; all threads of the
+// workgroup call it, the caller synchronises
+__device__ __forceinline__ void qnet_stage(const float *__restrict__ w, int H, int A, float *__restrict__ lds, int tid, int nthreads) {
+    const float *__restrict__ b1 = w + (size_t)H * kObs, *__restrict__ W2 = b1 + H, *__restrict__ b2 = W2 + (size_t)A * H;
+    for (int i = tid; i < H * 12; i += nthreads) { const int j = i / 12, k = i - 12 * j; lds[kQnetW1 + i] = k < kObs ? w[j * kObs + k] : 0.f; }
+    for (int i = tid; i < H * 8; i += nthreads) { const int j = i >> 3, a = i & 7; lds[kQnetW2 + i] = a < A ? W2[a * H + j] : 0.f; }
+    for (int i = tid; i < H; i += nthreads) lds[kQnetB1 + i] = b1[i];
+    if (tid < 8) lds[kQnetB2 + tid] = tid < A ? b2[tid] : -3.0e38f;
+}
 
 // The Q-network of the reference's DQN demo (examples/gym_PVDER_environment_tf_agents_DQN_demo.ipynb cell 17: QNetwork with
-// fc_layer_params = (100,)) as the greedy action of one env: relu(W1 obs + b1) -> W2 h + b2 -> first maximum.  w: W1 [H][11],
-// b1 [H], W2 [A][H], b2 [A] -- the same for every lane (uniform addresses: scalar loads), H (11 + A) fused multiply-adds per env.
-__device__ __forceinline__ int qnet_greedy(const float *__restrict__ w, int H, int A, const float (&obs)[kObs], float (&qout)[kQnetMaxAct]) {
-    const float *__restrict__ W1 = w, *__restrict__ b1 = w + (size_t)H * kObs, *__restrict__ W2 = b1 + H,
-                *__restrict__ b2 = W2 + (size_t)A * H;
+// fc_layer_params = (100,)) as the greedy action of one env: relu(W1 obs + b1) -> W2 h + b2 -> first maximum.  Every lane reads
+// the same LDS words (broadcast reads, no bank conflicts); H (11 + A) fused multiply-adds per env in the order k = 0..10, j = 0..H-1.
+// (Round 5, first version: the weights through the table pointer -- a non-const global pointer the tabular agent writes
+//  through, so hipcc issued 1600 per-lane vector loads per env step: 45 us; from LDS: see profiles/r05_agent_rate.txt)
+typedef float v4q __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int qnet_greedy(const float *__restrict__ lds, int H, int A, const float (&obs)[kObs], float (&qout)[kQnetMaxAct]) {
 #pragma unroll
-    for (int a = 0; a < kQnetMaxAct; ++a) qout[a] = a < A ? b2[a] : -3.0e38f;
+    for (int a = 0; a < kQnetMaxAct; ++a) qout[a] = lds[kQnetB2 + a];
     for (int j = 0; j < H; ++j) {
-        float h = b1[j];
-#pragma unroll
-        for (int k = 0; k < kObs; ++k) h = __builtin_fmaf(W1[j * kObs + k], obs[k], h);
+        const v4q *r1 = (const v4q *)(lds + kQnetW1 + 12 * j);
+        const v4q w0 = r1[0], w1 = r1[1], w2 = r1[2];
+        float h = lds[kQnetB1 + j];
+        h = __builtin_fmaf(w0.x, obs[0], h); h = __builtin_fmaf(w0.y, obs[1], h); h = __builtin_fmaf(w0.z, obs[2], h); h = __builtin_fmaf(w0.w, obs[3], h);
+        h = __builtin_fmaf(w1.x, obs[4], h); h = __builtin_fmaf(w1.y, obs[5], h); h = __builtin_fmaf(w1.z, obs[6], h); h = __builtin_fmaf(w1.w, obs[7], h);
+        h = __builtin_fmaf(w2.x, obs[8], h); h = __builtin_fmaf(w2.y, obs[9], h); h = __builtin_fmaf(w2.z, obs[10], h);
         h = fmaxf(h, 0.f);
-#pragma unroll
-        for (int a = 0; a < kQnetMaxAct; ++a)
-            if (a < A) qout[a] = __builtin_fmaf(W2[a * H + j], h, qout[a]);
+        const v4q *r2 = (const v4q *)(lds + kQnetW2 + 8 * j);
+        const v4q u0 = r2[0], u1 = r2[1];
+        qout[0] = __builtin_fmaf(u0.x, h, qout[0]); qout[1] = __builtin_fmaf(u0.y, h, qout[1]); qout[2] = __builtin_fmaf(u0.z, h, qout[2]);
+        qout[3] = __builtin_fmaf(u0.w, h, qout[3]); qout[4] = __builtin_fmaf(u1.x, h, qout[4]); qout[5] = __builtin_fmaf(u1.y, h, qout[5]);
+        qout[6] = __builtin_fmaf(u1.z, h, qout[6]); qout[7] = __builtin_fmaf(u1.w, h, qout[7]);
     }
     int best = 0;
     float bq = qout[0];
@@ -77,7 +98,7 @@ __device__ __forceinline__ long long discretise(const AgentK &K, const float (&o
 // state / action / alive / ret are the env's agent-side registers (or its array slots).
 __device__ __forceinline__ void agent_step(const AgentK &K, float *__restrict__ q, const float (&obs)[kObs], float r, bool done,
                                            long long gid, uint64_t counter, long long &state, int &action, bool &alive,
-                                           double &ret) {
+                                           double &ret, const float *__restrict__ qnet_lds = nullptr) {
     if (K.policy == 1) {
         // PVDER_POLICY_QNET: the network chooses, nobody learns here (the trainer holds the weights); the episode
         // bookkeeping of the tabular agent stays (return of the running episode, alive)
@@ -90,7 +111,7 @@ __device__ __forceinline__ void agent_step(const AgentK &K, float *__restrict__ 
         }
         if (K.choose) {
             float qv[kQnetMaxAct];
-            int best = qnet_greedy(q, K.hidden, K.n_act, obs, qv);
+            int best = qnet_greedy(qnet_lds, K.hidden, K.n_act, obs, qv);
             const float u = counter_uniform(K.seed, (uint64_t)gid, counter, 0, 0);
             if (u <= K.epsilon) {
                 int a = (int)(counter_uniform(K.seed, (uint64_t)gid, counter, 0, 1) * (float)K.n_act);
@@ -138,7 +159,7 @@ __device__ __forceinline__ void agent_step(const AgentK &K, float *__restrict__ 
 __device__ __forceinline__ void agent_step_block(const AgentK &K, float *__restrict__ q, const float *__restrict__ out, size_t N,
                                                  int e, uint64_t counter, long long *__restrict__ state,
                                                  uint8_t *__restrict__ action, uint8_t *__restrict__ alive,
-                                                 double *__restrict__ ep_reward) {
+                                                 double *__restrict__ ep_reward, const float *__restrict__ qnet_lds = nullptr) {
     float obs[kObs];
 #pragma unroll
     for (int k = 0; k < kObs; ++k) obs[k] = out[(size_t)k * N + e];
@@ -148,7 +169,7 @@ __device__ __forceinline__ void agent_step_block(const AgentK &K, float *__restr
     double ret = ep_reward[e];
     const float r = out[(size_t)11 * N + e];
     const bool done = out[(size_t)12 * N + e] != 0.f;
-    agent_step(K, q, obs, r, done, K.env_id_base + e, counter, s, a, al, ret);
+    agent_step(K, q, obs, r, done, K.env_id_base + e, counter, s, a, al, ret, qnet_lds);
     state[e] = s;
     if (K.choose) action[e] = (uint8_t)a;
     alive[e] = al ? 1 : 0;

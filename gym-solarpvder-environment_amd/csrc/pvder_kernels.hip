@@ -2973,9 +2973,14 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
     int ag_a = 0;
     bool ag_alive = false;
     double ag_ret = 0.0;
+    __shared__ __attribute__((aligned(16))) float qnet[AG ? pvder_agent::kQnetLdsFloats : 4];       // (PVDER_POLICY_QNET: the network's weights)
     if constexpr (AG) {
         const int ec = e < Q.G.A.n_env ? e : Q.G.A.n_env - 1;
         ag_s = Q.Rk.ag_state[ec]; ag_a = Q.Rk.ag_action[ec]; ag_alive = Q.Rk.ag_alive[ec] != 0; ag_ret = Q.Rk.ag_ret[ec];
+        if (Q.Rk.ag.policy == 1) {
+            pvder_agent::qnet_stage(Q.Rk.q, Q.Rk.ag.hidden, Q.Rk.ag.n_act, qnet, (int)threadIdx.x, kBlock);
+            __syncthreads();
+        }
     }
     if (!__syncthreads_or((int)bail) && k < Q.Rk.n_steps) {
         // what a step reads from memory -- its action, the event inputs and the schedule row of its first
@@ -3062,7 +3067,7 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
                                                       (float)ksub * (float)(1.0 / 60.0) * B.C.inv_tmax};
                 if (e < B.n_env)
                     pvder_agent::agent_step(Q2.Rk.ag, Q2.Rk.q, obs, last_reward, false, Q2.Rk.ag.env_id_base + e,
-                                            Q2.Rk.ag.counter + (uint64_t)k, ag_s, ag_a, ag_alive, ag_ret);
+                                            Q2.Rk.ag.counter + (uint64_t)k, ag_s, ag_a, ag_alive, ag_ret, qnet);
                 a_next = ag_a;
             }
             a_now = a_next;
@@ -3121,6 +3126,13 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
     if (k0 >= Rk.n_steps) return;
     const int k1 = Rk.n_steps - k0 > Rk.max_finish ? k0 + Rk.max_finish : Rk.n_steps;
     const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float qnet[AG ? pvder_agent::kQnetLdsFloats : 4];       // (PVDER_POLICY_QNET: the network's weights)
+    if constexpr (AG) {
+        if (Rk.ag.policy == 1) {
+            pvder_agent::qnet_stage(Rk.q, Rk.ag.hidden, Rk.ag.n_act, qnet, (int)threadIdx.x, kBlock);
+            __syncthreads();
+        }
+    }
     for (int k = k0; k < k1; ++k) {
         if (k > 0 && Rk.out_stride != 0 && !G.A.R.enabled) {      // stale tuples follow the output block (carry_stale_kernel)
             const int e = blockIdx.x * kBlock + threadIdx.x;
@@ -3143,7 +3155,7 @@ __global__ __launch_bounds__(kBlock) void step_etdlin_finish_kernel(const RollAr
             if (e < Qa.G.A.n_env)
                 pvder_agent::agent_step_block(Qa.Rk.ag, Qa.Rk.q, Qa.G.A.out + k * Qa.Rk.out_stride, (size_t)Qa.G.A.n_env, e,
                                               Qa.Rk.ag.counter + (uint64_t)k, Qa.Rk.ag_state, Qa.Rk.ag_action, Qa.Rk.ag_alive,
-                                              Qa.Rk.ag_ret);
+                                              Qa.Rk.ag_ret, qnet);
         }
         __threadfence();                 // the next step of this workgroup reads what this one wrote
         __syncthreads();
@@ -4474,7 +4486,7 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
     if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->R.enabled) return PVDER_EINVAL;   // (episodes are the caller's)
     if (cfg->n_act < 1 || cfg->n_act > 5 || cfg->first || !cfg->choose) return PVDER_EINVAL;
     if (cfg->policy == PVDER_POLICY_QNET) {
-        if (cfg->hidden < 1 || cfg->hidden > 1024) return PVDER_EINVAL;
+        if (cfg->hidden < 1 || cfg->hidden > pvder_agent::kQnetMaxHidden) return PVDER_EINVAL;
     } else if (cfg->policy != PVDER_POLICY_TABLE || cfg->bins < 1 || !(cfg->win > 0.0)) {
         return PVDER_EINVAL;
     }

@@ -39,8 +39,8 @@ class QNetwork(torch.nn.Module):
 
     def __init__(self, hidden: int = 100, device="cuda", seed: int = 0):
         super().__init__()
-        if not 1 <= hidden <= 1024:
-            raise ValueError("hidden must be in 1..1024")
+        if not 1 <= hidden <= 128:
+            raise ValueError("hidden must be in 1..128 (the device policy keeps the network in LDS)")
         self.hidden = int(hidden)
         H = self.hidden
         self.flat = torch.nn.Parameter(torch.zeros(H * N_OBS + H + N_ACT * H + N_ACT, dtype=torch.float32, device=device))

@@ -35,13 +35,14 @@ typedef struct pvder_qagent_cfg {
                            cell 17: observation(11) -> Dense(hidden, relu) -> Dense(n_act)), INFERENCE only: epsilon-greedy on its
                            outputs, no update on the device (the trainer owns the weights: gym_PVDER_amd/agents/dqn.py); bins / lr /
                            gamma / q_done / low / win unused, `state` left alone, `alive` / `ep_reward` kept as above */
-    int32_t hidden;     /* PVDER_POLICY_QNET: width of the hidden layer (100: fc_layer_params = (100,), cell 12); 1 .. 1024 */
+    int32_t hidden;     /* PVDER_POLICY_QNET: width of the hidden layer (100: fc_layer_params = (100,), cell 12); 1 .. 128 */
 } pvder_qagent_cfg;
 enum { PVDER_POLICY_TABLE = 0, PVDER_POLICY_QNET = 1 };
 /* PVDER_POLICY_QNET: `q_table` = device float[hidden * 11 + hidden + n_act * hidden + n_act]: W1 [hidden][11] row-major, b1 [hidden],
  * W2 [n_act][hidden] row-major, b2 [n_act] (torch.nn.Linear layouts); n_act <= 8.  Every lane evaluates the SAME network on its
- * own observation: the weights are wave-uniform operands (scalar loads), the products run on the vector ALUs in the order
- * k = 0..10 / j = 0..hidden-1 (fused multiply-adds): within fp32 rounding of a torch forward pass, the same argmax except on ties. */
+ * own observation: a launch stages the weights in LDS once per workgroup (broadcast reads), the products run on the vector ALUs
+ * in the order k = 0..10 / j = 0..hidden-1 (fused multiply-adds): within fp32 rounding of a torch forward pass, the same argmax
+ * except on ties. */
 
 /* One agent step for n_env envs.
  *   q_table : device float[bins^11 * n_act], row-major (row = flat index of the 11 bin numbers, first
