@@ -751,10 +751,14 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
     action 4 ends at the duty-cycle limit (23-state path on the switched operator sets).  Four envs on their own
     voltage + insolation events against the committed converged-bridge goldens (tests/golden/bridge_ramp_a*.npz,
     tests/bridge_cases.py): whole trajectory and worst single env step.  Action 4 is compared over ALL 160 steps
-    (VERDICT r3 #3): up to the first saturated step at the parity bar; beyond it against the golden at rtol 1e-12 with the
-    bound that regime supports -- the golden's OWN spread there is 3e-3 per env step (its 1e-10 run, stored beside it:
-    profiles/r04_saturation_convergence.txt, error ~ tol^0.17: a chattering approximation of the sliding solution), the
-    device's switched steps hold an anti-windup mode over a whole integrator step and are 1e-2 ... 1e-1 off."""
+    (VERDICT r3 #3): up to the first saturated step at the parity bar; beyond it against the round-5 golden -- the
+    EVENT-LOCATING integrator's run (oracle/pvder_bridge_filippov.h: the sliding solution itself; its OWN spread over all 160
+    steps is 5.1e-6, rtol 1e-9 against 1e-12: profiles/r05_filippov_convergence.txt).  The golden is converged now; the
+    DEVICE is not there: its switched steps hold an anti-windup mode over a whole integrator step and are 1e-2 ... 1e-1 off
+    in the env steps in which a phase enters, leaves or re-locks at the limit (median 8e-4) -- and a scheme of that kind does
+    not converge under step refinement (fp64 prototype at 480 steps per env step: still 7e-2): a clamped
+    duty cycle leaves the current loop OPEN, and the open loop integrates a duty-cycle error dm into a current error 276 dm t.
+    The bounds below are the measured ones (profiles/r05_a4_saturated_numbers.txt), a waiver that says what it waives."""
     import bridge_cases
     name = "ramp_a%d" % action
     g = bridge_cases.load(name)
@@ -800,8 +804,8 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
         # (the waiver "finite, |m| < 1.03" said nothing about accuracy), next to the golden's own spread
         e_sat = rel_l2(got[last:], want[last:], axis=2)
         spread = rel_l2(g["obs_coarser"][last:], want[last:], axis=2)
-        assert float(g["rtol"]) <= 1e-12 and spread.max() < 5e-3, spread.max()
-        # measured (tools/a4_saturated_numbers.py, profiles/r04_a4_saturated_numbers.txt): worst env step 9.0e-2 (where a phase
+        assert float(g["rtol"]) <= 1e-12 and str(g["method"]) == "filippov" and spread.max() < 1e-5, spread.max()
+        # measured (tools/a4_saturated_numbers.py, profiles/r05_a4_saturated_numbers.txt): worst env step 9.1e-2 (where a phase
         # enters or leaves the limit), MEDIAN 8.0e-4
         assert e_sat.max() < 1.5e-1, (last + int(e_sat.max(axis=1).argmax()), e_sat.max())
         assert np.median(e_sat) < 5e-3, np.median(e_sat)
