@@ -4386,6 +4386,20 @@ int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float
     return launch_plan(*plan, fstate, istate, ev_vg, ev_si, action, out, hstep, stats, 1, stream);
 }
 
+int pvder_plan_step_fetch(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                          const uint8_t *action, void *out, double *hstep, float *stats, void *snapshot, const void *snapshot_src,
+                          size_t snapshot_bytes, void *host_out, int32_t *host_ist, void *stream) {
+    if (!plan || plan->n_env != 1) return PVDER_EINVAL;
+    int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, action, out, hstep, stats, 1, stream);
+    if (rc) return rc;
+    if (snapshot) {
+        if (!snapshot_src) return PVDER_EINVAL;
+        const hipError_t e = hipMemcpyAsync(snapshot, snapshot_src, snapshot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_rc(e);
+    }
+    return pvder_fetch_env(out, istate, 1, 0, plan->integrator >= PVDER_INT_RK45 ? 1 : 0, host_out, host_ist, stream);
+}
+
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                        const uint8_t *actions, int n_steps, void *out, size_t out_step_stride, double *hstep,
                        float *stats, void *stream) {

@@ -29,7 +29,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
-           "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env"]
+           "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch"]
 LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
 
@@ -142,6 +142,8 @@ def lib() -> C.CDLL:
         f.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.pvder_reset_masked_lanes_f32.restype = i32
     L.pvder_reset_masked_lanes_f32.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.pvder_plan_step_fetch.restype = i32
+    L.pvder_plan_step_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.pvder_fetch_env.restype = i32
     L.pvder_fetch_env.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     L.pvder_step_rk4_f32.restype = i32

@@ -158,6 +158,30 @@ class PVDER(EnvSpecMixin):
                                              self._pin_out.data_ptr(), self._pin_ist.data_ptr(), v._stream()), "pvder_fetch_env")
         self._host_out, self._host_ist = self._pin_out.tolist(), self._pin_ist.tolist()
 
+    def _step_and_fetch(self, action: int):
+        """``PVDERVec.step`` + the trajectory snapshot + ``_read_back`` from ONE native call (pvder_plan_step_fetch): what were
+        three Python-level calls of ~10 us each.  Falls back to those when the vec env is in a state the fused call does not
+        cover (per-launch timing, an output block that is not the env's own)."""
+        v = self._vec
+        own_out = v.out.data_ptr() == v._state_and_out[v.ns + 2:].data_ptr()
+        if v._timing or not own_out or v._needs_reset:
+            v.step(self._actions[action], return_tensors=False)
+            self._read_back()
+            return
+        plan = v._plan or v._make_plan()
+        snap, nbytes = None, 0
+        if v._traj is not None:
+            slot = v._traj[v._traj_n % v._traj.shape[0]]
+            snap, nbytes = slot.data_ptr(), slot.numel() * slot.element_size()
+            v._traj_n += 1
+        rc = v._lib.pvder_plan_step_fetch(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v.ev_vg.data_ptr(), v.ev_si.data_ptr(),
+                                          self._actions[action].data_ptr(), v.out.data_ptr(),
+                                          v.hstep.data_ptr() if v.hstep is not None else None, v.stats.data_ptr(), snap,
+                                          v._state_and_out.data_ptr(), nbytes, self._pin_out.data_ptr(), self._pin_ist.data_ptr(),
+                                          v._stream())
+        _native.check(rc, "pvder_plan_step_fetch")
+        self._host_out, self._host_ist = self._pin_out.tolist(), self._pin_ist.tolist()
+
     @property
     def steps(self):                                                 # env_utilities.py:48-52
         return self._host_ist[1] if hasattr(self, 'sim') else 0
@@ -187,8 +211,7 @@ class PVDER(EnvSpecMixin):
             logger.warning('%s:Simulation completed - Reset environment to start new simulation!', self.name)
             return np.array(self.state), self._reward, self.done, {}
         self._action_stats[int(action)] += 1                         # :209
-        self._vec.step(self._actions[int(action)], return_tensors=False)   # device-resident action constants
-        self._read_back()                                            # the only host sync of the step
+        self._step_and_fetch(int(action))                            # launch + trajectory snapshot + read-back: ONE native call
         o, ist = self._host_out, self._host_ist
         r, status = o[11], ist[3]
         self.done = o[12] != 0.0

@@ -362,6 +362,12 @@ int pvder_fold_lane_params(const double *par, const double *lane, int n_env, flo
 int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded);
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream);
+/* The single env's whole step from ONE host call (the drop-in's `PVDER.step`, PVDER_env.py:138-196): pvder_plan_step, then --
+ * snapshot != NULL -- one device-to-device copy of snapshot_bytes from snapshot_src (the trajectory record the reference keeps
+ * of every solution row, :389), then pvder_fetch_env of env 0 (n_env = 1).  Three Python-level calls of ~10 us each become one. */
+int pvder_plan_step_fetch(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                          const uint8_t *action, void *out, double *hstep, float *stats, void *snapshot, const void *snapshot_src,
+                          size_t snapshot_bytes, void *host_out, int32_t *host_ist, void *stream);
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                        const uint8_t *actions, int n_steps, void *out, size_t out_step_stride, double *hstep,
                        float *stats, void *stream);
