@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -29,7 +29,9 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_step_etdlin_f32", "pvder_plan_create", "pvder_plan_destroy", "pvder_plan_step",
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
-           "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch"]
+           "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch",
+           "pvder_plan_step_mirror"]
+MIRROR_WORDS = 18       # PVDER_MIRROR_WORDS (pvder_plan_step_mirror): 13 output rows + 4 counters + the sequence word, doubles
 LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
 
@@ -80,7 +82,7 @@ class LinCoef(C.Structure):
 # v_accvgpr_read copies); -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (pointers and
 # sizes a launch needs for its first loads) arrive in SGPRs with the wave instead of through an s_load
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-               "-mllvm", "-amdgpu-kernarg-preload-count=12"]
+               "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 
 def hipcc_path() -> str:
@@ -144,6 +146,8 @@ def lib() -> C.CDLL:
     L.pvder_reset_masked_lanes_f32.argtypes = [dp, cfgp, arp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.pvder_plan_step_fetch.restype = i32
     L.pvder_plan_step_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.pvder_plan_step_mirror.restype = i32
+    L.pvder_plan_step_mirror.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_uint64, vp]
     L.pvder_fetch_env.restype = i32
     L.pvder_fetch_env.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     L.pvder_step_rk4_f32.restype = i32

@@ -13,6 +13,7 @@ fused launch, no separate code path.
 from __future__ import annotations
 
 import logging
+import os
 import pprint
 import time
 from types import SimpleNamespace
@@ -124,6 +125,10 @@ class PVDER(EnvSpecMixin):
         # host mirrors of the output block and the counters: pinned, filled by two asynchronous copies behind the launch
         self._pin_out = torch.zeros(13, dtype=self._vec.fdtype).pin_memory()
         self._pin_ist = torch.zeros(4, dtype=torch.int32).pin_memory()
+        # ... and of a step: 13 output rows + 4 counters + a sequence word the device writes itself (pvder_plan_step_mirror)
+        self._pin_mirror = torch.zeros(_native.MIRROR_WORDS, dtype=torch.float64).pin_memory()
+        self._mirror_seq = 0
+        self._use_mirror = os.environ.get("PVDER_SINGLE_ENV_COPIES", "0") != "1"            # (A/B: the copy-packet read-back of ABI 15)
         self._host_out, self._host_ist = [0.0] * 13, [0] * 4
         if record_trajectory:      # the reference always keeps the solution rows (self.results, :389)
             self._vec.record_trajectory(self._vec.max_episode_steps + 1)
@@ -174,6 +179,19 @@ class PVDER(EnvSpecMixin):
             slot = v._traj[v._traj_n % v._traj.shape[0]]
             snap, nbytes = slot.data_ptr(), slot.numel() * slot.element_size()
             v._traj_n += 1
+        if self._use_mirror:
+            # no copy packet, no stream wait: one small kernel behind the step writes rows, counters, the trajectory record and a
+            # sequence word into pinned host memory; the call returns when the word is there
+            self._mirror_seq += 1
+            rc = v._lib.pvder_plan_step_mirror(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v.ev_vg.data_ptr(), v.ev_si.data_ptr(),
+                                               self._actions[action].data_ptr(), v.out.data_ptr(),
+                                               v.hstep.data_ptr() if v.hstep is not None else None, v.stats.data_ptr(), snap,
+                                               v._state_and_out.data_ptr(), nbytes, self._pin_mirror.data_ptr(), self._mirror_seq,
+                                               v._stream())
+            _native.check(rc, "pvder_plan_step_mirror")
+            m = self._pin_mirror.tolist()
+            self._host_out, self._host_ist = m[:13], [int(x) for x in m[13:17]]
+            return
         rc = v._lib.pvder_plan_step_fetch(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v.ev_vg.data_ptr(), v.ev_si.data_ptr(),
                                           self._actions[action].data_ptr(), v.out.data_ptr(),
                                           v.hstep.data_ptr() if v.hstep is not None else None, v.stats.data_ptr(), snap,

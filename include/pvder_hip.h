@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 15
+#define PVDER_ABI_VERSION 16
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -368,6 +368,19 @@ int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float
 int pvder_plan_step_fetch(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                           const uint8_t *action, void *out, double *hstep, float *stats, void *snapshot, const void *snapshot_src,
                           size_t snapshot_bytes, void *host_out, int32_t *host_ist, void *stream);
+/* ... and without a copy packet or a stream wait (ABI 16): behind the step launch ONE small kernel writes the env's output block
+ * and counters -- and, snapshot != NULL, the trajectory record -- and then a sequence number into `host_block`, PVDER_MIRROR_WORDS
+ * doubles of PINNED host memory the device can address (hipHostMalloc / torch pin_memory: fine-grained, written over the bus as the
+ * kernel stores); the host spins on the sequence word.  host_block[0..12] = the 13 output rows (fp32 rows widened: exact),
+ * [13..16] = istate rows ksub / steps / done / status, [17] = seq as written LAST (system-scope release).  seq must differ from the
+ * block's current [17] (callers count up).  The wait is bounded (PVDER_MIRROR_TIMEOUT_MS, then hipStreamSynchronize decides):
+ * PVDER_EINVAL when host_block is not device-addressable or n_env != 1, PVDER_ETIMEOUT when the word never arrives. */
+#define PVDER_MIRROR_WORDS 18
+#define PVDER_MIRROR_TIMEOUT_MS 2000
+#define PVDER_ETIMEOUT (-10003)
+int pvder_plan_step_mirror(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                           const uint8_t *action, void *out, double *hstep, float *stats, void *snapshot, const void *snapshot_src,
+                           size_t snapshot_bytes, double *host_block, uint64_t seq, void *stream);
 int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                        const uint8_t *actions, int n_steps, void *out, size_t out_step_stride, double *hstep,
                        float *stats, void *stream);

@@ -21,7 +21,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "ramp":        # one action held from th
     env = PVDERVec(N, device=dev, seed=3, auto_reset=False, events_spec=both_events_spec())
     env.reset()
     a = torch.full((N,), act, dtype=torch.uint8, device=dev)
-    show = [1, 2, 3, 4, 5, 7, 8, 10, 11, 12]
+    show = [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12]
     for t in range(160):
         L.pvder_debug_counters(buf, 1)
         env.step(a, return_tensors=False)
