@@ -2434,30 +2434,100 @@ __device__ __forceinline__ float lin_cross_frac(float s0, float sm, float s1) {
     return fminf(1.f, fmaxf(0.f, t));
 }
 
+// What a hybrid step that SLID leaves for the lane's next one (round 5): the alpha it ended with and dy+/dalpha between its last
+// two evaluations.  A lane in six slides through most of its env step once the whole batch sits at the current limit
+// (profiles/r05_careful_counters.txt), three evaluations a step, and a wave waits for its slowest lane: 24 evaluations per env
+// step where fifty-nine lanes need eight.  The next step of such a lane starts AT the alpha the last one found: ONE evaluation,
+// then along the carried derivative onto s = 0 while that moves alpha by less than kSlideThr -- otherwise a second evaluation one
+// Newton step further and the secant through the two.  3 + 7 x (1 .. 2) evaluations, same 7e-5 against the converged bridge
+// (etd_linear.hybrid_step states the same; fp64 prototype: tools/careful_schemes_proto.py).
+struct LinSlide {
+    bool on = false;
+    float a = 0.f;
+    pvder::v4f D[3];
+};
+constexpr float kSlideThr = 0.03f;
+
+// t with s(Yb + t D) = 0, s = |iref|^2 - iref_limit^2 (quadratic in the state): slope and curvature along D from s(Yb + D),
+// s(Yb - D), two Newton steps
+template <int PH>
+__device__ __forceinline__ float lin_slide_along(const pvder::PkConst &K, const pvder::SubPk &S, const pvder::v4f (&Yb)[3], float sb,
+                                                 const pvder::v4f (&D)[3], float qref, float vdcref, v2 kpo, float lim) {
+    using namespace pvder;
+    v4f Yp[3], Ym[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { Yp[g] = Yb[g] + D[g]; Ym[g] = Yb[g] - D[g]; }
+    const float sp = lin_iref2<PH>(K, S, Yp, qref, vdcref, kpo) - lim, sm = lin_iref2<PH>(K, S, Ym, qref, vdcref, kpo) - lim;
+    const float gs = 0.5f * (sp - sm), q = 0.5f * (sp + sm) - sb;
+    if (gs == 0.f) return 0.f;
+    const float t = -sb / gs;
+    const float d = gs + 2.f * q * t;
+    return d != 0.f ? t - (sb + gs * t + q * t * t) / d : t;
+}
+
 // one hybrid step of every lane (`act`: the lanes that will commit it); Yn = y+; returns the hand-over flag
 template <int PH>
 __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
                                                 const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, bool act,
-                                                float msc, pvder::v4f (&Yn)[3]) {
+                                                float msc, LinSlide &C, pvder::v4f (&Yn)[3]) {
     using namespace pvder;
     const float lim = G.A.P.ilim2;
     const PkConst K = make_pkconst(G.A.P);
     const float s0 = lin_iref2<PH>(K, S, Y, qref, vdcref, kpo) - lim;
     const bool from_free = s0 <= 0.f;
-    const float a1 = from_free ? 1.f : 0.f;
+    const bool cont = act && C.on;               // behind a step that slid: from where that one ended
+    const float a1 = cont ? C.a : (from_free ? 1.f : 0.f);
     float irm, ire;
     bool trip = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a1, msc, Yn, irm, ire);
     const float s1 = ire - lim;
-    const bool need2 = act && (from_free ? s1 > 0.f : s1 < 0.f);
     PVDER_DBG_COUNT(6, act);
-    PVDER_DBG_COUNT(7, need2);
-    if (__builtin_amdgcn_readfirstlane(__any((int)need2))) {
+    float b = a1;
+    bool two = false;
+    if (__builtin_amdgcn_readfirstlane(__any((int)cont))) {
+        const float t = lin_slide_along<PH>(K, S, Yn, s1, C.D, qref, vdcref, kpo, lim);
+        const float at = a1 + t;
+        if (cont) {
+            if (fabsf(t) < kSlideThr && at >= 0.f && at <= 1.f) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) Yn[g] = Yn[g] + t * C.D[g];
+                C.a = at;
+            } else {
+                b = fminf(1.f, fmaxf(0.f, at));
+                two = b != a1;
+                if (!two) C.on = false;            // (pinned at an end of [0, 1] and asked to go further: the step as it is)
+            }
+        }
+    }
+    const bool need2 = act && !cont && (from_free ? s1 > 0.f : s1 < 0.f);
+    PVDER_DBG_COUNT(7, need2 || two);
+    if (__builtin_amdgcn_readfirstlane(__any((int)(need2 || two)))) {
         // the limit is crossed inside the step: the integrators run free for the fraction `tau` (1 - tau) of it
         const float tau = lin_cross_frac(s0, irm - lim, s1);
-        const float a2 = need2 ? (from_free ? tau : 1.f - tau) : a1;
+        const float a2 = need2 ? (from_free ? tau : 1.f - tau) : b;
         v4f Y2[3];
         const bool trip2 = lin_etd3rk_aw<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, a2, msc, Y2, irm, ire);
         const float s2 = ire - lim;
+        if (__builtin_amdgcn_readfirstlane(__any((int)two))) {
+            // a continued slide, second evaluation: the slide ends inside this step (free / frozen integrators are what holds from
+            // here on), or the secant through the two
+            v4f Dn[3];
+            const float rd = two ? 1.f / (b - a1) : 0.f;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) Dn[g] = (Y2[g] - Yn[g]) * rd;
+            float t = lin_slide_along<PH>(K, S, Y2, s2, Dn, qref, vdcref, kpo, lim);
+            if (two) {
+                const bool ends = (b == 1.f && s2 <= 0.f) || (b == 0.f && s2 >= 0.f);
+                t = (ends || fabsf(t) > 1.f) ? 0.f : t;
+                float bt = b + t;
+                const bool leaves = bt < 0.f || bt > 1.f;
+                if (leaves) { bt = fminf(1.f, fmaxf(0.f, bt)); t = bt - b; }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { Yn[g] = Y2[g] + t * Dn[g]; C.D[g] = Dn[g]; }
+                C.a = bt;
+                C.on = !(ends || leaves);
+                trip = trip2;
+            }
+        }
         if (need2) { Yn[0] = Y2[0]; Yn[1] = Y2[1]; Yn[2] = Y2[2]; trip = trip2; }
         const bool need3 = need2 && (from_free ? s2 < 0.f : s2 > 0.f);
         PVDER_DBG_COUNT(8, need3);
@@ -2474,9 +2544,19 @@ __device__ __forceinline__ bool lin_hybrid_step(const LinArgs &G, const pvder::L
                 // env step; etd_linear.hybrid_step states the same)
                 const float s3 = ire - lim;
                 float w = -s3 / (s3 - s2);
-                w = (s3 != s2 && a3 != a2 && fabsf(w) <= 1.f) ? w : 0.f;
+                const bool ok = s3 != s2 && fabsf(a3 - a2) > 1e-4f && fabsf(w) <= 1.f;
+                w = ok ? w : 0.f;
+                // ... and what the lane's next step starts from
+                const float as = a3 + w * (a3 - a2);
+                C.on = ok && as >= 0.f && as <= 1.f;
+                C.a = as;
+                const float rd = ok ? 1.f / (a3 - a2) : 0.f;
 #pragma unroll
-                for (int g = 0; g < 3; ++g) Yn[g] = Y2[g] + w * (Y2[g] - Yn[g]);
+                for (int g = 0; g < 3; ++g) {
+                    const v4f dY = Y2[g] - Yn[g];
+                    C.D[g] = dY * rd;
+                    Yn[g] = Y2[g] + w * dY;
+                }
                 trip = trip3;
             }
         }
@@ -2508,6 +2588,9 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
     bool start = true;
     bool done = !run;
     SubPk S;
+    LinSlide Cs;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) Cs.D[g] = v4f{0.f, 0.f, 0.f, 0.f};
     cur = __builtin_amdgcn_readfirstlane(cur);
     sg.sch = G.Lk.sched[C.n_sub + sg.seg - 1];           // the careful row of the first segment
     for (;;) {
@@ -2531,6 +2614,7 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
                 defer |= trip;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 start = false;
+                Cs.on = false;                     // (the jump moves |iref|: whatever slid starts over)
             }
         }
         const int sidx = (int)(sg.sch & 0xffull);
@@ -2545,7 +2629,7 @@ __device__ __forceinline__ bool lin_integrate_careful(const LinArgs &G, int lane
             }
             v4f Yn[3];
             const bool mine = todo && sidx == s_now;
-            const bool trip = lin_hybrid_step<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, mine, msc, Yn);
+            const bool trip = lin_hybrid_step<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, mine, msc, Cs, Yn);
             PVDER_DBG_COUNT(5, mine && trip);
             if (mine) {
                 defer |= trip;

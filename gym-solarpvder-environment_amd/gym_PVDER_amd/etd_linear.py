@@ -28,7 +28,7 @@ fp64, host only, once per (parameter set, step schedule) -- not on the hot path.
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -559,11 +559,22 @@ def careful_tick(c, P1: np.ndarray, y, inputs, ilim2: float):
     return yn
 
 
-def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
+SLIDE_THR = 0.03         # a step behind one that slid: the one-evaluation form while it moves alpha by less than this
+
+
+def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float, carry: Optional[dict] = None, slide_thr: float = SLIDE_THR):
     """One hybrid ETD3RK step of an env at the current limit (DESIGN.md "careful pass"): the same step up to three
     times -- free / frozen; with the crossing of |iref| = iref_limit located inside the step; sliding along it.
-    Returns (y+, evaluations)."""
+    Returns (y+, evaluations).
+
+    ``carry`` (round 5; the device keeps it per lane from the tick of an env step / segment on): what a step that SLID leaves
+    for the next one -- the alpha it ended with and dy+/dalpha between its last two evaluations.  The next step then starts AT
+    that alpha: one evaluation, and along the carried derivative onto s = 0 when that moves alpha by less than ``slide_thr``
+    (s is quadratic in the state: slope and curvature along D from s(y + D), s(y - D)); otherwise a second evaluation one Newton
+    step further and the secant through the two.  An env that slides through a whole env step takes 3 + 7 x (1 .. 2)
+    evaluations instead of 24 (fp64 prototype: tools/careful_schemes_proto.py, same 7e-5 against the converged bridge)."""
     M21, M31, M32, M41, M42, M43 = mats
+    s = lambda u: iref2(c, u, inputs[0], inputs[2], inputs[3]) - ilim2
 
     def step(alpha):
         F1 = f_bal_limited(c, y, inputs, alpha, ilim2); a = y + M21 @ F1
@@ -580,10 +591,47 @@ def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
             for k in (7, 8):
                 if F1[k] == 0.0 and F2[k] == 0.0 and F3[k] == 0.0:
                     yn[k] = y[k]
-        s = lambda u: iref2(c, u, inputs[0], inputs[2], inputs[3]) - ilim2
         return yn, s(a), s(yn)
 
-    s0 = iref2(c, y, inputs[0], inputs[2], inputs[3]) - ilim2
+    def along(yb, sb, D):
+        """t with s(yb + t D) = 0: two Newton steps on the quadratic through s(yb - D), sb, s(yb + D)"""
+        sp, sm_ = s(yb + D), s(yb - D)
+        g, q = 0.5 * (sp - sm_), 0.5 * (sp + sm_) - sb
+        if g == 0.0:
+            return 0.0
+        t = -sb / g
+        return t - (sb + g * t + q * t * t) / (g + 2.0 * q * t) if g + 2.0 * q * t != 0.0 else t
+
+    if carry is not None and carry.get("alpha") is not None:
+        a = carry["alpha"]
+        D = carry["D"]
+        ya, _, sa = step(a)
+        t = along(ya, sa, D)
+        if abs(t) < slide_thr and 0.0 <= a + t <= 1.0:
+            carry["alpha"] = a + t
+            return ya + t * D, 1
+        b = min(1.0, max(0.0, a + t))
+        if b == a:                                  # (pinned at an end of [0, 1] and asked to go further: the step as it is)
+            carry["alpha"] = None
+            return ya, 1
+        yb, _, sb = step(b)
+        if (b == 1.0 and sb <= 0.0) or (b == 0.0 and sb >= 0.0):
+            carry["alpha"] = None                   # the slide ends inside this step: free (frozen) is what holds from here on
+            return yb, 2
+        D = (yb - ya) / (b - a)
+        t = along(yb, sb, D)
+        if abs(t) > 1.0:
+            t = 0.0
+        if not 0.0 <= b + t <= 1.0:
+            # the slide ends inside this step (even free / frozen integrators do not hold the limit): free (frozen) it is, by
+            # the same affine combination -- and the next step starts as a first one
+            t = min(1.0, max(0.0, b + t)) - b
+            carry["alpha"] = None
+            return yb + t * D, 2
+        carry["alpha"], carry["D"] = b + t, D
+        return yb + t * D, 2
+
+    s0 = s(y)
     free = s0 <= 0
     a1 = 1.0 if free else 0.0
     y1, sm, s1 = step(a1)
@@ -603,6 +651,9 @@ def hybrid_step(c, mats: Sequence[np.ndarray], y, inputs, ilim2: float):
         # |iref| = iref_limit to 1e-8, these steps used to end 1.6e-4 above it: 1.4e-4 in the observations)
         w = -s3 / (s3 - s2)                       # (alpha* - a3) / (a3 - a2)
         if abs(w) <= 1.0:
+            a_end = a3 + w * (a3 - a2)
+            if carry is not None and abs(a3 - a2) > 1e-4 and 0.0 <= a_end <= 1.0:
+                carry["alpha"], carry["D"] = a_end, (y3 - y2) / (a3 - a2)
             y3 = y3 + w * (y3 - y2)
     return y3, 3
 

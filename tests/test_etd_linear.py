@@ -214,6 +214,51 @@ def test_current_limit_hybrid_steps_fp64(lin50):
     assert worst < 4e-5, worst
 
 
+def test_a_step_behind_one_that_slid_starts_where_that_one_ended(lin50):
+    """Round 5 (csrc LinSlide, el.hybrid_step's `carry`): an env that slides along |iref| = iref_limit needs three evaluations
+    in every step of the shipped scheme; with the alpha and dy+/dalpha of its last step carried over it needs one or two --
+    same trajectory to 2e-5 of the three-evaluation scheme on the committed ramp samples, a third fewer evaluations for the
+    envs that slide, and what is carried stays inside [0, 1]."""
+    import bridge_cases
+    par, c, L, ystar = lin50
+    ilim2 = par[der_model.IDX["IREF_LIMIT"]] ** 2
+    vdc0 = par[der_model.IDX["VDC_REF0"]]
+    g = bridge_cases.load("ramp_a1_sample")
+    tick = 2 / 1920.0
+    P1 = tick * el.phis(L, tick, 1)[1]
+    M = el.etd3rk_f_matrices(L, (0.25 - tick) / el.CAREFUL_STEPS)
+    y0f = der_model.steady_state(par, "50")
+    K = g["vgrid"].shape[0] - 1
+    row = lambda k: 0 if k < 60 else min((k - 60) // 60 + 1, K)
+    tot = {False: 0, True: 0}
+    slid = {False: 0, True: 0}
+    worst = 0.0
+    for e in (20, 3):                                      # (env 20: slides through env step 140 with alpha 0.13 -> 1)
+        ys = {}
+        for carried in (False, True):
+            y = np.concatenate([y0f[:6], y0f[18:]])
+            traj = []
+            for t in range(150):
+                inp = (g["vgrid"][row(15 * t), e], g["sinsol"][row(15 * t), e], 0.0075 * (t + 1), vdc0)
+                y = el.careful_tick(c, P1, y, inp, ilim2)
+                W = {} if carried else None
+                n_env_step = 0
+                for _ in range(el.CAREFUL_STEPS):
+                    y, ne = el.hybrid_step(c, M, y, inp, ilim2, carry=W)
+                    n_env_step += ne
+                    if W and W.get("alpha") is not None:
+                        assert 0.0 <= W["alpha"] <= 1.0
+                tot[carried] += n_env_step
+                if n_env_step > el.CAREFUL_STEPS + 4:
+                    slid[carried] += n_env_step
+                traj.append(y.copy())
+            ys[carried] = np.array(traj)
+        sel = [0, 1, 6, 7, 8]
+        worst = max(worst, float(np.abs(ys[True] - ys[False])[:, sel].max() / np.abs(ys[False][:, sel]).max()))
+    assert slid[False] > 0 and slid[True] < 0.75 * slid[False], (slid, tot)
+    assert worst < 2e-5, worst
+
+
 @pytest.mark.parametrize("name", ["random_both_n15", "random_both_n4", "vdcalt_both_n15"])
 def test_fp32_emulation_of_the_kernel_arithmetic_vs_golden(lin50, name):
     """The kernel's scheme in numpy float32 (two steps per segment: one tick, then the rest) against

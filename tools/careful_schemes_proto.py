@@ -9,12 +9,21 @@ evaluation and wave (one wave per SIMD, latency bound), and a wave pays for the 
 once the whole batch sits at the limit (profiles/r05_careful_counters.txt).  Schemes compared here, per step count:
 
     hybrid   the shipped step (etd_linear.hybrid_step)
+    hybrid2  the shipped step without its third evaluation: a step that should slide ends on s = 0 of the affine combination of
+             the two evaluations it has
     affine   TWO evaluations, alpha = 0 and alpha = 1, for a step that crosses or slides; the state at any alpha in between
-             is their affine combination (the outward-moving integrators advance at alpha times their rate: y+(alpha) is
-             affine in alpha up to the curvature of N over a change of 1e-4 in two slow states) -- crossing fraction and
-             the slide onto |iref| = iref_limit are then scalar root searches on iref2, no further evaluation
+             is their affine combination -- crossing fraction and the slide onto |iref| = iref_limit are then scalar root
+             searches on iref2, no further evaluation
+    sens     ONE evaluation; y+(alpha) from the LINEAR response h phi1(hL) g to the integrators' forcing
     eqctl    ONE evaluation: alpha per STAGE from Filippov's equivalent control with a Baumgarte term,
              alpha = clamp(-(A + gamma s) / B, 0, 1),  ds/dt = A + alpha B,  gamma = 1 / h
+    warm1/2  the shipped step, but a step behind one that SLID starts from the alpha that one ended with: one evaluation and
+             the last step's dy+/dalpha (warm1), or two evaluations one secant step apart (warm2)
+    slide    warm1 / warm2 as the device has them (etd_linear.hybrid_step with a carry; gamma*h column = the threshold on the
+             alpha the one-evaluation form may move by)
+    warmeq   ... or the equivalent control stage by stage, then onto s = 0 along the last step's dy+/dalpha
+Result (profiles/r05_careful_schemes_proto.txt): only warm2 keeps the shipped step's accuracy (7e-5 worst env step); every
+one-evaluation form and both two-evaluation forms of the FIRST sliding step lose a factor 3-30.
 
     python tools/careful_schemes_proto.py [n_envs]      -> profiles/r05_careful_schemes_proto.txt"""
 import os
@@ -155,7 +164,15 @@ def warm_step(y, M, inp, W, evals_warm=1):
         ya, _ = etd3(y, M, inp, a)
         sa = s_of(ya, inp)
         D = W["D"]
-        if evals_warm == 2:
+        if evals_warm == 3:
+            # adaptive: the last step's dy+/dalpha if the polish moves alpha by less than thr, the second evaluation otherwise
+            eps = 1e-3
+            ds = (s_of(ya + eps * D, inp) - sa) / eps
+            evals_here = 1 if (ds != 0 and abs(sa / ds) < W.get("thr", 0.03)) else 2
+            W["n1"] = W.get("n1", 0) + (evals_here == 1); W["n2"] = W.get("n2", 0) + (evals_here == 2)
+        else:
+            evals_here = evals_warm
+        if evals_here == 2:
             ds = None
             # slope ds/dalpha from the last step's derivative of the STATE: one scalar evaluation of iref2
             eps = 1e-3
@@ -202,6 +219,14 @@ def warm_step(y, M, inp, W, evals_warm=1):
             W["D"] = (y3 - y2) / (a3 - a2)
             y3 = y3 + w * (y3 - y2)
     return y3
+
+
+def slide_step(y, M, inp, W, thr=0.03, dtype=np.float64):
+    """The step as the device takes it from round 5 on (etd_linear.hybrid_step with its `carry`): a FIRST sliding step as shipped
+    (three evaluations); a step behind one that slid starts at the alpha that one ended with -- ONE evaluation, then along the
+    last step's dy+/dalpha onto s = 0 (s is quadratic in the state: its directional derivative from s(y + D), s(y - D)) when that
+    moves alpha by less than `thr`, otherwise a second evaluation one Newton step further and the secant through the two"""
+    return el.hybrid_step(c, M, y, inp, ILIM2, carry=W, slide_thr=thr)
 
 
 def sens_step(y, M, inp, PH1, weights=(1.0 / 6, 4.0 / 6, 1.0 / 6)):
@@ -318,6 +343,11 @@ def ramp(action, vgt, sit, steps, nst, mode, n=15, gscale=1.0):
                 y = affine_step(y, M, inp)
             elif mode == "warmeq":
                 y = warm_step(y, M, inp, W, 0)
+            elif mode == "slide":
+                y, ne = slide_step(y, M, inp, W, gscale); EVALS[0] += ne
+            elif mode == "warm12":
+                W["thr"] = gscale
+                y = warm_step(y, M, inp, W, 3)
             elif mode == "warm1":
                 y = warm_step(y, M, inp, W, 1)
             elif mode == "warm2":
@@ -340,7 +370,8 @@ def main():
     for name, a in (("ramp_a1_sample", 1), ("ramp_a2_sample", 2)):
         g = bridge_cases.load(name)
         envs = list(range(0, g["obs"].shape[1], max(1, g["obs"].shape[1] // n_envs)))[:n_envs]
-        for mode, counts, gs in (("hybrid", (8,), 1.0), ("warmeq", (8,), 0.0), ("warmeq", (8,), 0.3), ("warmeq", (8,), 1.0), ("warm2", (8,), 1.0)):
+        for mode, counts, gs in (("hybrid", (8, 6, 4), 1.0), ("slide", (8,), 0.03), ("slide", (8,), 0.1), ("hybrid2", (8,), 1.0), ("affine", (8,), 1.0), ("sens", (8,), 1.0), ("eqctl", (8,), 1.0),
+                                 ("warm1", (8,), 1.0), ("warm2", (8, 6), 1.0), ("warmeq", (8,), 0.0)):
             for nst in counts:
                 worst, traj = [], 0.0
                 EVALS[0] = 0
