@@ -2671,7 +2671,7 @@ template <int PH, int KOFF, bool T3 = false>
 __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinRegs &R,
                                               const uint8_t *__restrict__ act, long long out_off, int stats_fresh,
                                               const float *__restrict__ fstate, const int32_t *__restrict__ istate, int n_env,
-                                              bool only = true, int32_t *second_pass = nullptr, int second_pass_was = 0) {
+                                              bool only = true) {
     using namespace pvder;
     const EtdArgs &A = G.A;
     constexpr int NS = 6 * PH + 5;
@@ -2697,11 +2697,9 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
     PVDER_TRACE_AT(1);
     bool defer = PH == 3 && A.force_full != 0;
     bool seq = false;                   // off balance, carried by its positive-sequence component (lin_seq_split)
-    bool off_std = false;               // this env needed more than the standard pass (step_etdlin_kernel's second_pass note)
     float msc = 1.f;
     if constexpr (PH == 3) {
         const bool unb = L.run && !defer && lin_unbalanced(ys);
-        off_std = unb;
         if (__builtin_amdgcn_readfirstlane(__any((int)unb))) {
             // (rare: the propagator is read from the kernel-argument segment right here, not kept in SGPRs for the launch)
             KernargPtr kq = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
@@ -2729,7 +2727,6 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
         defer = defer0 || (defer && !careful);
         PVDER_TRACE_COLD_AT(9);
         PVDER_DBG_COUNT(2, careful);
-        off_std |= careful;
         if (__builtin_amdgcn_readfirstlane(__any((int)careful))) {
             // envs at the current limit: their env step again, from the state it started with, by the careful pass
             v4f Yc[3];
@@ -2774,12 +2771,6 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
         // RK4 micro-steps (single phase) right here -- no second launch
         defer = defer && !L.fail && only;
         PVDER_DBG_COUNT(10, defer);
-        if (second_pass != nullptr) {
-            // what the NEXT launch's workgroup of these envs starts with (step_etdlin_entry): this body at once while any of
-            // its envs is off the standard path -- written only when it changes
-            const int now = __syncthreads_or((int)((off_std || defer) && only)) ? 1 : 0;
-            if (threadIdx.x == 0 && now != second_pass_was) second_pass[blockIdx.x] = now;
-        }
         if (__syncthreads_or((int)defer)) {
             PVDER_DBG_COUNT(11, threadIdx.x == 0);
             KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
@@ -2804,7 +2795,6 @@ struct LinHead {
     const float *lcoef;
     int n_env, ksub_hint;            // ksub_hint: -1 = none; else the clock, | kLinHintQuiet when the env step that starts there is a QUIET one
     const float *k4coef;
-    int32_t *second_pass;            // plan-owned int32[workgroups], or NULL: see step_etdlin_entry
 };
 constexpr int kLinHintQuiet = 1 << 30;
 constexpr int kLinHeadBytes = (int)sizeof(LinHead);
@@ -2895,17 +2885,10 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
 constexpr int kChainSpinLimit = 1 << 22;            // x ~0.1 us of s_sleep: ~0.4 s
 template <int PH, bool T3, bool CHAIN = false>
 __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate, const uint8_t *action, const float *lcoef, int n_env,
-                                                  int ksub_word, const float *k4coef, int32_t *second_pass, const LinArgs &G,
-                                                  int32_t *chain = nullptr, int seq = 0) {
+                                                  int ksub_word, const float *k4coef, const LinArgs &G, int32_t *chain = nullptr,
+                                                  int seq = 0) {
     using namespace pvder;
     PVDER_TRACE_AT(0);
-    // (round 5) what this workgroup's envs needed in the PREVIOUS step of the plan: a workgroup whose envs sit at a limit (fixed
-    // actions 1 / 2 / 4, one saturated env among 65 535 quiet ones) needs the second pass step after step, and the lean pass in
-    // front of it is 7.5 us of results nobody uses (profiles/r04_careful_timeline.txt).  A note per workgroup in plan-owned memory,
-    // read here with the first loads (a scalar load: back before the state rows are) and rewritten by lin_step_body when it changes:
-    // a PREDICTION of the path, never a result -- both paths are the same arithmetic (single phase takes the body always).
-    int sp_was = 0;
-    if (PH == 3 && !CHAIN && second_pass != nullptr) sp_was = __builtin_nontemporal_load(second_pass + blockIdx.x);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
     // first ETD3RK set stay in registers for the whole launch; another set replaces the latter only when
     // an env needs it (an env off the event grid).  Issued FIRST (they depend on nothing but the kernel
@@ -2950,14 +2933,8 @@ __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate
         lin_step_body<PH, kLinHeadBytes, T3>(G, lane, R, action, 0, G.A.stats_fresh, fstate, istate, n_env);
         return;
     }
-    bool leave = true;
-    int second_fresh = G.A.stats_fresh;
-    sp_was = __builtin_amdgcn_readfirstlane(sp_was);
-    if (sp_was == 0) {
-        leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, R, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
-        second_fresh = 0;
-    }
-    if (sp_was != 0 || __syncthreads_or((int)leave)) {
+    const bool leave = lin_step_lean<PH, kLinHeadBytes>(G, lane, R, action, G.A.stats_fresh, fstate, istate, n_env, ksub_hint);
+    if (__syncthreads_or((int)leave)) {
         // (rare: every argument again through a laundered copy of the kernarg pointer -- nothing of this pass stays
         // live across the lean one)
         typedef __attribute__((address_space(4))) const char *KernargBytes;
@@ -2967,8 +2944,7 @@ __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate
         const LinArgs &Gc = *(const LinArgs *)kc;
         LinRegs Rc;                      // (its coefficient registers too: loaded where the pass needs them)
         Rc.at_ok = false; Rc.cur = 0; Rc.k4_ok = false;
-        lin_step_body<PH, kLinHeadBytes, T3>(Gc, lane, Rc, Gc.A.action, 0, second_fresh, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave,
-                                             CHAIN ? nullptr : second_pass, sp_was);
+        lin_step_body<PH, kLinHeadBytes, T3>(Gc, lane, Rc, Gc.A.action, 0, 0, Gc.A.fstate, Gc.A.istate, Gc.A.n_env, leave);
     }
 #endif
     if constexpr (CHAIN) {
@@ -2988,21 +2964,21 @@ __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate
 // launch_plan picks by batch size; same arithmetic, same results.
 template <int PH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel(float *fstate, int32_t *istate, const uint8_t *action,
-                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, int32_t *second_pass, const LinArgs G) {
-    step_etdlin_entry<PH, false>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, second_pass, G);
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
+    step_etdlin_entry<PH, false>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G);
 }
 template <int PH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_etdlin_kernel_w1(float *fstate, int32_t *istate, const uint8_t *action,
-                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, int32_t *second_pass, const LinArgs G) {
-    step_etdlin_entry<PH, PH == 3>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, second_pass, G);
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G) {
+    step_etdlin_entry<PH, PH == 3>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G);
 }
 #ifdef PVDER_CHAIN_EXPERIMENT
 // (A/B, -DPVDER_CHAIN_EXPERIMENT builds + PVDER_CHAIN=1: see step_etdlin_entry; NOT in the shipped library -- measured and not kept,
 //  profiles/r05_ab_workgroup_chained_launches.txt) the two-waves-per-SIMD kernel, so that a workgroup of step t+1 finds room beside one of step t
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_kernel_chain(float *fstate, int32_t *istate, const uint8_t *action,
-                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, int32_t *second_pass,
-                                                             const LinArgs G, int32_t *chain, int seq) {
-    step_etdlin_entry<3, false, true>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, second_pass, G, chain, seq);
+                                                             const float *lcoef, int n_env, int ksub_word, const float *k4coef, const LinArgs G,
+                                                             int32_t *chain, int seq) {
+    step_etdlin_entry<3, false, true>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G, chain, seq);
 }
 #endif
 constexpr int kOneWavePerSimdEnvs = 65536;       // 256 CUs x 4 SIMDs x 64 lanes (MI355X)
@@ -4096,15 +4072,11 @@ struct pvder_plan {
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
-    mutable int32_t *second_pass = nullptr;    // etdlin, three-phase: device int32[workgroups], which path each workgroup's envs took
-                                               // in the previous step (step_etdlin_entry: a prediction, never a result); plans
-                                               // made by pvder_plan_create only
     // A/B experiment (PVDER_CHAIN=1, pvder_plan_rollout): per-workgroup chained launches on two streams
     mutable int32_t *chain = nullptr;          // device: int32[n_wg + 1] (progress per workgroup, [n_wg] = a wait timed out)
     mutable hipStream_t chain_stream = nullptr;
     mutable hipEvent_t chain_fork = nullptr, chain_join = nullptr;
     ~pvder_plan() {
-        if (second_pass) (void)hipFree(second_pass);
         if (chain) (void)hipFree(chain);
         if (chain_fork) (void)hipEventDestroy(chain_fork);
         if (chain_join) (void)hipEventDestroy(chain_join);
@@ -4256,14 +4228,12 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
             const int hint = (capturing && !hint_in_graphs) ? -1 : hint_word(p);
-            static const bool no_sp = []() { const char *v = getenv("PVDER_NO_SECOND_PASS_NOTE"); return v && v[0] == '1'; }();    // (A/B)
-            int32_t *sp = no_sp ? nullptr : p.second_pass;
             if (p.ph == 3 && n_env <= kOneWavePerSimdEnvs && !no_w1)
-                hipLaunchKernelGGL(step_etdlin_kernel_w1<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, sp, G);
+                hipLaunchKernelGGL(step_etdlin_kernel_w1<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, G);
             else if (p.ph == 3)
-                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, sp, G);
+                hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, G);
             else
-                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, sp, G);
+                hipLaunchKernelGGL(step_etdlin_kernel<1>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, G);
             if (!capturing || hint_in_graphs) advance_hint(p, 1);
         } else {
             // per-lane parameters: a phase per lane (four times the waves, 0.6 x the instructions per wave: the LATENCY form) while
@@ -4426,15 +4396,6 @@ int pvder_plan_create(pvder_plan **plan, int integrator, const double *par, cons
     if (!p) return -(int)hipErrorOutOfMemory;
     const int rc = fill_plan(*p, integrator, par, cfg, ar, coef, lin, n_env);
     if (rc) { delete p; return rc; }
-    if (integrator == PVDER_INT_ETDLIN && p->ph == 3) {
-        // (a host without a device -- the CPU tests fold plans too -- leaves it NULL: the step then takes the lean pass first)
-        const size_t bytes = (size_t)((n_env + kBlock - 1) / kBlock) * sizeof(int32_t);
-        if (hipMalloc((void **)&p->second_pass, bytes) != hipSuccess || hipMemset(p->second_pass, 0, bytes) != hipSuccess) {
-            if (p->second_pass) (void)hipFree(p->second_pass);
-            p->second_pass = nullptr;
-            (void)hipGetLastError();
-        }
-    }
     *plan = p;
     return 0;
 }
@@ -4608,7 +4569,7 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
             A.action = actions + (size_t)k * n_env; A.out = (float *)out + (size_t)k * out_step_stride; A.stats = stats; A.stats_fresh = 1;
             static const bool one_stream = []() { const char *v = getenv("PVDER_CHAIN_ONE_STREAM"); return v && v[0] == '1'; }();
             hipLaunchKernelGGL(step_etdlin_kernel_chain, grid, block, 0, ((k & 1) && !one_stream) ? p.chain_stream : sa, A.fstate, A.istate, A.action,
-                               G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, (int32_t *)nullptr, G, p.chain, k);
+                               G.Lk.lcoef, n_env, hint_word(p), G.Lk.k4coef, G, p.chain, k);
             advance_hint(p, 1);
         }
         e = hipEventRecord(p.chain_join, p.chain_stream);

@@ -82,7 +82,7 @@ class LinCoef(C.Structure):
 # v_accvgpr_read copies); -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (pointers and
 # sizes a launch needs for its first loads) arrive in SGPRs with the wave instead of through an s_load
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-               "-mllvm", "-amdgpu-kernarg-preload-count=14"]
+               "-mllvm", "-amdgpu-kernarg-preload-count=12"]
 
 
 def hipcc_path() -> str:

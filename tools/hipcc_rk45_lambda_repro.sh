@@ -8,7 +8,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p tools/_ab
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=14 -fPIC -shared \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=12 -fPIC -shared \
   -Iinclude -Igym-solarpvder-environment_amd/csrc -DPVDER_RK45_LAMBDA "$@" -o tools/_ab/librk45l.so \
   gym-solarpvder-environment_amd/csrc/pvder_agent.hip gym-solarpvder-environment_amd/csrc/pvder_kernels.hip || exit 1
 PVDER_LIB_PATH=$PWD/tools/_ab/librk45l.so python -m pytest tests -m gpu -q -x -k "rk45 and not etdlin64" 2>&1 | tail -15

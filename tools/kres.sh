@@ -3,7 +3,7 @@
 #   tools/kres.sh [extra hipcc flags]
 cd "$(dirname "$0")/.."
 mkdir -p .scratch
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=14 -Iinclude \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=12 -Iinclude \
   -Igym-solarpvder-environment_amd/csrc -Rpass-analysis=kernel-resource-usage "$@" -o .scratch/kres.so \
   gym-solarpvder-environment_amd/csrc/pvder_kernels.hip 2>&1 |
   python3 -c '

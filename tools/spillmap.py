@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, ".scratch", "k.s")
 if len(sys.argv) <= 2:
     os.makedirs(os.path.dirname(asm), exist_ok=True)
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-kernarg-preload-count=14",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-kernarg-preload-count=12",
                            "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "gym-solarpvder-environment_amd/csrc"),
                            "--cuda-device-only", "-S", "-o", asm,
                            os.path.join(root, "gym-solarpvder-environment_amd/csrc/pvder_kernels.hip")], stderr=subprocess.DEVNULL)
