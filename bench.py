@@ -443,8 +443,10 @@ def single_env_leg(steps=1000):
 
 def lane_params_leg(torch, dev, n_sub, sizes=(16384, 65536), steps=40):
     """The per-env parameter override (domain randomisation over C, the outer-loop gains, the PV array size and the
-    insolation scale; PVDERVec(integrator="etdrk4", lane_params=...)): every env of the batch with its OWN set on the 23-state
-    ETDRK4 path, one launch per env step -- the phase-per-lane kernel up to 32 768 envs, the lane-per-env kernel beyond."""
+    insolation scale; PVDERVec(lane_params=...)): every env of the batch with its OWN set, one launch per env step -- on the
+    matrix-core path (the default integrator, round 5: the group's exponential operator, the env's own constants in the right-hand
+    side, two Krogstad steps per env step: step_etdlin_lane_kernel) and on the 23-state ETDRK4 path (integrator="etdrk4": the
+    phase-per-lane kernel up to 32 768 envs, the lane-per-env kernel beyond)."""
     import numpy as np
     from gym_PVDER_amd import der_model
     from gym_PVDER_amd.vec_env import PVDERVec
@@ -456,22 +458,26 @@ def lane_params_leg(torch, dev, n_sub, sizes=(16384, 65536), steps=40):
                 "Ki_DC": base["Ki_DC"] * rng.uniform(0.8, 1.25, N), "Kp_Q": base["Kp_Q"] * rng.uniform(0.8, 1.25, N),
                 "Ki_Q": base["Ki_Q"] * rng.uniform(0.8, 1.25, N), "Np": rng.integers(10, 12, N).astype(np.float64),
                 "Sinsol_scale": rng.uniform(0.9, 1.0, N)}
-        env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2, events_spec=events_on_spec(), auto_reset=True,
-                       integrator="etdrk4", lane_params=sets)
-        env.reset()
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(9)
-        a = torch.randint(0, 5, (steps, N), generator=gen, device=dev, dtype=torch.uint8)
-        env.rollout(a, fused=False)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record(); env.rollout(a, fused=False); e1.record()
-        torch.cuda.synchronize(dev)
-        us = e0.elapsed_time(e1) * 1e3 / steps
-        out["envs_%d" % N] = {"us_per_step": us, "value": N / us * 1e6, "unit": "env-steps/s", "distinct_parameter_sets": N,
-                              "kernel": "step_etdrk4_lane3_kernel" if N <= 32768 else "step_etdrk4_lane_kernel",
-                              "n_nonfinite": env.step_stats()["n_nonfinite"]}
-    out["parity"] = "tests/test_gpu_lane_params.py (64 sets vs the bridge integrating each: 3.4e-5; the two kernels bit for bit)"
+        for integ in ("etdlin", "etdrk4"):
+            env = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, seed=2, events_spec=events_on_spec(), auto_reset=True,
+                           integrator=integ, lane_params=sets)
+            env.reset()
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(9)
+            a = torch.randint(0, 5, (steps, N), generator=gen, device=dev, dtype=torch.uint8)
+            env.rollout(a, fused=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record(); env.rollout(a, fused=False); e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / steps
+            row = {"us_per_step": us, "value": N / us * 1e6, "unit": "env-steps/s", "distinct_parameter_sets": N,
+                   "kernel": "step_etdlin_lane_kernel" if integ == "etdlin" else ("step_etdrk4_lane3_kernel" if N <= 32768 else "step_etdrk4_lane_kernel"),
+                   "n_nonfinite": env.step_stats()["n_nonfinite"]}
+            # (keys of rounds 3-5 -- envs_16384 / envs_65536 -- stay the ETDRK4 kernels; the matrix-core path beside them)
+            out[("envs_%d" % N) if integ == "etdrk4" else ("etdlin_envs_%d" % N)] = row
+    out["parity"] = ("tests/test_gpu_lane_params.py (64 sets vs the bridge integrating each: ETDRK4 lane kernels 3.4e-5, etdlin lane kernel "
+                     "< 1e-4 -- see the test; the two ETDRK4 kernels bit for bit)")
     return out
 
 

@@ -2048,9 +2048,10 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
 template <int PH, bool EARLY>
 __device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs &Ak, const pvder::v4f (&Y)[3],
                                        const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
-                                       float msc, pvder::v4f (&Yn)[3], bool &near_ilim, bool mine, bool &cut) {
+                                       float msc, pvder::v4f (&Yn)[3], bool &near_ilim, bool mine, bool &cut,
+                                       const ModelK<float> *lane_model = nullptr) {
     using namespace pvder;
-    const ModelK<float> &P = G.A.P;
+    const ModelK<float> &P = lane_model ? *lane_model : G.A.P;        // (step_etdlin_lane_kernel: the env's own constants in f)
     const EtdK &Ec = G.A.Ec;
     const PkConst K = make_pkconst(P);
     v2 yp[6], F[6];
@@ -2981,6 +2982,99 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     step_etdlin_entry<3, false, true>(fstate, istate, action, lcoef, n_env, ksub_word, k4coef, G, chain, seq);
 }
 #endif
+// ---- per-LANE parameter sets on the matrix-core path (round 5; pvder_plan_lane_params on an etdlin plan) ------------------------
+// Domain randomisation (an optional per-env override of config_der.json:2-21) went through the 23-state ETDRK4 lane
+// kernels: 48-78 us per batched step against 7.8.  The exponential integrator does not need the env's own operator: f = L y + N(y)
+// holds for ANY L, the f-form steps evaluate f alone -- with the env's OWN constants (the seven folded rows of lane_par: 1/C, the
+// outer PI gains, the PV array) -- and L, the GROUP's Jacobian at its operating point, stays the one shared coefficient block.  What
+// the mismatch costs is accuracy per step (the outer loops' part of N is no longer small): TWO Krogstad steps per env step instead
+// of one hold 6e-5 of the converged per-set bridge on the 64-set golden (C x 0.7-1.4, gains x 0.8-1.25, 10 / 11 strings; one step:
+// 2.7e-4, the env's own operator: 1.7e-5 -- tools/lane_etdlin_proto.py).  k4lane: two Krogstad blocks behind the plan's own
+// (pvder_lin_coef.k4 & 2): half a quiet env step, half of what a tick leaves of an env step that starts at an event row.
+// An env that needs more than that -- off balance, near the current or the duty-cycle limit, an event row change INSIDE its env
+// step -- takes the 23-state lane path in the same launch (etdrk4_full_tail<LP>), as the lockstep kernels do.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_lane_kernel(const LinArgs G, const float *__restrict__ lane_par,
+                                                                                                          const float *__restrict__ k4lane) {
+    using namespace pvder;
+    const EtdArgs &A = G.A;
+    constexpr int NS = 23;
+    const size_t N = (size_t)A.n_env;
+    const int lane = threadIdx.x & 63;
+    Lane<float> L;
+    float ys[NS];
+    prologue<float, NS>(A.C, A.fstate, A.istate, A.action, A.n_env, L, ys);
+    ModelK<float> Pl = A.P;
+    {
+        const float *__restrict__ lp = lane_par + L.ec;
+        Pl.iC = lp[(size_t)PVDER_LPF_IC * N];
+        Pl.KpDC = lp[(size_t)PVDER_LPF_KP_DC * N]; Pl.KiDC = lp[(size_t)PVDER_LPF_KI_DC * N];
+        Pl.KpQ = lp[(size_t)PVDER_LPF_KP_Q * N];   Pl.KiQ = lp[(size_t)PVDER_LPF_KI_Q * N];
+        Pl.pvA = lp[(size_t)PVDER_LPF_PVA * N];    Pl.pvB = lp[(size_t)PVDER_LPF_PVB * N];
+    }
+    const LinSeg sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
+    int row_stop = sg.row;                 // (the inputs in force at tStop: see lin_step_body)
+    if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
+    else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
+    const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
+    // one segment per env step here; anything else, and whatever the guards below find, is the 23-state path's
+    bool leave = (A.force_full != 0 || lin_unbalanced(ys) || sg.seg < A.C.n_sub) && L.run;
+    {
+        v4f Y[3];
+        lin_from_rows<3>(ys, Y);
+        const v2 kpo = mk2(Pl.KpDC, -Pl.KpQ), kio = mk2(Pl.KiDC, -Pl.KiQ);
+        const float irg = G.Lk.ir2_careful;
+        SubPk S;
+        make_sub_pk(Pl, sg.in_vg, sg.in_si, S);
+        LinK4Regs Ak;
+#pragma unroll 1
+        for (int kind = 0; kind < 2; ++kind) {          // 0: quiet env steps; 1: env steps that start at an event row (tick first)
+            const bool mine = L.run && !leave && (sg.at_event ? kind == 1 : kind == 0);
+            if (!__builtin_amdgcn_readfirstlane(__any((int)mine))) continue;
+            lin_load_k4(k4lane + (size_t)kind * kLinK4Floats, lane, Ak);
+            if (kind == 1) {
+                LinMatRegs At;
+                lin_load_mat(G.Lk.lcoef, lane, At);
+                const PkConst K = make_pkconst(Pl);
+                v2 yp[6], F[6];
+                float m2a, ir2a;
+                lin_pairs(Y, yp);
+                bal_f<3>(Pl, K, S, yp, L.qref, L.vdcref, kpo, kio, F, m2a, ir2a);
+                v4f acc[3] = {Y[0], Y[1], Y[2]};
+                lin_mfma1(At, F, acc);
+                const float pk2 = lin_tick_peak2(Pl, Y, acc, m2a);
+                if (mine) {
+                    leave |= pk2 > A.Ec.sat2_smooth || ir2a > irg;
+                    Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
+                }
+            }
+#pragma unroll 1
+            for (int st = 0; st < 2; ++st) {
+                v4f Yn[3];
+                bool near, cut;
+                const bool trip = lin_k4<3, false>(G, Ak, Y, S, L.qref, L.vdcref, kpo, kio, irg, 1.f, Yn, near, mine, cut, &Pl);
+                if (mine && !leave) {
+                    leave |= trip || near;
+                    Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
+                }
+            }
+        }
+        if (L.run && !leave) {
+            lin_to_rows<3>(Y, ys);
+            L.ksub += A.C.n_sub;
+            L.steps += 1;
+        }
+    }
+    if (leave) { L.run = false; L.live = false; }
+    epilogue<float, 3>(Pl, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats, A.n_env, A.stats_fresh, true, vg_stop,
+                       si_stop, lane_par);
+    if (__syncthreads_or((int)leave)) {
+        typedef __attribute__((address_space(4))) const char *KernargBytes;
+        KernargPtr kb = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr());
+        asm volatile("" : "+s"(kb));
+        etdrk4_full_tail<true>(*(const EtdArgs *)kb, leave, nullptr, 0, lane_par, 0);
+    }
+}
+
 constexpr int kOneWavePerSimdEnvs = 65536;       // 256 CUs x 4 SIMDs x 64 lanes (MI355X)
 
 // =============================================================================================
@@ -4068,7 +4162,8 @@ struct pvder_plan {
     StepK<double> Cd;
     Lin64K l64;                      // etdlin64
     ResetK R;
-    const float *lane_par;           // etdrk4: [PVDER_LPF_ROWS][n_env] folded per-lane constants (pvder_plan_lane_params), or NULL
+    const float *lane_par;           // etdrk4 / etdlin: [PVDER_LPF_ROWS][n_env] folded per-lane constants (pvder_plan_lane_params), or NULL
+    const float *k4lane = nullptr;   // etdlin: the two Krogstad blocks of step_etdlin_lane_kernel (pvder_lin_coef.k4 & 2), or NULL
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
@@ -4159,7 +4254,10 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         for (int k = 0; k < 18; ++k) K.seqE[k] = lin->seq_prop[k];
         // the Krogstad block of the quiet env step sits behind the sets (pvder_lin_coef.k4; PVDER_NO_K4=1: A/B runs without it)
         static const bool no_k4 = []() { const char *v = getenv("PVDER_NO_K4"); return v && v[0] == '1'; }();
-        K.k4coef = (lin->k4 != 0 && !no_k4) ? lin->sets + pvder::kLinMatFloats + (size_t)(lin->n_sets - 1) * pvder::kLinSetFloats : nullptr;
+        K.k4coef = ((lin->k4 & 1) != 0 && !no_k4) ? lin->sets + pvder::kLinMatFloats + (size_t)(lin->n_sets - 1) * pvder::kLinSetFloats : nullptr;
+        // ... and behind it the two blocks of the per-lane parameter path (half a quiet env step, half of what a tick leaves)
+        p.k4lane = ((lin->k4 & 3) == 3 && p.ph == 3)
+                       ? lin->sets + pvder::kLinMatFloats + (size_t)(lin->n_sets - 1) * pvder::kLinSetFloats + pvder::kLinK4Floats : nullptr;
     }
     return 0;
 }
@@ -4228,7 +4326,9 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
             const int hint = (capturing && !hint_in_graphs) ? -1 : hint_word(p);
-            if (p.ph == 3 && n_env <= kOneWavePerSimdEnvs && !no_w1)
+            if (p.ph == 3 && p.lane_par)
+                hipLaunchKernelGGL(step_etdlin_lane_kernel, grid, block, 0, st, G, p.lane_par, p.k4lane);
+            else if (p.ph == 3 && n_env <= kOneWavePerSimdEnvs && !no_w1)
                 hipLaunchKernelGGL(step_etdlin_kernel_w1<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, G);
             else if (p.ph == 3)
                 hipLaunchKernelGGL(step_etdlin_kernel<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, G);
@@ -4461,7 +4561,9 @@ int pvder_fold_lane_params(const double *par, const double *lane, int n_env, flo
 
 int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded) {
     if (!plan) return PVDER_EINVAL;
-    if (lane_folded && (plan->integrator != PVDER_INT_ETDRK4 || plan->ph != 3)) return PVDER_EINVAL;
+    if (lane_folded && plan->ph != 3) return PVDER_EINVAL;
+    if (lane_folded && plan->integrator == PVDER_INT_ETDLIN && !plan->k4lane) return PVDER_EINVAL;
+    if (lane_folded && plan->integrator != PVDER_INT_ETDRK4 && plan->integrator != PVDER_INT_ETDLIN) return PVDER_EINVAL;
     plan->lane_par = lane_folded;
     return 0;
 }
@@ -4596,7 +4698,7 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
                              const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
                              int32_t *progress, void *stream) {
     if (!plan || n_steps < 0 || !actions || !out || !progress || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
-    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3) return PVDER_EINVAL;
+    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->lane_par) return PVDER_EINVAL;     // (per-lane sets: pvder_plan_rollout)
     if (n_steps == 0) return 0;
     const int n_env = plan->n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
@@ -4634,7 +4736,7 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
                                    void *stream) {
     if (!plan || n_steps < 0 || !out || !progress || !fstate || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
     if (!cfg || !q_table || !state || !action || !alive || !ep_reward) return PVDER_EINVAL;
-    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->R.enabled) return PVDER_EINVAL;   // (episodes are the caller's)
+    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->R.enabled || plan->lane_par) return PVDER_EINVAL;   // (episodes are the caller's)
     if (cfg->n_act < 1 || cfg->n_act > 5 || cfg->first || !cfg->choose) return PVDER_EINVAL;
     if (cfg->policy == PVDER_POLICY_QNET) {
         if (cfg->hidden < 1 || cfg->hidden > pvder_agent::kQnetMaxHidden) return PVDER_EINVAL;

@@ -286,7 +286,10 @@ typedef struct pvder_lin_coef {
                               * (etd_linear.py::k4_f_matrices).  An env step that is one segment and does not start at an event row
                               * change (a new action at most: no input jump the stiff loop rings from) is then taken as that one
                               * step, without tick: 4 right-hand sides instead of 7 at unchanged accuracy (tools/scheme_proto.py).
-                              * 0: every segment by tick + ETD3RK steps (the schedule table) */
+                              * 0: every segment by tick + ETD3RK steps (the schedule table).
+                              * Bit 1 (ABI 16, with bit 0: k4 = 3): TWO more blocks of the same kind follow -- Krogstad steps of
+                              * n_sub / 120 s and of (n_sub / 60 - len_ticks[0] ticks) / 2 -- for pvder_plan_lane_params on an etdlin
+                              * plan (etd_linear.py::pack_block(lane_k4=True)) */
 } pvder_lin_coef;
 int pvder_lin_set_floats(void);
 int pvder_lin_max_sets(void);
@@ -358,7 +361,12 @@ int pvder_fold_lane_params(const double *par, const double *lane, int n_env, flo
  * 32 768 envs with an env's three phases on three lanes (step_etdrk4_lane3_kernel: 45-65 us per batched step), larger ones
  * with a lane per env (step_etdrk4_lane_kernel: 72 us at 65 536 envs); same scheme, results within fp32 rounding of each other.  The same-step auto-reset restarts an env from ITS OWN steady state (rows PVDER_LPF_IA_RE ..), and so does
  * pvder_reset_masked_lanes_f32; the observation's Ppv and the reward use the env's own constants.
- * PVDER_EINVAL unless the plan is a three-phase PVDER_INT_ETDRK4 plan. */
+ * PVDER_EINVAL unless the plan is a three-phase PVDER_INT_ETDRK4 plan -- or (ABI 16) a three-phase PVDER_INT_ETDLIN plan whose
+ * coefficient block carries the two lane blocks (pvder_lin_coef.k4 = 3): the batch then stays on the matrix-core path, the
+ * exponential operator the GROUP's (one shared coefficient block), each env's own constants in the right-hand side alone and two
+ * Krogstad steps per env step (step_etdlin_lane_kernel: 6e-5 of the converged per-set bridge on the 64-set golden in fp64,
+ * tools/lane_etdlin_proto.py; ~12 us per batched step at 65 536 distinct sets); an env off balance, near a limit or with an event row
+ * change inside its env step takes the 23-state lane path in the same launch.  Fused rollouts refuse such a plan. */
 int pvder_plan_lane_params(pvder_plan *plan, const float *lane_folded);
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream);

@@ -158,10 +158,94 @@ def test_lane_params_through_episode_ends_with_auto_reset(gpu_device, N):
 
 def test_lane_params_are_refused_where_they_cannot_apply(gpu_device):
     with pytest.raises(ValueError):
-        make_vec(8, gpu_device, lane_params={"Np": np.full(8, 10.0)})                      # the default integrator: per-set tables
+        make_vec(8, gpu_device, integrator="rk4", lane_params={"Np": np.full(8, 10.0)})    # classic RK4: one parameter set per launch
+    with pytest.raises(ValueError):
+        make_vec(8, gpu_device, model_type="model_1", lane_params={"Np": np.full(8, 10.0)})   # the single-phase model
     with pytest.raises(ValueError):
         make_vec(8, gpu_device, integrator="etdrk4", lane_params={"Rf_actual": np.full(8, 0.002)})   # inside the operator
     with pytest.raises(ValueError):
         make_vec(8, gpu_device, integrator="etdrk4", lane_params={"Np": np.full(7, 10.0)})
     with pytest.raises(ValueError):
         make_vec(8, gpu_device, integrator="etdrk4", lane_params={"C_actual": np.zeros(8)})  # pvder_fold_lane_params: EINVAL
+
+
+# ---- round 5: the same override on the ETDLIN path (the default integrator): the group's operator, the env's own constants in f ----
+def test_64_distinct_parameter_sets_on_the_matrix_core_path_vs_the_bridge(gpu_device):
+    """pvder_plan_lane_params on an etdlin plan (ABI 16, step_etdlin_lane_kernel): the exponential operator stays the GROUP's (one
+    coefficient block), each env's own 1/C, outer PI gains and PV array enter the right-hand side alone, two Krogstad steps per env
+    step.  Same golden, same bars as the ETDRK4 lane kernels (worst env step < 1e-4, trajectory < 3e-5, discrete rewards exact; fp64
+    prototype 5.9e-5 / 2.0e-5: tools/lane_etdlin_proto.py) -- at a sixth of their cost (bench.py `lane_params`)."""
+    import bridge_cases
+    name = "lane_params"
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    sets = bridge_cases.lane_param_sets(name)
+    env = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdlin",
+                   lane_params=sets)
+    assert env.integrator == "etdlin"
+    obs0 = env.reset().cpu().numpy().astype(np.float64)
+    assert np.abs(obs0[:, :10] - g["obs_reset"][:, :10]).max() < 1e-6          # every env at ITS OWN steady state
+    assert np.array_equal(env.ev_vg.cpu().numpy(), vg.astype(np.float32)) and np.array_equal(env.ev_si.cpu().numpy(), si.astype(np.float32))
+    got = _replay(env, acts, gpu_device)
+    want = g["obs"]
+    per_step = rel_l2(got[:, :, :10], want[:, :, :10], axis=2)
+    traj = rel_l2(got[:, :, :10].transpose(1, 0, 2).reshape(c["N"], -1), want[:, :, :10].transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
+    assert per_step.max() < 1e-4, (np.unravel_index(per_step.argmax(), per_step.shape), per_step.max())
+    assert traj.max() < 3e-5, traj.max()
+    assert np.array_equal(got[:, :, 11], g["reward"])
+    # the sets matter here too, and the two lane paths agree with each other far inside their distance to a batch without sets
+    plain = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdlin")
+    plain.reset()
+    assert rel_l2(_replay(plain, acts, gpu_device)[:, :, :10], want[:, :, :10], axis=2).max() > 1e-2
+    other = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4", lane_params=sets)
+    other.reset()
+    assert rel_l2(_replay(other, acts, gpu_device)[:, :, :10], got[:, :, :10], axis=2).max() < 1.5e-4
+    # a lane's result does not depend on where it sits: the batch tiled 40 x (2 560 envs), every copy bit for bit
+    reps = 40
+    big = make_vec(c["N"] * reps, gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdlin",
+                   lane_params={k: np.tile(v, reps) for k, v in sets.items()})
+    big.reset()
+    big.set_event_tables(torch.from_numpy(np.tile(vg.astype(np.float32), (1, reps))).to(gpu_device),
+                         torch.from_numpy(np.tile(si.astype(np.float32), (1, reps))).to(gpu_device))
+    big.reset()
+    gb = _replay(big, np.tile(acts[:12], (1, reps)), gpu_device)[:, :, :10].reshape(12, reps, c["N"], 10)
+    assert np.array_equal(gb, np.broadcast_to(gb[:, :1], gb.shape)) and np.array_equal(gb[:, 0], got[:12, :, :10])
+    # fused rollouts refuse a plan with per-lane sets (the per-step launches carry them)
+    with pytest.raises(Exception):
+        env.rollout(torch.zeros((4, c["N"]), dtype=torch.uint8, device=gpu_device), fused=True)
+
+
+def test_lane_sets_on_the_matrix_core_path_through_limits_and_episode_ends(gpu_device):
+    """... and what the lane kernel does NOT integrate itself -- envs off balance, at the current limit (Q_ref pushed to it), with a
+    sagging DC link -- goes to the 23-state lane path in the same launch: against the ETDRK4 lane kernel on the same batch to the
+    two paths' tolerance for the envs that stay, and to 2e-5 / bit-comparable rewards for the envs both send down the 23-state path;
+    same-step auto-reset through two episode ends, every env restarts twice at its own steady state, statistics = plain sums."""
+    N = 1000
+    rng = np.random.default_rng(5)
+    lp = {"Np": rng.integers(10, 12, N).astype(np.float64), "C_actual": 300e-6 * rng.uniform(0.8, 1.3, N),
+          "Kp_Q": 0.2 * rng.uniform(0.8, 1.25, N)}
+    runs = {}
+    for integ in ("etdlin", "etdrk4"):
+        env = make_vec(N, gpu_device, seed=7, auto_reset=True, integrator=integ, lane_params=lp, events_spec=None, max_sim_time=10.0)
+        env.reset()
+        env.fstate[6, 1::50] *= 1.02                      # off balance
+        env.fstate[env.ns, 7::40] = 1.0                   # Q_ref 1 pu: the current limit within a few env steps
+        gen = torch.Generator(device=gpu_device); gen.manual_seed(3)
+        rows, done_count = [], torch.zeros(N, device=gpu_device)
+        for t in range(85):
+            a = torch.randint(0, 5, (N,), generator=gen, device=gpu_device, dtype=torch.uint8)
+            obs, rew, done, _ = env.step(a)
+            done_count += done.float()
+            st = env.step_stats()
+            assert st["n_nonfinite"] == 0 and st["n_done"] == int(done.sum().item())
+            assert abs(st["reward_sum"] - float(rew.sum().item())) < 1e-3 * max(1.0, abs(float(rew.sum().item())))
+            rows.append(obs.cpu().numpy().astype(np.float64))
+        assert bool((done_count == 2).all()) and bool(torch.isfinite(env.fstate).all())
+        runs[integ] = np.stack(rows)
+    d = rel_l2(runs["etdlin"][:, :, :10], runs["etdrk4"][:, :, :10], axis=2)
+    hard = np.zeros(N, dtype=bool)
+    hard[1::50] = True; hard[7::40] = True               # (a 1 pu Q_ref step, a 2 % imbalance: two integrators' own errors meet here)
+    assert d[:, ~hard].max() < 2e-4, (np.unravel_index(d.argmax(), d.shape), d[:, ~hard].max())
+    assert d[:, hard].max() < 2e-3, d[:, hard].max()
+    assert np.median(d) < 3e-5

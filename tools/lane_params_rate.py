@@ -15,18 +15,19 @@ dev = torch.device("cuda:0")
 name = "lane_params"
 g, c = bridge_cases.load(name), bridge_cases.CASES[name]
 vg, si, acts, cc = bridge_cases.case_inputs(name)
-env = PVDERVec(c["N"], device=dev, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator="etdrk4",
-               lane_params=bridge_cases.lane_param_sets(name))
-env.reset()
-got = []
-for t in range(c["steps"]):
-    obs, rew, done, _ = env.step(torch.as_tensor(acts[t], dtype=torch.uint8, device=dev))
-    got.append(obs.cpu().numpy().astype(np.float64))
-got, want = np.stack(got)[:, :, :10], g["obs"][:, :, :10]
-per = rel_l2(got, want, axis=2)
-traj = rel_l2(got.transpose(1, 0, 2).reshape(c["N"], -1), want.transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
-print("64 parameter sets in one launch vs the bridge (40 steps, random actions): worst env step %.2e (median over envs of the worst %.2e), trajectory max %.2e"
-      % (per.max(), np.median(per.max(axis=0)), traj.max()))
+for integ in ("etdrk4", "etdlin"):
+    env = PVDERVec(c["N"], device=dev, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], integrator=integ,
+                   lane_params=bridge_cases.lane_param_sets(name))
+    env.reset()
+    got = []
+    for t in range(c["steps"]):
+        obs, rew, done, _ = env.step(torch.as_tensor(acts[t], dtype=torch.uint8, device=dev))
+        got.append(obs.cpu().numpy().astype(np.float64))
+    got, want = np.stack(got)[:, :, :10], g["obs"][:, :, :10]
+    per = rel_l2(got, want, axis=2)
+    traj = rel_l2(got.transpose(1, 0, 2).reshape(c["N"], -1), want.transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
+    print("%s: 64 parameter sets in one launch vs the bridge (40 steps, random actions): worst env step %.2e (median over envs of the worst %.2e), trajectory max %.2e"
+          % (integ, per.max(), np.median(per.max(axis=0)), traj.max()))
 N = 65536
 rng = np.random.default_rng(1)
 base = der_model.DER_CONFIG["50"]
@@ -35,7 +36,8 @@ sets = {"C_actual": base["C_actual"] * rng.uniform(0.7, 1.4, N), "Kp_DC": base["
         "Ki_Q": base["Ki_Q"] * rng.uniform(0.8, 1.25, N), "Np": rng.integers(10, 12, N).astype(np.float64),
         "Sinsol_scale": rng.uniform(0.9, 1.0, N)}
 a = torch.randint(0, 5, (40, N), device=dev, dtype=torch.uint8)
-for label, kw in (("etdrk4 + lane parameters (65 536 distinct sets)", dict(integrator="etdrk4", lane_params=sets)),
+for label, kw in (("etdlin + lane parameters (65 536 distinct sets)", dict(integrator="etdlin", lane_params=sets)),
+                  ("etdrk4 + lane parameters (65 536 distinct sets)", dict(integrator="etdrk4", lane_params=sets)),
                   ("etdrk4, one set (balanced fast path)", dict(integrator="etdrk4")), ("etdlin, one set (default)", dict())):
     env = PVDERVec(N, device=dev, seed=2, events_spec=both_events_spec(), auto_reset=True, **kw)
     env.reset()
