@@ -430,3 +430,29 @@ def test_sequence_propagator_vs_the_bridge_without_actions(lin50):
                 assert abs(want[1]) > 1e-4 and abs(got[1] - want[1]) < 1e-6 * abs(want[1]), (t, e, k)
                 assert abs(got[0] - want[0]) < 1e-6 * abs(want[1]) and abs(got[2] - want[2]) < 1e-6 * abs(want[1])
         prev = now
+
+
+def test_lane_blocks_follow_the_krogstad_block(lin50):
+    """pack_block(lane_k4=True) (pvder_lin_coef.k4 = 3; csrc step_etdlin_lane_kernel): behind the Krogstad block of the whole quiet
+    env step two more of the same kind -- half of it, and half of what the tick leaves of an env step that starts at an event row --
+    and nothing else moves; two half steps of the lane blocks compose to the whole step on a linear problem (f = L y: exact)."""
+    par, c, L, ystar = lin50
+    lens = el.choose_sets(15, 32, 60, 60, 38, 2400)
+    h = el.quiet_step_length(15)
+    plain = el.pack_block(L, 32, lens, h)
+    lane = el.pack_block(L, 32, lens, h, lane_k4=True)
+    K4 = el.N_K4_MATS * el.MAT_FLOATS
+    assert lane.size == plain.size + 2 * K4 and np.array_equal(lane[:plain.size], plain)
+    tick = lens[0] / (60.0 * 32)
+    for blk, hh in ((lane[plain.size:plain.size + K4], 0.5 * h), (lane[plain.size + K4:], 0.5 * (h - tick))):
+        want = np.concatenate([el.pack_matrix(M) for M in el.k4_f_matrices(L, hh)])
+        assert np.array_equal(blk, want)
+    rng = np.random.default_rng(0)
+    y = ystar + 1e-3 * rng.standard_normal(11)
+    def lin_step(mats, y):          # Krogstad step in f-form on f(y) = L y
+        F1 = L @ y; u2 = y + mats[0] @ F1; F2 = L @ u2; u3 = y + mats[1] @ F1 + mats[2] @ F2; F3 = L @ u3
+        u4 = y + mats[3] @ F1 + mats[4] @ F2 + mats[5] @ F3; F4 = L @ u4
+        return y + mats[6] @ F1 + mats[7] @ F2 + mats[8] @ F3 + mats[9] @ F4
+    half, whole = el.k4_f_matrices(L, 0.5 * h), el.k4_f_matrices(L, h)
+    a, b = lin_step(half, lin_step(half, y)), lin_step(whole, y)
+    assert np.abs(a - b).max() < 1e-9 * np.abs(b).max()
