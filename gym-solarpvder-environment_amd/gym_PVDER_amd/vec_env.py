@@ -501,6 +501,9 @@ class PVDERVec(EnvSpecMixin):
         k4_h = etd_linear.quiet_step_length(cfg.n_sub)
         # ... and, with per-env parameter sets installed, the two blocks of the lane path behind it (pvder_lin_coef.k4 = 3)
         lane_k4 = self.__dict__.get("_lane_folded") is not None and k4_h > 0.0 and self.phases == 3
+        if self.__dict__.get("_lane_folded") is not None and not lane_k4:
+            raise ValueError("lane_params on the etdlin path take the env step as two Krogstad steps: n_sim_time_steps_per_env_step "
+                             "<= %d (three-phase model); use integrator='etdrk4' beyond" % int(etd_linear.K4_MAX_H * 60))
         key = (self.der_id if not (self.der_config or self.model_options) else (self.der_id, self.par.tobytes()), cfg.micro, cfg.n_sub, tuple(lens),
                lane_k4)
         if getattr(self, "_lin_key", None) != key:
