@@ -813,15 +813,13 @@ def run_rank(args):
             drain()
         r1.record()
         host = time.perf_counter() - t0        # host side of the loop (launches are asynchronous)
-        # the host polls the closing event before it calls synchronize(): the blocking wait inside
-        # hipDeviceSynchronize wakes the thread tens of microseconds after the GPU is done -- nothing next to
-        # 4000 steps, a quarter of a 20-step window (the synchronize below then returns at once)
-        while not r1.query():
-            pass
+        # (rounds 2-4 polled the closing event ahead of synchronize(); on ROCm 7.2 the blocking wait returns 5 us EARLIER than
+        #  the first successful query: tools/window_overhead.py -- 20-step graph 190 us with the poll, 185 without, 177 without
+        #  the event pair, which stays: it is the roofline's region measurement)
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         if dist is not None:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
