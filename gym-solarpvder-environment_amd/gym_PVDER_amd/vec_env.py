@@ -285,6 +285,22 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("lane_params need integrator='etdlin' or 'etdrk4' and the three-phase model (for whole parameter "
                              "GROUPS with their own operators see param_groups.PVDERVecGroups)")
         rows = np.ascontiguousarray(der_model.lane_param_rows(lane_params, self.num_envs))
+        if self.integrator == "etdlin":
+            # the matrix-core path keeps the GROUP's exponential operator: two Krogstad steps per env step hold 1e-4 of the per-set
+            # converged solution while the sets stay within C x 0.7-1.4 and outer PI gains x 0.8-1.25 of the group's (validated:
+            # tests, profiles/r05_lane_etdlin_envelope.txt: 4.5e-4 at C x 0.5-2 / gains x 0.67-1.5, 2.6e-3 at x 0.33-3 / 0.5-2)
+            base = der_model.lane_param_rows({k: np.full(self.num_envs, float(self._der_cfg_value(k))) for k in
+                                              ("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q")}, self.num_envs)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                ratio = rows[:5] / base[:5]
+            ratio = np.where(np.isfinite(ratio), ratio, 1.0)             # (NaN / a missing key: the group's value)
+            lo, hi = ratio.min(axis=1), ratio.max(axis=1)
+            wide = [k for i, k in enumerate(("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q"))
+                    if np.isfinite(lo[i]) and (lo[i] < (0.7 if i == 0 else 0.8) - 1e-9 or hi[i] > (1.4 if i == 0 else 1.25) + 1e-9)]
+            if wide:
+                logger.warning("lane_params %s reach beyond the spread the etdlin lane path is validated for (C x 0.7-1.4, gains x 0.8-1.25 "
+                               "of the group's value: < 1e-4 of the per-set converged solution; 4.5e-4 at twice that spread) -- "
+                               "integrator='etdrk4' holds its 3e-5 at any spread", wide)
         folded = np.empty((_native.LPF_ROWS, self.num_envs), dtype=np.float32)
         _native.check(self._lib.pvder_fold_lane_params(self._par_c, rows.ctypes.data, self.num_envs, folded.ctypes.data),
                       "pvder_fold_lane_params")
@@ -536,6 +552,10 @@ class PVDERVec(EnvSpecMixin):
         return lc
 
     est_guard = etd_linear.EST_GUARD
+
+    def _der_cfg_value(self, key: str) -> float:
+        """The group's value of a config_der.json key (with this env's der_config overrides)."""
+        return float(der_model.der_config(self.der_id, self.der_config or None)[key])
 
     def _lin64_coef(self, cfg) -> _native.LinCoef:
         """``struct pvder_lin_coef`` of the etdlin64 path: the fp64 f-form matrices of the tick and of the dyadic menu

@@ -249,3 +249,21 @@ def test_lane_sets_on_the_matrix_core_path_through_limits_and_episode_ends(gpu_d
     assert d[:, ~hard].max() < 2e-4, (np.unravel_index(d.argmax(), d.shape), d[:, ~hard].max())
     assert d[:, hard].max() < 2e-3, d[:, hard].max()
     assert np.median(d) < 3e-5
+
+
+def test_lane_sets_beyond_the_validated_spread_are_named(gpu_device, caplog):
+    """The etdlin lane path keeps the group's exponential operator: its 1e-4 is validated for C x 0.7-1.4 and outer PI gains
+    x 0.8-1.25 (profiles/r05_lane_etdlin_envelope.txt); sets beyond that still step -- with a warning that says which keys and
+    what holds at any spread."""
+    import logging
+    N = 8
+    base_c = 300e-6
+    with caplog.at_level(logging.WARNING):
+        make_vec(N, gpu_device, lane_params={"C_actual": base_c * np.linspace(0.8, 1.3, N), "Kp_Q": 0.2 * np.linspace(0.8, 1.25, N)})
+    assert "validated" not in caplog.text
+    with caplog.at_level(logging.WARNING):
+        env = make_vec(N, gpu_device, lane_params={"C_actual": base_c * np.linspace(0.5, 2.0, N), "Ki_DC": -10.0 * np.linspace(0.9, 1.1, N)})
+    assert "C_actual" in caplog.text and "Ki_DC" not in caplog.text.split("lane_params")[-1].split("reach")[0] and "etdrk4" in caplog.text
+    env.reset()
+    env.step(torch.zeros(N, dtype=torch.uint8, device=gpu_device))
+    assert env.step_stats()["n_nonfinite"] == 0
