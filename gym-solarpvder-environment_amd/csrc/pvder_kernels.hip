@@ -2989,12 +2989,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
 // outer PI gains, the PV array) -- and L, the GROUP's Jacobian at its operating point, stays the one shared coefficient block.  What
 // the mismatch costs is accuracy per step (the outer loops' part of N is no longer small): TWO Krogstad steps per env step instead
 // of one hold 6e-5 of the converged per-set bridge on the 64-set golden (C x 0.7-1.4, gains x 0.8-1.25, 10 / 11 strings; one step:
-// 2.7e-4, the env's own operator: 1.7e-5 -- tools/lane_etdlin_proto.py).  k4lane: two Krogstad blocks behind the plan's own
-// (pvder_lin_coef.k4 & 2): half a quiet env step, half of what a tick leaves of an env step that starts at an event row.
+// 2.7e-4, the env's own operator: 1.7e-5 -- tools/lane_etdlin_proto.py); n_k4 = 6 holds 5e-5 at C x 0.5-2 / gains x 0.67-1.5, 8
+// hold 8e-5 at C x 0.33-3 / gains x 0.5-2 (tools/lane_etdlin_envelope.py).  k4lane: two Krogstad blocks behind the plan's own
+// (pvder_lin_coef.k4 & 2): a quiet env step / n_k4, and what a tick leaves of an env step that starts at an event row / n_k4.
 // An env that needs more than that -- off balance, near the current or the duty-cycle limit, an event row change INSIDE its env
 // step -- takes the 23-state lane path in the same launch (etdrk4_full_tail<LP>), as the lockstep kernels do.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_lane_kernel(const LinArgs G, const float *__restrict__ lane_par,
-                                                                                                          const float *__restrict__ k4lane) {
+                                                                                                          const float *__restrict__ k4lane, int n_k4) {
     using namespace pvder;
     const EtdArgs &A = G.A;
     constexpr int NS = 23;
@@ -3048,7 +3049,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
                 }
             }
 #pragma unroll 1
-            for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < n_k4; ++st) {
                 v4f Yn[3];
                 bool near, cut;
                 const bool trip = lin_k4<3, false>(G, Ak, Y, S, L.qref, L.vdcref, kpo, kio, irg, 1.f, Yn, near, mine, cut, &Pl);
@@ -4164,6 +4165,7 @@ struct pvder_plan {
     ResetK R;
     const float *lane_par;           // etdrk4 / etdlin: [PVDER_LPF_ROWS][n_env] folded per-lane constants (pvder_plan_lane_params), or NULL
     const float *k4lane = nullptr;   // etdlin: the two Krogstad blocks of step_etdlin_lane_kernel (pvder_lin_coef.k4 & 2), or NULL
+    int lane_steps = 2;              // ... and the Krogstad steps per env step they were folded for (pvder_lin_coef.k4 bits 8-15; 0 = 2)
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
@@ -4258,6 +4260,9 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         // ... and behind it the two blocks of the per-lane parameter path (half a quiet env step, half of what a tick leaves)
         p.k4lane = ((lin->k4 & 3) == 3 && p.ph == 3)
                        ? lin->sets + pvder::kLinMatFloats + (size_t)(lin->n_sets - 1) * pvder::kLinSetFloats + pvder::kLinK4Floats : nullptr;
+        p.lane_steps = (lin->k4 >> 8) & 0xff;
+        if (p.lane_steps == 0) p.lane_steps = 2;
+        if (p.k4lane && p.lane_steps > 16) return PVDER_EINVAL;
     }
     return 0;
 }
@@ -4327,7 +4332,7 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
             const int hint = (capturing && !hint_in_graphs) ? -1 : hint_word(p);
             if (p.ph == 3 && p.lane_par)
-                hipLaunchKernelGGL(step_etdlin_lane_kernel, grid, block, 0, st, G, p.lane_par, p.k4lane);
+                hipLaunchKernelGGL(step_etdlin_lane_kernel, grid, block, 0, st, G, p.lane_par, p.k4lane, p.lane_steps);
             else if (p.ph == 3 && n_env <= kOneWavePerSimdEnvs && !no_w1)
                 hipLaunchKernelGGL(step_etdlin_kernel_w1<3>, grid, block, 0, st, A.fstate, A.istate, A.action, G.Lk.lcoef, n_env, hint, G.Lk.k4coef, G);
             else if (p.ph == 3)

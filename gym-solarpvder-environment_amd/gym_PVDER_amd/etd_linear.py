@@ -471,11 +471,11 @@ def schedule_steps(table: np.ndarray, n_sub: int, row: int) -> List[int]:
             return out
 
 
-def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[float], k4_h: float = 0.0, lane_k4: bool = False) -> np.ndarray:
+def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[float], k4_h: float = 0.0, lane_k4: int = 0) -> np.ndarray:
     """fp32 coefficient block of a launch: the tick matrix  h phi1(hL)  (h = len_ticks[0] ticks), then one
     ETD3RK set per entry of len_ticks[1:], then -- k4_h > 0 -- the ten matrices of a Krogstad step of k4_h seconds, then --
-    lane_k4 -- the two blocks of the per-lane parameter path (csrc step_etdlin_lane_kernel): Krogstad steps of k4_h / 2 and of
-    (k4_h - tick) / 2 seconds (two steps per env step, behind the tick where the env step starts at an event row)."""
+    lane_k4 = K > 0 (True: 2) -- the two blocks of the per-lane parameter path (csrc step_etdlin_lane_kernel): Krogstad steps of
+    k4_h / K and of (k4_h - tick) / K seconds (K steps per env step, behind the tick where the env step starts at an event row)."""
     tick = 1.0 / (60.0 * micro)
     h0 = len_ticks[0] * tick
     parts = [pack_matrix(h0 * phis(L, h0, 1)[1])]
@@ -483,13 +483,14 @@ def pack_block(L: np.ndarray, micro: int, len_ticks: Sequence[float], k4_h: floa
     if k4_h > 0.0:
         parts += [pack_matrix(M) for M in k4_f_matrices(L, k4_h)]
         if lane_k4:
-            parts += [pack_matrix(M) for M in k4_f_matrices(L, 0.5 * k4_h)]
-            parts += [pack_matrix(M) for M in k4_f_matrices(L, 0.5 * (k4_h - h0))]
+            K = 2 if lane_k4 is True else int(lane_k4)
+            parts += [pack_matrix(M) for M in k4_f_matrices(L, k4_h / K)]
+            parts += [pack_matrix(M) for M in k4_f_matrices(L, (k4_h - h0) / K)]
     return np.concatenate(parts)
 
 
 def build_coefficients(par: np.ndarray, der_id: str, micro: int, len_ticks: Sequence[float], k4_h: float = 0.0,
-                       lane_k4: bool = False) -> np.ndarray:
+                       lane_k4: int = 0) -> np.ndarray:
     """fp32 coefficient block [MAT + (n_sets - 1) * SET_FLOATS (+ N_K4_MATS * MAT (+ 2 * N_K4_MATS * MAT))] for the step lengths
     ``len_ticks`` (ticks)."""
     L, _ = jacobian(par, der_id)

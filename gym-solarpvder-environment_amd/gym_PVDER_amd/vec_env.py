@@ -169,8 +169,9 @@ class PVDERVec(EnvSpecMixin):
         ``lane_params``: per-ENV values (domain randomisation) of the parameters outside the exponential operator --
         ``{"C_actual": [N], "Kp_DC": [N], "Ki_DC": [N], "Kp_Q": [N], "Ki_Q": [N], "Np": [N], "Sinsol_scale": [N]}``, any subset,
         NaN = the set's value (three-phase model).  With the default ``integrator="etdlin"`` the batch stays on the matrix-core
-        path: the exponential operator is the set's, each env's own constants enter the right-hand side, two Krogstad steps per env
-        step (include/pvder_hip.h pvder_plan_lane_params, ABI 16; ~12 us per batched step); with ``integrator="etdrk4"`` every env
+        path: the exponential operator is the set's, each env's own constants enter the right-hand side, 2 / 6 / 8 Krogstad steps per
+        env step by the spread of the sets (``lane_steps`` overrides; include/pvder_hip.h pvder_plan_lane_params, ABI 16; 11 / 22 /
+        27 us per batched step); with ``integrator="etdrk4"`` every env
         steps on the 23-state ETDRK4 path with its own constants (45-75 us per batched step).  reset() and
         the same-step auto-reset start every env from ITS OWN steady state (a Newton root per env, folded on the host: the
         reference builds each DER with steadyStateInitialization=True, PVDER_env.py:374-378).
@@ -270,7 +271,7 @@ class PVDERVec(EnvSpecMixin):
             pass
 
     # -- everything a plan folds in: assigning any of these drops the plan (rebuilt at the next step)
-    _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded", "env_reward_spec",
+    _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded", "env_reward_spec", "lane_steps",
                             "est_guard", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
                             "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "env_goal_spec", "integrator",
                             "off_range"))
@@ -286,21 +287,29 @@ class PVDERVec(EnvSpecMixin):
                              "GROUPS with their own operators see param_groups.PVDERVecGroups)")
         rows = np.ascontiguousarray(der_model.lane_param_rows(lane_params, self.num_envs))
         if self.integrator == "etdlin":
-            # the matrix-core path keeps the GROUP's exponential operator: two Krogstad steps per env step hold 1e-4 of the per-set
-            # converged solution while the sets stay within C x 0.7-1.4 and outer PI gains x 0.8-1.25 of the group's (validated:
-            # tests, profiles/r05_lane_etdlin_envelope.txt: 4.5e-4 at C x 0.5-2 / gains x 0.67-1.5, 2.6e-3 at x 0.33-3 / 0.5-2)
+            # The matrix-core path keeps the GROUP's exponential operator and takes K Krogstad steps per env step: how many it needs
+            # for 1e-4 of the per-set converged solution follows the spread of the sets around the group's values
+            # (profiles/r05_lane_etdlin_envelope.txt, fp64 against bridge runs): C x 0.7-1.4 and outer PI gains x 0.8-1.25: K = 2
+            # (5.6e-5); C x 0.5-2 / gains x 0.67-1.5: K = 6 (5.2e-5); C x 0.33-3 / gains x 0.5-2: K = 8 (8.1e-5); beyond: K = 8 and a
+            # warning.  `lane_steps` (attribute, before reset()) overrides the choice.
             base = der_model.lane_param_rows({k: np.full(self.num_envs, float(self._der_cfg_value(k))) for k in
                                               ("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q")}, self.num_envs)
             with np.errstate(invalid="ignore", divide="ignore"):
                 ratio = rows[:5] / base[:5]
-            ratio = np.where(np.isfinite(ratio), ratio, 1.0)             # (NaN / a missing key: the group's value)
-            lo, hi = ratio.min(axis=1), ratio.max(axis=1)
-            wide = [k for i, k in enumerate(("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q"))
-                    if np.isfinite(lo[i]) and (lo[i] < (0.7 if i == 0 else 0.8) - 1e-9 or hi[i] > (1.4 if i == 0 else 1.25) + 1e-9)]
-            if wide:
-                logger.warning("lane_params %s reach beyond the spread the etdlin lane path is validated for (C x 0.7-1.4, gains x 0.8-1.25 "
-                               "of the group's value: < 1e-4 of the per-set converged solution; 4.5e-4 at twice that spread) -- "
-                               "integrator='etdrk4' holds its 3e-5 at any spread", wide)
+            ratio = np.where(np.isfinite(ratio) & (ratio > 0), ratio, 1.0)             # (NaN / a missing key: the group's value)
+            spread = np.maximum(ratio, 1.0 / ratio).max(axis=1)                         # per key: how far the farthest env sits
+            s_c, s_g = float(spread[0]), float(spread[1:].max())
+            if s_c <= 1.0 / 0.7 + 1e-9 and s_g <= 1.25 + 1e-9:
+                steps = 2
+            elif s_c <= 2.0 + 1e-9 and s_g <= 1.5 + 1e-9:
+                steps = 6
+            else:
+                steps = 8
+                if s_c > 3.0 + 1e-9 or s_g > 2.0 + 1e-9:
+                    logger.warning("lane_params reach beyond the spread the etdlin lane path is validated for (C x %.2f, outer PI gains x %.2f "
+                                   "of the group's value; validated to x 3 / x 2: 8e-5 of the per-set converged solution with 8 Krogstad "
+                                   "steps per env step) -- integrator='etdrk4' holds its 3e-5 at any spread", s_c, s_g)
+            object.__setattr__(self, "_lane_steps_auto", steps)
         folded = np.empty((_native.LPF_ROWS, self.num_envs), dtype=np.float32)
         _native.check(self._lib.pvder_fold_lane_params(self._par_c, rows.ctypes.data, self.num_envs, folded.ctypes.data),
                       "pvder_fold_lane_params")
@@ -517,6 +526,10 @@ class PVDERVec(EnvSpecMixin):
         k4_h = etd_linear.quiet_step_length(cfg.n_sub)
         # ... and, with per-env parameter sets installed, the two blocks of the lane path behind it (pvder_lin_coef.k4 = 3)
         lane_k4 = self.__dict__.get("_lane_folded") is not None and k4_h > 0.0 and self.phases == 3
+        if lane_k4:
+            lane_k4 = int(self.__dict__.get("lane_steps") or self.__dict__.get("_lane_steps_auto", 2))
+            if not 1 <= lane_k4 <= 16:
+                raise ValueError("lane_steps must be 1 .. 16")
         if self.__dict__.get("_lane_folded") is not None and not lane_k4:
             raise ValueError("lane_params on the etdlin path take the env step as two Krogstad steps: n_sim_time_steps_per_env_step "
                              "<= %d (three-phase model); use integrator='etdrk4' beyond" % int(etd_linear.K4_MAX_H * 60))
@@ -541,7 +554,7 @@ class PVDERVec(EnvSpecMixin):
         for k, t in enumerate(lens):
             lc.len_ticks[k] = int(math.ceil(t))      # (informational: the careful pass's set may end on a fraction of a tick)
         lc.est_guard = self.est_guard
-        lc.k4 = (3 if lane_k4 else 1) if k4_h > 0.0 else 0
+        lc.k4 = ((3 | (int(lane_k4) << 8)) if lane_k4 else 1) if k4_h > 0.0 else 0
         if self.phases == 3:
             if getattr(self, "_seq_key", None) != key[:3]:       # (a steady state + an eig: cached with the coefficient block)
                 self._seq_E, self._seq_key = etd_linear.seq_propagator(self.par, self.der_id, cfg.n_sub), key[:3]

@@ -287,9 +287,10 @@ typedef struct pvder_lin_coef {
                               * change (a new action at most: no input jump the stiff loop rings from) is then taken as that one
                               * step, without tick: 4 right-hand sides instead of 7 at unchanged accuracy (tools/scheme_proto.py).
                               * 0: every segment by tick + ETD3RK steps (the schedule table).
-                              * Bit 1 (ABI 16, with bit 0: k4 = 3): TWO more blocks of the same kind follow -- Krogstad steps of
-                              * n_sub / 120 s and of (n_sub / 60 - len_ticks[0] ticks) / 2 -- for pvder_plan_lane_params on an etdlin
-                              * plan (etd_linear.py::pack_block(lane_k4=True)) */
+                              * Bit 1 (ABI 16, with bit 0: k4 & 3 = 3): TWO more blocks of the same kind follow -- Krogstad steps of
+                              * (n_sub / 60) / K s and of (n_sub / 60 - len_ticks[0] ticks) / K, K = bits 8-15 of k4 (0: K = 2; at
+                              * most 16) -- for pvder_plan_lane_params on an etdlin plan, which takes K such steps per env step
+                              * (etd_linear.py::pack_block(lane_k4=K)) */
 } pvder_lin_coef;
 int pvder_lin_set_floats(void);
 int pvder_lin_max_sets(void);

@@ -51,6 +51,9 @@ CASES = {
     # state (round 5; the reference builds each DER with steadyStateInitialization=True, PVDER_env.py:374-378).  The bridge
     # integrates each env with a model built from its own config block; obs_reset = its reset observation.
     "lane_params": dict(N=64, seed=21, spec="both", n=15, steps=40, actions=("random", 99), lane_seed=5),
+    # ... twice that spread (round 5: the etdlin lane path picks its number of Krogstad steps per env step by the spread)
+    "lane_params_wide": dict(N=24, seed=21, spec="both", n=15, steps=24, actions=("random", 99), lane_seed=6,
+                             lane_spread=(0.5, 2.0, 0.67, 1.5)),
 }
 
 
@@ -60,8 +63,15 @@ def lane_param_sets(name):
     c = CASES[name]
     rng = np.random.default_rng(c["lane_seed"])
     N, base = c["N"], DER_CONFIG["50"]
-    sets = {k: base[k] * rng.uniform(lo, hi, N) for k, (lo, hi) in
-            (("C_actual", (0.7, 1.4)), ("Kp_DC", (0.8, 1.25)), ("Ki_DC", (0.8, 1.25)), ("Kp_Q", (0.8, 1.25)), ("Ki_Q", (0.8, 1.25)))}
+    if "lane_spread" in c:           # log-uniform: as many envs below the group's value as above
+        clo, chi, glo, ghi = c["lane_spread"]
+        lu = lambda lo, hi: np.exp(rng.uniform(np.log(lo), np.log(hi), N))
+        sets = {"C_actual": base["C_actual"] * lu(clo, chi)}
+        for k in ("Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q"):
+            sets[k] = base[k] * lu(glo, ghi)
+    else:
+        sets = {k: base[k] * rng.uniform(lo, hi, N) for k, (lo, hi) in
+                (("C_actual", (0.7, 1.4)), ("Kp_DC", (0.8, 1.25)), ("Ki_DC", (0.8, 1.25)), ("Kp_Q", (0.8, 1.25)), ("Ki_Q", (0.8, 1.25)))}
     # (10 or 11 strings at 90-100 % insolation: the operating points stay clear of the duty-cycle limit -- |m| = 1.00004 with 9
     #  strings at 80 % --, where the device's switched steps are 1e-2 off: tests/test_gpu_etdlin.py, action 4)
     sets["Np"] = rng.integers(10, 12, N).astype(np.float64)           # 10 or 11 parallel strings (11: the reference's)

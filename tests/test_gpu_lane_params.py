@@ -252,18 +252,48 @@ def test_lane_sets_on_the_matrix_core_path_through_limits_and_episode_ends(gpu_d
 
 
 def test_lane_sets_beyond_the_validated_spread_are_named(gpu_device, caplog):
-    """The etdlin lane path keeps the group's exponential operator: its 1e-4 is validated for C x 0.7-1.4 and outer PI gains
-    x 0.8-1.25 (profiles/r05_lane_etdlin_envelope.txt); sets beyond that still step -- with a warning that says which keys and
-    what holds at any spread."""
+    """The etdlin lane path keeps the group's exponential operator and is validated up to C x 0.33-3 and outer PI gains x 0.5-2
+    (profiles/r05_lane_etdlin_envelope.txt); sets beyond that still step -- with the most Krogstad steps and a warning that says
+    how far they reach and what holds at any spread."""
     import logging
     N = 8
     base_c = 300e-6
     with caplog.at_level(logging.WARNING):
-        make_vec(N, gpu_device, lane_params={"C_actual": base_c * np.linspace(0.8, 1.3, N), "Kp_Q": 0.2 * np.linspace(0.8, 1.25, N)})
-    assert "validated" not in caplog.text
+        env = make_vec(N, gpu_device, lane_params={"C_actual": base_c * np.linspace(0.5, 2.0, N), "Kp_Q": 0.2 * np.linspace(0.8, 1.25, N)})
+    assert "validated" not in caplog.text and env._lane_steps_auto == 6
     with caplog.at_level(logging.WARNING):
-        env = make_vec(N, gpu_device, lane_params={"C_actual": base_c * np.linspace(0.5, 2.0, N), "Ki_DC": -10.0 * np.linspace(0.9, 1.1, N)})
-    assert "C_actual" in caplog.text and "Ki_DC" not in caplog.text.split("lane_params")[-1].split("reach")[0] and "etdrk4" in caplog.text
+        env = make_vec(N, gpu_device, lane_params={"C_actual": base_c * np.linspace(0.2, 1.0, N), "Ki_DC": -10.0 * np.linspace(0.9, 1.1, N)})
+    assert "validated" in caplog.text and "x 5.00" in caplog.text and "etdrk4" in caplog.text and env._lane_steps_auto == 8
     env.reset()
     env.step(torch.zeros(N, dtype=torch.uint8, device=gpu_device))
     assert env.step_stats()["n_nonfinite"] == 0
+
+
+def test_wider_parameter_spreads_take_more_krogstad_steps(gpu_device):
+    """The etdlin lane path picks its number of Krogstad steps per env step from the spread of the sets around the group's values
+    (profiles/r05_lane_etdlin_envelope.txt): 2 inside the first golden's spread, 6 at twice that (C x 0.5-2, outer PI gains
+    x 0.67-1.5; tests/golden/bridge_lane_params_wide.npz: 24 sets, each integrated by the bridge from its own steady state) --
+    where 6 steps hold 1e-4 and 2 steps do not; `lane_steps` overrides the choice."""
+    import bridge_cases
+    narrow = bridge_cases.lane_param_sets("lane_params")
+    env = make_vec(64, gpu_device, lane_params=narrow)
+    assert env._lane_steps_auto == 2
+    name = "lane_params_wide"
+    g = bridge_cases.load(name)
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    sets = bridge_cases.lane_param_sets(name)
+    errs = {}
+    for steps in (None, 2):
+        env = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], lane_params=sets)
+        assert env._lane_steps_auto == 6
+        if steps:
+            env.lane_steps = steps
+        obs0 = env.reset().cpu().numpy().astype(np.float64)
+        assert np.abs(obs0[:, :10] - g["obs_reset"][:, :10]).max() < 1e-6
+        got = _replay(env, acts, gpu_device)
+        errs[steps] = rel_l2(got[:, :, :10], g["obs"][:, :, :10], axis=2).max()
+        if not steps:
+            assert np.array_equal(got[:, :, 11], g["reward"])
+    assert errs[None] < 1e-4, errs
+    assert errs[2] > 1.5 * errs[None] and errs[2] > 1e-4, errs

@@ -104,7 +104,7 @@ if __name__ == "__main__":
         want = {e: o for s, e, o in res if s == spread}
         sets = sets_for(spread)
         row = []
-        for nk in (1, 2, 3, 4):
+        for nk in (1, 2, 3, 4, 6, 8):
             worst = []
             for e in range(NENV):
                 got = lane_run(sets, e, nk)

@@ -37,9 +37,14 @@ sets = {"C_actual": base["C_actual"] * rng.uniform(0.7, 1.4, N), "Kp_DC": base["
         "Sinsol_scale": rng.uniform(0.9, 1.0, N)}
 a = torch.randint(0, 5, (40, N), device=dev, dtype=torch.uint8)
 for label, kw in (("etdlin + lane parameters (65 536 distinct sets)", dict(integrator="etdlin", lane_params=sets)),
+                  ("... 6 Krogstad steps per env step (twice the spread)", dict(integrator="etdlin", lane_params=sets, _lane_steps=6)),
+                  ("... 8 Krogstad steps per env step (three times)", dict(integrator="etdlin", lane_params=sets, _lane_steps=8)),
                   ("etdrk4 + lane parameters (65 536 distinct sets)", dict(integrator="etdrk4", lane_params=sets)),
                   ("etdrk4, one set (balanced fast path)", dict(integrator="etdrk4")), ("etdlin, one set (default)", dict())):
+    steps_override = kw.pop("_lane_steps", None)
     env = PVDERVec(N, device=dev, seed=2, events_spec=both_events_spec(), auto_reset=True, **kw)
+    if steps_override:
+        env.lane_steps = steps_override
     env.reset()
     env.rollout(a, fused=False)
     ts = []
