@@ -55,8 +55,7 @@ FLOP_PER_TICK = 70 + 242
 FLOP_PER_K4 = 4 * 70 + 10 * 242       # (round 4: the quiet env step as ONE Krogstad step: 4 evaluations, 10 products, no tick)
 INSTR_PER_STEP = {"etdrk4": 396}
 DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1}
-KERNEL_NAME = {"etdlin": "step_etdlin_kernel", "etdrk4": "step_etdrk4_bal_kernel", "rk4": "step_rk4_pk_kernel",
-               "rk45": "step_rk45_kernel<double,3>"}
+# (the kernel a leg ran is asked of the plan itself: PVDERVec.kernel_name() -> pvder_plan_kernel_name, ABI 17)
 
 
 def parse(argv=None):
@@ -304,7 +303,7 @@ def classic_rk4_leg(torch, dev, N, n_sub, steps, micro=3750):
     fl = FLOP_PER_STEP["rk4"] * micro * n_sub * N / avg
     return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "micro_steps": micro,
             "h_lambda_max": 2.582 * 4096.0 / micro, "h_lambda_bound": 2.95,
-            "kernel": KERNEL_NAME["rk4"], "kernel_avg_ms": avg * 1e3,
+            "kernel": env.kernel_name(), "kernel_avg_ms": avg * 1e3,
             "valu_frac": fl / VALU_PEAK_F32, "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / avg / HBM_PEAK}
 
 
@@ -413,7 +412,7 @@ def rk45_leg(torch, dev, N, n_sub, steps=2):
     fl = (7 * 300 + 23 * 60) * spe * N / avg if spe else None
     return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "dtype": "f64", "rtol": env.rtol, "atol": env.atol,
             "workload": "BASELINE configs[4]: %d envs, fp64 adaptive RK45, same events and random actions" % N,
-            "kernel": KERNEL_NAME["rk45"], "ms_per_step": 1e3 * el / steps, "kernel_avg_ms": avg * 1e3,
+            "kernel": env.kernel_name(), "ms_per_step": 1e3 * el / steps, "kernel_avg_ms": avg * 1e3,
             "integrator_steps_per_env_step": spe, "valu_f64_frac": finite(fl / VALU_PEAK_F64) if fl else None,
             "hbm_frac": BYTES_PER_ENV_STEP["f64"] * N / avg / HBM_PEAK, "n_nonfinite": env.step_stats()["n_nonfinite"]}
 
@@ -504,7 +503,7 @@ def configs1_leg(torch, dev, steps=400, classic_steps=2):
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     out["etdlin"] = {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "us_per_step": 1e6 * el / steps,
-                     "region_us_per_step": e0.elapsed_time(e1) * 1e3 / steps, "kernel": KERNEL_NAME["etdlin"],
+                     "region_us_per_step": e0.elapsed_time(e1) * 1e3 / steps, "kernel": env.kernel_name(),
                      "n_nonfinite": env.step_stats()["n_nonfinite"], "max_sim_time": env.max_sim_time}
     del env
     rk = PVDERVec(N, device=dev, n_sim_time_steps_per_env_step=n_sub, max_sim_time=40.0, integrator="rk4", micro_steps=3750, seed=2024,
@@ -521,7 +520,7 @@ def configs1_leg(torch, dev, steps=400, classic_steps=2):
     el = time.perf_counter() - t0
     out["classic_rk4"] = {"value": N * classic_steps / el, "unit": "env-steps/s", "steps": classic_steps, "micro_steps": 3750,
                           "us_per_step": 1e6 * el / classic_steps, "region_us_per_step": e0.elapsed_time(e1) * 1e3 / classic_steps,
-                          "kernel": KERNEL_NAME["rk4"], "n_nonfinite": rk.step_stats()["n_nonfinite"],
+                          "kernel": rk.kernel_name(), "n_nonfinite": rk.step_stats()["n_nonfinite"],
                           "note": "4096 envs are 16 workgroups on 256 CUs: a latency figure (the 65 536-env rate is the classic_rk4 key)"}
     return out
 
@@ -554,7 +553,7 @@ def desynchronised_leg(torch, dev, N, n_sub, steps=640, warm=160):
     per = e0.elapsed_time(e1) * 1e-3 / steps
     return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "us_per_step": 1e6 * el / steps,
             "region_us_per_step": per * 1e6, "distinct_clocks_in_the_batch": spread, "episode_steps": ep,
-            "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK, "kernel": KERNEL_NAME["etdlin"],
+            "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK, "kernel": env.kernel_name(),
             "n_nonfinite": env.step_stats()["n_nonfinite"],
             "workload": "%d envs, events on, random actions, auto-reset, episode phases spread over all %d clocks by staggered masked "
                         "resets: waves mix quiet and event lanes, the clock hint misses, a few envs end their episode in every step" % (N, ep)}
@@ -581,7 +580,7 @@ def large_batch_leg(torch, dev, n_sub, N=1 << 20, steps=300, warm=60):
     per = r0.elapsed_time(r1) * 1e-3 / steps
     return {"value": N * steps / el, "unit": "env-steps/s", "envs": N, "steps": steps, "ms_per_step": 1e3 * el / steps,
             "region_ms_per_step": per * 1e3, "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK,
-            "achieved_GBps": BYTES_PER_ENV_STEP["f32"] * N / per / 1e9, "kernel": KERNEL_NAME["etdlin"],
+            "achieved_GBps": BYTES_PER_ENV_STEP["f32"] * N / per / 1e9, "kernel": env.kernel_name(),
             "n_nonfinite": env.step_stats()["n_nonfinite"],
             "note": "one launch per env step, same events / random actions / auto-reset as the headline; NOT the headline (configs[2] is 65 536 envs)"}
 
@@ -865,6 +864,7 @@ def run_rank(args):
             # launch it enqueues -- captured or not -- so each graph carries the clock its replay will find): the first is
             # replayed UNTIMED (K more warm-up steps, reported as config.graph_warm_steps: the first launch of a graph pays
             # for its upload), the second is the timed window
+            env.graph_hints(True)         # (opt in: these two graphs are replayed exactly where they were captured)
             warm_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(warm_graph):
                 env.rollout(actions[args.warmup:args.warmup + args.steps], fused=False)
@@ -874,6 +874,7 @@ def run_rank(args):
             warm_graph.replay()
             torch.cuda.synchronize(dev)
             graph_warm_steps = args.steps
+            env.graph_hints(False)
         except Exception as exc:
             window_graph = None
             warnings.append("HIP-graph capture of the window failed (%r): eager launches" % (exc,))
@@ -1017,7 +1018,7 @@ def run_rank(args):
         flops = fps * steps_per_env_step * N / avg_kern_s if (fps and avg_kern_s) else None
         if flops and args.integrator == "etdlin":
             flops = ((1.0 - quiet_frac) * (2.0 * fps + FLOP_PER_TICK) * segs + quiet_frac * FLOP_PER_K4) * N / avg_kern_s
-        traffic, traffic_src = pmc_traffic(KERNEL_NAME[args.integrator], N)
+        traffic, traffic_src = pmc_traffic(env.kernel_name(), N)
         valu_peak = VALU_PEAK_F64 if prec == "f64" else VALU_PEAK_F32
         out = {
             "metric": "env-steps/sec (batched PVDER-v0)", "value": value, "unit": "env-steps/s",
@@ -1050,7 +1051,7 @@ def run_rank(args):
             "roofline": {"bound": "hbm", "achieved": finite(achieved / 1e9) if achieved else None, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": finite(achieved / HBM_PEAK) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": KERNEL_NAME[args.integrator],
+                         "kernel": env.kernel_name(),
                          "kernel_avg_ms": finite(avg_kern_s * 1e3) if avg_kern_s else None,
                          "kernel_avg_source": src, "kernel_samples": len(kern_ms),
                          "region_ms_per_step": finite(region_ms),

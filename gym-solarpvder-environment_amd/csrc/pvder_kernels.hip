@@ -4166,6 +4166,7 @@ struct pvder_plan {
     const float *lane_par;           // etdrk4 / etdlin: [PVDER_LPF_ROWS][n_env] folded per-lane constants (pvder_plan_lane_params), or NULL
     const float *k4lane = nullptr;   // etdlin: the two Krogstad blocks of step_etdlin_lane_kernel (pvder_lin_coef.k4 & 2), or NULL
     int lane_steps = 2;              // ... and the Krogstad steps per env step they were folded for (pvder_lin_coef.k4 bits 8-15; 0 = 2)
+    bool graph_hints = false;        // pvder_plan_graph_hints: a CAPTURED pvder_plan_rollout keeps the clock hints it was captured with
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
@@ -4326,8 +4327,9 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             // The hint is a kernel ARGUMENT: a launch captured into a HIP graph replays the clock and the quiet bit it was
             // captured with while the plan's own hint moves on -- every replay at another clock would fetch the event rows twice
             // and preload the wrong coefficient block (slower than no hint at all; results unaffected).  A captured step is
-            // therefore taken with the hint cleared, and leaves the plan's clock alone.  pvder_plan_rollout keeps its
-            // hints under capture (hint_in_graphs): a K-step rollout graph is replayed where it was captured -- bench.py's window.
+            // therefore taken with the hint cleared, and leaves the plan's clock alone -- per-step launches and rollouts
+            // alike.  A caller that replays its K-step rollout graph exactly where it was captured (bench.py's window)
+            // opts in with pvder_plan_graph_hints (hint_in_graphs).
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
             const int hint = (capturing && !hint_in_graphs) ? -1 : hint_word(p);
@@ -4375,11 +4377,15 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         if (p.integrator == PVDER_INT_ETDLIN64) {
             // the tolerance-match path on the balanced reduction; the RK45 kernel behind it takes the envs it hands over
             const size_t lds = sizeof(double) * ((size_t)(1 + p.l64.levels) * kL64Set + 11 * (size_t)kBlock);
-            static size_t lds_allowed = 0;       // (beyond 64 KB of dynamic LDS the kernel has to be told: once per size)
-            if (lds > lds_allowed) {
+            // beyond 64 KB of dynamic LDS the kernel has to be told -- once per size AND per device (the attribute is the device's:
+            // a process that steps on a second GPU needs it there too; gfx950's 160 KB per CU is what this kernel is sized for)
+            static size_t lds_allowed[64] = {0};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PVDER_EINVAL;
+            if (lds > lds_allowed[dev]) {
                 const hipError_t e = hipFuncSetAttribute((const void *)step_etdlin64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return hip_rc(e);
-                lds_allowed = lds;
+                lds_allowed[dev] = lds;
             }
             hipLaunchKernelGGL(step_etdlin64_kernel, grid, block, lds, st, p.Pd, p.Cd, p.R, p.l64, (double *)fstate, istate, ev_vg,
                                ev_si, action, (double *)out, stats, n_env, fresh);
@@ -4403,6 +4409,30 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
     }
     }
     return hip_rc(hipGetLastError());
+}
+
+
+// The step kernel launch_plan picks for this plan (same conditions, same order) as rocprofv3 prints it.
+const char *plan_kernel_name(const pvder_plan &p) {
+    static const bool no_w1 = []() { const char *v = getenv("PVDER_NO_W1"); return v && v[0] == '1'; }();
+    static const int lane_form = []() { const char *a = getenv("PVDER_LANE1"), *b = getenv("PVDER_LANE3");
+                                        return (a && a[0] == '1') ? 1 : ((b && b[0] == '1') ? 3 : 0); }();
+    static const bool generic = []() { const char *v = getenv("PVDER_RK4_VARIANT"); return v && v[0] == 'g'; }();
+    switch (p.integrator) {
+    case PVDER_INT_ETDLIN:
+        if (p.ph == 3 && p.lane_par) return "step_etdlin_lane_kernel";
+        if (p.ph == 3 && p.n_env <= kOneWavePerSimdEnvs && !no_w1) return "step_etdlin_kernel_w1<3>";
+        return p.ph == 3 ? "step_etdlin_kernel<3>" : "step_etdlin_kernel<1>";
+    case PVDER_INT_ETDRK4:
+        if (p.ph == 3 && p.lane_par)
+            return (lane_form == 1 || (lane_form == 0 && p.n_env > kLane3MaxEnvs)) ? "step_etdrk4_lane_kernel" : "step_etdrk4_lane3_kernel";
+        return p.ph == 3 ? "step_etdrk4_bal_kernel<3>" : "step_etdrk4_bal_kernel<1>";
+    case PVDER_INT_RK4:
+        if (p.ph == 3 && !generic) return "step_rk4_pk_kernel";
+        return p.ph == 3 ? "step_rk4_kernel<float, 3>" : "step_rk4_kernel<float, 1>";
+    case PVDER_INT_ETDLIN64: return "step_etdlin64_kernel";
+    default: return p.ph == 3 ? "step_rk45_kernel<double, 3>" : "step_rk45_kernel<double, 1>";
+    }
 }
 
 }  // namespace
@@ -4588,6 +4618,15 @@ int pvder_plan_hint(pvder_plan *plan, int ksub) {
     return plan->ksub_hint;
 }
 
+int pvder_plan_graph_hints(pvder_plan *plan, int on) {
+    if (!plan) return PVDER_EINVAL;
+    const int was = plan->graph_hints ? 1 : 0;
+    if (on >= 0) plan->graph_hints = on != 0;
+    return was;
+}
+
+const char *pvder_plan_kernel_name(const pvder_plan *plan) { return plan ? plan_kernel_name(*plan) : ""; }
+
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream) {
     if (!plan) return PVDER_EINVAL;
@@ -4636,7 +4675,12 @@ int pvder_plan_step_mirror(const pvder_plan *plan, void *fstate, int32_t *istate
         if (__atomic_load_n((const uint64_t *)word, __ATOMIC_ACQUIRE) == seq) return 0;
         if ((spins & 0x3ffu) == 0x3ffu) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > (double)PVDER_MIRROR_TIMEOUT_MS) break;
+            const double ms = (t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+            if (ms > (double)PVDER_MIRROR_TIMEOUT_MS) break;
+            if (ms > 0.2) {                    // a slow (fp64) step: stop burning the core, look again every 20 us
+                const timespec nap = {0, 20000};
+                nanosleep(&nap, nullptr);
+            }
         }
     }
     e = hipStreamSynchronize(st);             // (a fault in the step kernel surfaces here)
@@ -4687,7 +4731,7 @@ int pvder_plan_rollout(const pvder_plan *plan, void *fstate, int32_t *istate, fl
     for (int k = 0; k < n_steps; ++k) {
         char *blk = (char *)out + (size_t)k * out_step_stride * esz;
         const int rc = launch_plan(*plan, fstate, istate, ev_vg, ev_si, actions + (size_t)k * plan->n_env, blk, hstep, stats, 1,
-                                   stream, k > 0 ? blk - out_step_stride * esz : nullptr, true);
+                                   stream, k > 0 ? blk - out_step_stride * esz : nullptr, plan->graph_hints);
         if (rc) return rc;
     }
     return 0;

@@ -49,15 +49,29 @@ def make_vec(num_envs: int, env_id: str = ENV_ID, **kwargs):
 
 
 def _register_with_gym():
+    """Register ``PVDER-v0`` with every importable gym package, as the reference does at import time
+    (gym_PVDER/__init__.py:1-10).  A package that is not installed is not an error; anything else that goes wrong -- the id
+    already taken because the reference's own ``gym_PVDER`` was imported first, a registry API that moved -- is LOGGED, never
+    swallowed: ``gym.make('PVDER-v0')`` would otherwise fail (or build the other package's env) without a word."""
+    import importlib
+    import logging
+    done = []
     for mod in ("gym", "gymnasium"):
         try:
-            reg = __import__(mod + ".envs.registration", fromlist=["register"])
+            reg = importlib.import_module(mod + ".envs.registration")
+        except ImportError:
+            continue
+        try:
             reg.register(id=ENV_ID, entry_point='gym_PVDER_amd.envs:PVDER', kwargs=dict(DEFAULT_KWARGS),
                          max_episode_steps=MAX_EPISODE_STEPS)
-        except Exception:
-            pass
+            done.append(mod)
+        except Exception as e:                    # noqa: BLE001  (whatever the registry raises: report it)
+            logging.getLogger("gym_PVDER_amd").warning("could not register %s with %s: %s: %s -- %s.make(%r) will not build this "
+                                                       "package's env (gym_PVDER_amd.make does)", ENV_ID, mod, type(e).__name__, e,
+                                                       mod, ENV_ID)
+    return done
 
 
-_register_with_gym()
+REGISTERED_WITH = _register_with_gym()
 
 __all__ = ["make", "make_vec", "spec", "ENV_ID", "DEFAULT_KWARGS"]

@@ -20,7 +20,8 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
-ABI_VERSION = 16
+ETIMEOUT = -10003             # include/pvder_hip.h PVDER_ETIMEOUT: the device never wrote the host mirror's sequence word
+ABI_VERSION = 17
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -30,7 +31,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
            "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch",
-           "pvder_plan_step_mirror"]
+           "pvder_plan_step_mirror", "pvder_plan_graph_hints", "pvder_plan_kernel_name"]
 MIRROR_WORDS = 18       # PVDER_MIRROR_WORDS (pvder_plan_step_mirror): 13 output rows + 4 counters + the sequence word, doubles
 LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
@@ -167,6 +168,10 @@ def lib() -> C.CDLL:
     L.pvder_plan_destroy.argtypes = [vp]
     L.pvder_plan_hint.restype = i32
     L.pvder_plan_hint.argtypes = [vp, i32]
+    L.pvder_plan_graph_hints.restype = i32
+    L.pvder_plan_graph_hints.argtypes = [vp, i32]
+    L.pvder_plan_kernel_name.restype = C.c_char_p
+    L.pvder_plan_kernel_name.argtypes = [vp]
     L.pvder_fold_lane_params.restype = i32
     L.pvder_fold_lane_params.argtypes = [dp, vp, i32, vp]
     L.pvder_plan_lane_params.restype = i32
@@ -201,4 +206,6 @@ def check(rc: int, what: str) -> None:
         return
     if rc == EINVAL:
         raise ValueError("%s: invalid argument (PVDER_EINVAL)" % what)
+    if rc == ETIMEOUT:
+        raise TimeoutError("%s: the device did not deliver the step within the time limit (PVDER_ETIMEOUT)" % what)
     raise RuntimeError("%s: HIP error %d" % (what, -rc))

@@ -28,6 +28,22 @@ from ..vec_env import EnvSpecMixin, PVDERVec, SIM_TIME_STEP, OBSERVED_QUANTITIES
 logger = logging.getLogger("gym_PVDER_amd")
 
 
+def _gym_env_base():
+    """``gym.Env`` (or ``gymnasium.Env``) when such a package is importable (else None) -- the reference is ``class PVDER(gym.Env, Logging,
+    Utilities)`` (PVDER_env.py:39) and wrappers / checkers test ``isinstance(env, gym.Env)`` --."""
+    import importlib
+    for mod in ("gym", "gymnasium"):
+        try:
+            return importlib.import_module(mod).Env
+        except ImportError:
+            continue
+    return None
+
+
+_GymEnv = _gym_env_base()
+_BASES = (EnvSpecMixin,) if _GymEnv is None else (_GymEnv, EnvSpecMixin)
+
+
 class _EventsView:
     """``env.sim.simulation_events`` -- exposes ``_events_spec`` (test_gym_PVDER.py:124)."""
 
@@ -87,7 +103,7 @@ class _SimView:
         self.simulation_events = _EventsView(env)
         self.PV_model = _PVModelView(env)
         self.SOLVER_CONVERGENCE = True
-        self.jacFlag = False        # explicit integrator: no Jacobian (reference sets True, :386)
+        self.jacFlag = True         # :386 (here: the exponential integrators are built on the model's analytic Jacobian)
 
     @property
     def tStart(self):
@@ -98,7 +114,7 @@ class _SimView:
         return self.tStart
 
 
-class PVDER(EnvSpecMixin):
+class PVDER(*_BASES):
     """Old-gym style single env; see module docstring."""
 
     count = 0
@@ -159,8 +175,9 @@ class PVDER(EnvSpecMixin):
         no pageable staging copy, no synchronising read per attribute (round 4: two device copies + a blocking .tolist(): 58 us
         per step)."""
         v = self._vec
-        _native.check(v._lib.pvder_fetch_env(v.out.data_ptr(), v.istate.data_ptr(), 1, 0, 1 if v.fdtype == torch.float64 else 0,
-                                             self._pin_out.data_ptr(), self._pin_ist.data_ptr(), v._stream()), "pvder_fetch_env")
+        with v._device_ctx():       # the C side launches on the CURRENT device (null stream): make that the env's (ADVICE r5 #1)
+            _native.check(v._lib.pvder_fetch_env(v.out.data_ptr(), v.istate.data_ptr(), 1, 0, 1 if v.fdtype == torch.float64 else 0,
+                                                 self._pin_out.data_ptr(), self._pin_ist.data_ptr(), v._stream()), "pvder_fetch_env")
         self._host_out, self._host_ist = self._pin_out.tolist(), self._pin_ist.tolist()
 
     def _step_and_fetch(self, action: int):
@@ -173,22 +190,27 @@ class PVDER(EnvSpecMixin):
             v.step(self._actions[action], return_tensors=False)
             self._read_back()
             return
+        with v._device_ctx():       # plan creation, launch and the host-mirror pointers all resolve against the CURRENT device
+            self._launch_and_fetch(v, action)
+
+    def _launch_and_fetch(self, v, action: int):
         plan = v._plan or v._make_plan()
         snap, nbytes = None, 0
         if v._traj is not None:
             slot = v._traj[v._traj_n % v._traj.shape[0]]
             snap, nbytes = slot.data_ptr(), slot.numel() * slot.element_size()
-            v._traj_n += 1
         if self._use_mirror:
             # no copy packet, no stream wait: one small kernel behind the step writes rows, counters, the trajectory record and a
             # sequence word into pinned host memory; the call returns when the word is there
-            self._mirror_seq += 1
             rc = v._lib.pvder_plan_step_mirror(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v.ev_vg.data_ptr(), v.ev_si.data_ptr(),
                                                self._actions[action].data_ptr(), v.out.data_ptr(),
                                                v.hstep.data_ptr() if v.hstep is not None else None, v.stats.data_ptr(), snap,
-                                               v._state_and_out.data_ptr(), nbytes, self._pin_mirror.data_ptr(), self._mirror_seq,
+                                               v._state_and_out.data_ptr(), nbytes, self._pin_mirror.data_ptr(), self._mirror_seq + 1,
                                                v._stream())
             _native.check(rc, "pvder_plan_step_mirror")
+            self._mirror_seq += 1
+            if snap is not None:
+                v._traj_n += 1          # (only behind a step that ran: a failed call leaves no hole in the trajectory ring)
             m = self._pin_mirror.tolist()
             self._host_out, self._host_ist = m[:13], [int(x) for x in m[13:17]]
             return
@@ -198,6 +220,8 @@ class PVDER(EnvSpecMixin):
                                           v._state_and_out.data_ptr(), nbytes, self._pin_out.data_ptr(), self._pin_ist.data_ptr(),
                                           v._stream())
         _native.check(rc, "pvder_plan_step_fetch")
+        if snap is not None:
+            v._traj_n += 1
         self._host_out, self._host_ist = self._pin_out.tolist(), self._pin_ist.tolist()
 
     @property

@@ -34,6 +34,8 @@ DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1, "etdlin64":
 # ETDRK4 step schedule: a sim time step that starts at an input jump (new action / event) takes a first
 # step of 1/(60*micro) s and one more over the remainder (graded), every other one DEFAULT_MICRO_COARSE
 DEFAULT_MICRO_COARSE = 1
+# etdlin lane path: validated range of (Np / group Np) x Sinsol_scale (profiles/r05_lane_etdlin_envelope.txt)
+LANE_OP_RANGE = (0.8, 1.0)
 
 OBSERVED_QUANTITIES = ['iaR', 'iaI', 'vaR', 'vaI', 'P_PCC', 'Q_PCC', 'Vdc', 'Ppv', 'Vdc_ref', 'Q_ref',
                        'tStart']         # PVDER_env.py:44-49
@@ -276,9 +278,39 @@ class PVDERVec(EnvSpecMixin):
                             "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "env_goal_spec", "integrator",
                             "off_range"))
 
+    def _lane_envelope(self, rows: np.ndarray):
+        """(Krogstad steps per env step, None) for per-env sets inside the validated envelope of the etdlin lane path, else
+        (None, what left it) -- see set_lane_params."""
+        base = der_model.lane_param_rows({k: np.full(self.num_envs, float(self._der_cfg_value(k))) for k in
+                                          ("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q", "Np")}, self.num_envs)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ratio = rows[:5] / base[:5]
+            op = (rows[5] / base[5]) * rows[6]                     # Np / the group's Np x insolation scale (NaN = 1)
+        if np.any(np.isfinite(ratio) & (ratio <= 0)) or np.any(np.isfinite(op) & (op <= 0)):
+            return None, "a parameter of the opposite sign"
+        ratio = np.where(np.isfinite(ratio), ratio, 1.0)                              # (NaN / a missing key: the group's value)
+        npr = np.where(np.isfinite(rows[5]), rows[5] / base[5], 1.0)
+        op = npr * np.where(np.isfinite(rows[6]), rows[6], 1.0)
+        spread = np.maximum(ratio, 1.0 / ratio).max(axis=1)                           # per key: how far the farthest env sits
+        s_c, s_g = float(spread[0]), float(spread[1:].max())
+        op_lo, op_hi = float(op.min()), float(op.max())
+        if op_lo < LANE_OP_RANGE[0] - 1e-9 or op_hi > LANE_OP_RANGE[1] + 1e-9:
+            return None, "PV array x insolation scale %.2f-%.2f of the group's; validated %.2f-%.2f" % ((op_lo, op_hi) + LANE_OP_RANGE)
+        if s_c > 3.0 + 1e-9 or s_g > 2.0 + 1e-9:
+            return None, "C x %.2f, outer PI gains x %.2f of the group's value; validated to x 3 / x 2" % (s_c, s_g)
+        if s_c <= 1.0 / 0.7 + 1e-9 and s_g <= 1.25 + 1e-9:
+            return 2, None
+        if s_c <= 2.0 + 1e-9 and s_g <= 1.5 + 1e-9:
+            return 6, None
+        return 8, None
+
     def set_lane_params(self, lane_params: Optional[dict]):
         """Install (or, with None, remove) the per-env parameter override -- see the constructor's ``lane_params``."""
         self._drop_plan()
+        user = self.__dict__.get("_integrator_user")
+        if user is not None and self.integrator != user:          # (an earlier set had sent this env to the ETDRK4 lane kernels)
+            self.integrator = user
+        object.__setattr__(self, "_integrator_user", self.integrator)
         if not lane_params:
             object.__setattr__(self, "_lane_folded", None)
             return
@@ -290,26 +322,20 @@ class PVDERVec(EnvSpecMixin):
             # The matrix-core path keeps the GROUP's exponential operator and takes K Krogstad steps per env step: how many it needs
             # for 1e-4 of the per-set converged solution follows the spread of the sets around the group's values
             # (profiles/r05_lane_etdlin_envelope.txt, fp64 against bridge runs): C x 0.7-1.4 and outer PI gains x 0.8-1.25: K = 2
-            # (5.6e-5); C x 0.5-2 / gains x 0.67-1.5: K = 6 (5.2e-5); C x 0.33-3 / gains x 0.5-2: K = 8 (8.1e-5); beyond: K = 8 and a
-            # warning.  `lane_steps` (attribute, before reset()) overrides the choice.
-            base = der_model.lane_param_rows({k: np.full(self.num_envs, float(self._der_cfg_value(k))) for k in
-                                              ("C_actual", "Kp_DC", "Ki_DC", "Kp_Q", "Ki_Q")}, self.num_envs)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                ratio = rows[:5] / base[:5]
-            ratio = np.where(np.isfinite(ratio) & (ratio > 0), ratio, 1.0)             # (NaN / a missing key: the group's value)
-            spread = np.maximum(ratio, 1.0 / ratio).max(axis=1)                         # per key: how far the farthest env sits
-            s_c, s_g = float(spread[0]), float(spread[1:].max())
-            if s_c <= 1.0 / 0.7 + 1e-9 and s_g <= 1.25 + 1e-9:
-                steps = 2
-            elif s_c <= 2.0 + 1e-9 and s_g <= 1.5 + 1e-9:
-                steps = 6
+            # (5.6e-5); C x 0.5-2 / gains x 0.67-1.5: K = 6 (5.2e-5); C x 0.33-3 / gains x 0.5-2: K = 8 (8.1e-5).  The PV array's
+            # size and insolation scale move each env's OPERATING POINT away from the one the shared Jacobian was taken at: validated
+            # for Np x Sinsol_scale within 0.8-1.0 of the group's array (Np 10-11 of 11, scale 0.9-1.0; same file).  BEYOND either
+            # envelope the scheme is 5e-4 ... 3e-3 off, so the env FAILS SAFE: it steps with the ETDRK4 lane kernels (every env on the
+            # 23-state path with its own constants: 3e-5 at any spread, 45-76 us per batched step instead of 11-24), one INFO line.
+            # `lane_steps` (attribute, before reset()) overrides the step count inside the envelope.
+            steps, why = self._lane_envelope(rows)
+            if steps is None:
+                logger.info("lane_params reach beyond the spread the etdlin lane path is validated for (%s): this env steps with "
+                            "integrator='etdrk4' (per-env constants on the 23-state path, 3e-5 of the per-set converged solution "
+                            "at any spread)", why)
+                self.integrator = "etdrk4"
             else:
-                steps = 8
-                if s_c > 3.0 + 1e-9 or s_g > 2.0 + 1e-9:
-                    logger.warning("lane_params reach beyond the spread the etdlin lane path is validated for (C x %.2f, outer PI gains x %.2f "
-                                   "of the group's value; validated to x 3 / x 2: 8e-5 of the per-set converged solution with 8 Krogstad "
-                                   "steps per env step) -- integrator='etdrk4' holds its 3e-5 at any spread", s_c, s_g)
-            object.__setattr__(self, "_lane_steps_auto", steps)
+                object.__setattr__(self, "_lane_steps_auto", steps)
         folded = np.empty((_native.LPF_ROWS, self.num_envs), dtype=np.float32)
         _native.check(self._lib.pvder_fold_lane_params(self._par_c, rows.ctypes.data, self.num_envs, folded.ctypes.data),
                       "pvder_fold_lane_params")
@@ -638,7 +664,22 @@ class PVDERVec(EnvSpecMixin):
         # where the batch's envs are (a prefetch hint for the step launch, include/pvder_hip.h): kept across plan rebuilds
         # (PVDER_NO_HINT=1: A/B runs without it)
         self._lib.pvder_plan_hint(h, -1 if os.environ.get("PVDER_NO_HINT") else self.__dict__.get("_ksub_hint", -1))
+        if self.__dict__.get("_graph_hints"):
+            self._lib.pvder_plan_graph_hints(h, 1)
         return h
+
+    def kernel_name(self) -> str:
+        """The step kernel a launch of this env runs, as rocprofv3 prints it (pvder_plan_kernel_name, ABI 17)."""
+        plan = self._plan or self._make_plan()
+        return self._lib.pvder_plan_kernel_name(plan).decode()
+
+    def graph_hints(self, on: bool = True):
+        """Let a HIP-graph CAPTURE of ``rollout(fused=False)`` keep the clock hints it was captured with (pvder_plan_graph_hints):
+        only for a graph replayed exactly where it was captured (bench.py's window).  The default clears the hint in every captured
+        launch -- a graph replayed in a loop would otherwise carry stale ones (slower than none; results never depend on it)."""
+        object.__setattr__(self, "_graph_hints", bool(on))
+        if self._plan is not None:
+            self._lib.pvder_plan_graph_hints(self._plan, 1 if on else 0)
 
     def _device_ctx(self):
         """``torch.cuda.device(self.device)``, or nothing when it is the current device already."""

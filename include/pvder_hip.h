@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 16
+#define PVDER_ABI_VERSION 17
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -331,6 +331,16 @@ void pvder_plan_destroy(pvder_plan *plan);
  * flop); an env whose own counter says otherwise takes the dependent fetch as before.  A prefetch hint: a wrong or missing
  * one costs time, never a result. */
 int pvder_plan_hint(pvder_plan *plan, int ksub);
+/* (ABI 17) The clock hint is a kernel ARGUMENT: a launch captured into a HIP graph replays the hint it was captured with.  By
+ * default every captured launch -- pvder_plan_step and pvder_plan_rollout alike -- is therefore taken with the hint cleared and
+ * leaves the plan's clock alone (a replay at another clock with a stale hint is slower than no hint; results never depend on it).
+ * on = 1: a captured pvder_plan_rollout keeps and advances its hints -- for a caller that replays the graph exactly where it was
+ * captured (bench.py's timed window).  on < 0 = query only.  Returns the previous setting, PVDER_EINVAL without a plan. */
+int pvder_plan_graph_hints(pvder_plan *plan, int on);
+/* (ABI 17) The step kernel a launch of this plan runs, as rocprofv3 prints it without its namespace and argument list (e.g.
+ * "step_etdlin_kernel_w1<3>": the one-wave-per-SIMD form a batch of up to 65 536 three-phase envs takes): what a measurement
+ * names as "the kernel that ran".  Static storage; "" without a plan. */
+const char *pvder_plan_kernel_name(const pvder_plan *plan);
 
 /* Per-LANE parameter override (PVDER_INT_ETDRK4, three-phase model): every env of the batch with its own values of the
  * parameters that stay outside the exponential operator of the 23-state ETDRK4 path -- domain randomisation over the

@@ -54,6 +54,10 @@ CASES = {
     # ... twice that spread (round 5: the etdlin lane path picks its number of Krogstad steps per env step by the spread)
     "lane_params_wide": dict(N=24, seed=21, spec="both", n=15, steps=24, actions=("random", 99), lane_seed=6,
                              lane_spread=(0.5, 2.0, 0.67, 1.5)),
+    # ... four times (round 6): BEYOND what the etdlin lane path is validated for -- the default constructor sends such a batch to the
+    # ETDRK4 lane kernels by itself (vec_env.PVDERVec._lane_envelope)
+    "lane_params_x4": dict(N=16, seed=21, spec="both", n=15, steps=16, actions=("random", 99), lane_seed=7,
+                           lane_spread=(0.25, 4.0, 0.4, 2.5)),
 }
 
 

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 BARGS="--steps 400 --warmup 100 --preroll-steps 0 --cpu-seconds 0 --classic-steps 0 --sustained-seconds 0 --fused-seconds 0.1 --fixed-policy 0 --rk45-steps 0 --large-batch 0 --single-env-steps 0 --side-legs 0"
-export PVDER_PMC_KERNEL=${PVDER_PMC_KERNEL:-step_etdlin_kernel}
+export PVDER_PMC_KERNEL="${PVDER_PMC_KERNEL:-step_etdlin_kernel_w1<3>}"
 echo "[profile] kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $BARGS > $out/stats.log 2>&1
 echo "[profile] pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py $BARGS > $out/fetch.log 2>&1
 echo "[profile] pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py $BARGS > $out/write.log 2>&1

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 out=gpurun_out/sq_$tag
 rm -rf $out; mkdir -p $out
 BARGS="--steps 200 --warmup 50 --preroll-steps 0 --cpu-seconds 0 --classic-steps 0 --sustained-seconds 0 --fused-seconds 0 --fixed-policy 0 --rk45-steps 0 --large-batch 0 --single-env-steps 0 --side-legs 0"
-export PVDER_PMC_KERNEL=${PVDER_PMC_KERNEL:-step_etdlin_kernel}
+export PVDER_PMC_KERNEL="${PVDER_PMC_KERNEL:-step_etdlin_kernel_w1<3>}"
 echo "[sq] pass 1: wave cycles"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $out/p1 -- python3 bench.py $BARGS > $out/p1.log 2>&1
 echo "[sq] pass 2: instruction mix + matrix pipe"

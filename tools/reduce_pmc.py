@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNEL = os.environ.get("PVDER_PMC_KERNEL", "step_etdrk4_bal_kernel")
+KERNEL = os.environ.get("PVDER_PMC_KERNEL", "step_etdlin_kernel_w1<3>")      # PVDERVec.kernel_name() of the bench workload
 ENVS = 65536
 ALGO_BYTES = 269 * ENVS
 

@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNEL = os.environ.get("PVDER_PMC_KERNEL", "step_etdlin_kernel")
+KERNEL = os.environ.get("PVDER_PMC_KERNEL", "step_etdlin_kernel_w1<3>")
 ENVS = int(os.environ.get("PVDER_PMC_ENVS", "65536"))
 
 
