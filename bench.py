@@ -188,6 +188,27 @@ def expected_payload_efficiency(world: int, n_local: int, kernel_s: float, gathe
     return out
 
 
+def scaling_note(world: int, value: float, legs: dict, expected: dict) -> str:
+    """One sentence a reader of a lone N > 1 line needs: `value` is the payload configs[3] names ("full": the whole
+    [13, N_local] block all-gathered every step); next to it the rate with no collation at all (`compute_only`: what the step path
+    itself scales to -- envs are independent, no collective on the integration path) and, per payload, the efficiency xGMI allows
+    at this kernel speed beside the one measured in this run (rate of the leg / compute_only rate)."""
+    co = (legs.get("compute_only") or {}).get("value")
+    parts = []
+    for pl in ("full", "obs8", "full_every_k", "reward_done"):
+        exp = (expected.get(pl) or {}).get("expected_efficiency")
+        got = (legs.get(pl) or {}).get("value")
+        if exp is None and got is None:
+            continue
+        parts.append("%s expected %s measured %s" % (pl, "%.2f" % exp if exp is not None else "n/a",
+                                                       "%.2f" % (got / co) if (got and co) else "n/a"))
+    return ("value = payload 'full' at %d GPUs (%.3g env-steps/s): every step all-gathers the whole [13, N_local] block, as BASELINE "
+            "configs[3] names it; the step path alone (compute_only, no collation) runs %s env-steps/s at the same %d GPUs -- the "
+            "figure to hold against N x the 1-GPU value for the scaling of the integration path.  A peer's block crosses one xGMI "
+            "link direction (76.5 GB/s) and overlaps the next step's kernel, so a step takes max(kernel, link): efficiency against "
+            "compute_only per payload -- %s." % (world, value, "%.3g" % co if co else "n/a", world, "; ".join(parts)))
+
+
 def xgmi_roofline(world: int, n_local: int, rows: float, sec_per_step: float) -> dict:
     """What the collective must move and the bound xGMI puts on it (MI355X_MICROARCH.md: 7 links x ~153 GB/s
     bidirectional per GPU, i.e. ~77 GB/s into a GPU per link, all peers in parallel)."""
@@ -236,8 +257,10 @@ def selftest_rank():
         legs[name] = ({"value": world * n_local * steps / el, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * el / steps}
                       if name == "compute_only" else payload_leg(world, n_local, steps, el, name, 1))
     if rank == 0:
+        exp = expected_payload_efficiency(world, 65536, 8e-6, 8)
         print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(t.sum()), "payload_legs": legs,
-                          "expected_payload_efficiency": expected_payload_efficiency(world, 65536, 8e-6, 8)}))
+                          "expected_payload_efficiency": exp,
+                          "scaling_note": scaling_note(world, legs["full"]["value"], legs, exp)}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -1090,6 +1113,7 @@ def run_rank(args):
             out["payload_legs"] = {"compute_only": compute_only, **{k: legs[k] for k in sorted(legs)}}
             kc = (compute_only or {}).get("kernel_avg_ms") or (compute_only or {}).get("ms_per_step")
             out["expected_payload_efficiency"] = expected_payload_efficiency(world, N, (kc or 0.0) * 1e-3, args.gather_every)
+            out["scaling_note"] = scaling_note(world, value, out["payload_legs"], out["expected_payload_efficiency"])
             out["xgmi_bound"] = {"bytes_received_per_step_per_gpu": (world - 1) * blk,
                                  "link_GBps_one_direction": 76.5,
                                  "min_us_per_step": blk / 76.5e9 * 1e6 if world > 1 else 0.0,

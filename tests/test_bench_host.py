@@ -36,6 +36,10 @@ def test_launcher_starts_n_ranks_by_itself():
         x = legs[k]["xgmi_roofline"]
         assert x["bound"] == "xgmi" and x["bytes_received_per_step_per_gpu"] == 256 * 4 * legs[k]["rows_per_step"] and x["frac"] > 0
     assert all(v["value"] > 0 for v in legs.values())
+    # the line explains itself -- value is the 'full' leg, compute_only beside it, expectation beside measurement
+    note = d["scaling_note"]
+    assert "payload 'full' at 2 GPUs" in note and "compute_only" in note and "full expected 0.18 measured" in note
+    assert "obs8 expected 0.23" in note and "reward_done expected 1.00" in note
 
 
 def test_launcher_propagates_a_failing_rank():
