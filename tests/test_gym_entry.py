@@ -103,7 +103,7 @@ obs = env.reset(); n = 0; done = False; q = 0.0
 env.action_space.seed(1) if hasattr(env.action_space, 'seed') else None
 while not done:
     a = env.action_space.sample()
-    q += {1: -1, 2: 1}.get(a, 0) * 25.0 * 15 / 50e3
+    q += {1: 1, 2: -1}.get(a, 0) * 25.0 * 15 / 50e3          # PVDER_env.py:214-217, :225
     obs, reward, done, info = env.step(a); n += 1
     assert obs.shape == (11,) and isinstance(reward, int) and isinstance(done, bool)
 res = {"steps": n, "env_steps": env.env.steps, "q_ref": env.env.sim.PV_model.Q_ref, "q_want": q, "obs9": float(obs[9]), "spec": env.spec.id,

@@ -1,0 +1,411 @@
+#!/usr/bin/env python
+"""CPU (fp64): the duty-cycle limit on the SLOW time scale -- a hybrid step for the 23-state path that follows the converged
+(event-locating, Filippov) solution of the oracle with LARGE steps (reference path PVDER_env.py:166, :218-221, :229,
+:480-487).  Statement of what the device's tail has to do; runs on the oracle's own right-hand side.
+
+What the converged solution does at the limit (oracle/pvder_bridge_filippov.h, zoomed with .scratch tools):
+per phase p and axis c (real / imaginary part) the current controller's low-pass state u_c can only move INWARD (towards zero) while
+|m_p| >= m_limit: with D_c = e_c - u_c (e_c = iref_c - i_c; du_c/dt = wp D_c) the axis is FROZEN while h_c = D_c sgn(u_c) > 0.
+
+  flight    every axis of the phase frozen: m_p constant, the phase's current loop OPEN -- di_c/dt = g (m_c - m_needed), g = Vdc / 2 Lf
+            -- nothing fast, rates of 1-10 /s
+  impact    h_c reaches zero from above at rate r = -dh_c/dt: the axis is released, the closed loop (omega_0^2 = wp Kp g, zeta =
+            wp / 2 omega_0 = 0.17) swings u_c inward and the anti-windup freezes it again at the FIRST extremum, half a damped period
+            (5.4 us) later: u_c jumps inward by (1 + rho) r / (g Kp), rho = exp(-pi zeta / sqrt(1 - zeta^2)) = 0.58, and h_c leaves at
+            + rho r -- a bouncing ball with restitution rho; i_c does not move (1e-6).  If the jump takes |m_p| below the limit the OTHER
+            axis, which wants outward, follows the circle (Filippov sliding for those 5 us)
+  contact   the impacts' Zeno limit: the axis regulates (closed loop, u_c creeping inward), the other one follows the circle
+  clamp     a component that reaches zero sits there while the phase is saturated
+  entry / exit   |m_p| reaches the limit from inside with outward-moving components / no frozen component wants outward any more
+
+    python tools/sat_hybrid_proto.py            (needs .scratch checkpoints for the window tests; the ramp test needs only the golden)
+"""
+import dataclasses
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")]
+import numpy as np
+from scipy.linalg import expm
+
+from oracle import pvder_model as pm
+from oracle.exp_rk_proto import DT, NS
+from switched_proto import SwRK
+
+ROT = [1.0, pm.A240, pm.A120]
+
+
+class Hybrid(SwRK):
+    """modes[p]: bit 0 = u_R frozen, bit 1 = u_I frozen; sat[p]: the phase is at the limit (its x components that would grow are held,
+    frozen components that want outward follow the circle when |m| would fall below the limit)."""
+
+    def __init__(self, contact_dm=5e-5, verbose=False):
+        super().__init__()
+        self.modes = [0, 0, 0]
+        self.sat = [False, False, False]
+        self.verbose = verbose
+        self.contact_dm = contact_dm
+        self.ev = {"entry": 0, "impact": 0, "contact": 0, "freeze": 0, "exit": 0, "clamp": 0, "follow": 0}
+        self.K = self.m.Kp_GCC
+
+    # ---- pieces of the state
+    def xu(self, y, p):
+        return np.array([y[6 * p + 2], y[6 * p + 3]]), np.array([y[6 * p + 4], y[6 * p + 5]])
+
+    def mvec(self, y, p):
+        x, u = self.xu(y, p)
+        return x + self.K * u
+
+    def s_of(self, y, p):
+        mm = self.mvec(y, p)
+        return mm[0] * mm[0] + mm[1] * mm[1] - self.m.m_limit ** 2
+
+    def demand(self, y, t, inp):
+        """f (free field) and D[p] = (e - u) of phase p as a 2-vector"""
+        f = self.f_free(y, t, inp)
+        return f, [np.array([f[6 * p + 4], f[6 * p + 5]]) / self.m.wp for p in range(3)]
+
+    def demand_rate(self, y, t, inp, f, p):
+        """d/dt (e_p) with u_p held: d iref_p/dt - d i_p/dt (complex -> 2-vector), from the free field at y"""
+        m = self.m
+        o = pm.algebraic(m, y, t, *inp)
+        dS = 0
+        for q in range(3):
+            di = complex(f[6 * q], f[6 * q + 1])
+            dS += 0.5 * ((m.kv_i * di) * o.i[q].conjugate() + o.v[q] * di.conjugate())
+        dia = complex(f[19] - m.Kp_DC * f[18], f[20] + m.Kp_Q * dS.imag)
+        de = dia * ROT[p] - complex(f[6 * p], f[6 * p + 1])
+        return np.array([de.real, de.imag]), o
+
+    def loop(self, Vdc):
+        """(g, rho) of the released axis: di_c/dt = g dm_c; restitution of the swing"""
+        m = self.m
+        g = Vdc / (2.0 * m.Lf)
+        w0 = np.sqrt(m.wp * self.K * g)
+        z = m.wp / (2.0 * w0)
+        return g, np.exp(-np.pi * z / np.sqrt(1.0 - z * z))
+
+    def loop_of(self, y, t, inp, p, c, de):
+        """the same from the field itself: g_c = -d(de_c/dt)/dm_c includes what the current does to its own reference"""
+        y2 = y.copy(); y2[6 * p + 4 + c] += 1e-9
+        # if the inward jump takes |m| below the limit and the other axis (frozen, wanting outward) follows the circle, the two move
+        # together: dm_o = -(m_c / m_o) dm_c
+        mm = self.mvec(y, p); o_ = 1 - c
+        x, u = self.xu(y, p)
+        if (self.modes[p] >> o_) & 1 and mm[c] * u[c] > 0 and mm[o_] != 0.0:
+            y2[6 * p + 4 + o_] += -(mm[c] / mm[o_]) * 1e-9
+        f2 = self.f_free(y2, t, inp)
+        de2, _ = self.demand_rate(y2, t, inp, f2, p)
+        g = -(de2[c] - de[c]) / (1e-9 * self.K)
+        w0 = np.sqrt(self.m.wp * self.K * g)
+        z = self.m.wp / (2.0 * w0)
+        return g, np.exp(-np.pi * z / np.sqrt(1.0 - z * z))
+
+    # ---- the exponential step with per-component masks
+    def etd(self, y, t, h, inp, modes, xmask):
+        L, (f0, f1, f2, f3) = self.phis_m(h, tuple(modes))
+        _, (g0, g1, g2, g3) = self.phis_m(h / 2, tuple(modes))
+
+        def F(yy, tt):
+            f = self.f_free(yy, tt, inp)
+            for p, md in enumerate(modes):
+                if md & 1: f[6 * p + 4] = 0
+                if md & 2: f[6 * p + 5] = 0
+                if xmask[p][0]: f[6 * p + 2] = 0
+                if xmask[p][1]: f[6 * p + 3] = 0
+            return f
+        N = lambda yy, tt: F(yy, tt) - L @ yy
+        N1 = N(y, t); N2 = N(g0 @ y + h * (0.5 * g1) @ N1, t + h / 2); N3 = N(g0 @ y + h * ((0.5 * g1 - g2) @ N1 + g2 @ N2), t + h / 2)
+        N4 = N(f0 @ y + h * ((f1 - 2 * f2) @ N1 + f2 @ (N2 + N3)), t + h)
+        a52 = 0.5 * g2 - f3 + 0.25 * f2 - 0.5 * g3; a54 = 0.25 * g2 - a52; a51 = 0.5 * g1 - 2 * a52 - a54
+        N5 = N(g0 @ y + h * (a51 @ N1 + a52 @ (N2 + N3) + a54 @ N4), t + h / 2)
+        yn = f0 @ y + h * ((f1 - 3 * f2 + 4 * f3) @ N1 + (-f2 + 4 * f3) @ N4 + (4 * f2 - 8 * f3) @ N5)
+        for p, md in enumerate(modes):            # held components are held exactly
+            if md & 1: yn[6 * p + 4] = y[6 * p + 4]
+            if md & 2: yn[6 * p + 5] = y[6 * p + 5]
+            if xmask[p][0]: yn[6 * p + 2] = y[6 * p + 2]
+            if xmask[p][1]: yn[6 * p + 3] = y[6 * p + 3]
+        return yn
+
+    def xmask_of(self, y):
+        """x_c of a saturated phase is held while it would grow: dx_c = Ki u_c has the sign of u_c"""
+        out = []
+        for p in range(3):
+            x, u = self.xu(y, p)
+            out.append([self.sat[p] and (u[c] * x[c] > 0 or x[c] == 0.0) for c in range(2)])
+        return out
+
+    # ---- the circle
+    def follow_circle(self, y, p, D, mover=-1, m_from=None, exclude=-1):
+        """The circle constraint of a saturated phase after component `mover` (or, mover = -1, the slow motion of a step) has moved:
+        wherever |m_p| would fall below the limit the frozen components that want outward (h_c > 0; a component AT zero moves with its
+        demand, through m_c = 0 if need be) move out -- instantly on this time scale, K wp D_c ~ 1e8 /s -- and, being frozen, do NOT come
+        back when the mover's path lets |m_p| grow again (a ratchet): what counts is the SMALLEST |m_mover| along its path (zero if it
+        changes sign).  Returns False when the phase is inside the limit and nothing may move (it then leaves the limit)."""
+        x, u = self.xu(y, p)
+        lim2 = self.m.m_limit ** 2
+        mm = x + self.K * u
+        cand = []
+        for c in range(2):
+            if c == mover or c == exclude or not (self.modes[p] >> c) & 1:
+                continue
+            if (u[c] == 0.0 and D[c] != 0.0) or D[c] * u[c] > 1e-12 * abs(u[c]):
+                cand.append(c)
+        if mover >= 0:
+            o = 1 - mover
+            m0, m1 = m_from, mm[mover]
+            mmin2 = 0.0 if m0 * m1 < 0 else min(m0 * m0, m1 * m1)
+            if o in cand and lim2 - mmin2 > mm[o] * mm[o]:
+                dirn = np.sign(D[o])
+                tgt = dirn * np.sqrt(lim2 - mmin2)
+                if (tgt - mm[o]) * dirn > 0:
+                    # ... as far as its demand lasts: D_o = e_o - u_o falls one for one with the move
+                    du_o = min((tgt - mm[o]) * dirn / self.K, abs(D[o]))
+                    y[6 * p + 4 + o] = u[o] + dirn * du_o
+                    self.ev["follow"] += 1
+            return self.s_of(y, p) >= -1e-13
+        if mm @ mm >= lim2 - 1e-13:
+            return True
+        if not cand:
+            return False
+        d = np.zeros(2)
+        for c in cand:
+            d[c] = D[c]
+        dm = self.K * d
+        qa, qb, qc = dm @ dm, 2 * (mm @ dm), mm @ mm - lim2
+        disc = qb * qb - 4 * qa * qc
+        if disc < 0:
+            return False
+        beta = (-qb + np.sqrt(disc)) / (2 * qa)
+        if beta < 0:
+            return False
+        y[6 * p + 4], y[6 * p + 5] = u + min(beta, 1.0) * d          # (beta = 1: the demands are used up)
+        self.ev["follow"] += 1
+        return beta <= 1.0
+
+    # ---- one macro step with the slow-time-scale events located inside it
+    def advance(self, y, t, h, inp, depth=0):
+        """from (t, y) over h; returns y(t + h).  Events split the step."""
+        K, m = self.K, self.m
+        t_end = t + h
+        guard = 0
+        while t < t_end - 1e-15:
+            guard += 1
+            if guard > 200:
+                raise RuntimeError("event loop does not advance at t = %.9f (modes %s)" % (t, self.modes))
+            hh = t_end - t
+            f0, D0 = self.demand(y, t, inp)
+            modes0 = list(self.modes)
+            y1 = self.etd(y, t, hh, inp, modes0, self.xmask_of(y))
+            f1, D1 = self.demand(y1, t + hh, inp)
+            # -- event functions at both ends: (kind, p, c, value0, value1); an event = sign change - to + of `value`
+            cands = []
+            for p in range(3):
+                x0, u0 = self.xu(y, p); x1, u1 = self.xu(y1, p)
+                if not self.sat[p]:
+                    s0, s1 = self.s_of(y, p), self.s_of(y1, p)
+                    if s1 > 0:
+                        cands.append(("entry", p, -1, s0, s1))
+                    continue
+                for c in range(2):
+                    if (modes0[p] >> c) & 1:                       # frozen: impact when h_c = D_c sgn(u_c) falls through zero
+                        if u0[c] == 0.0:
+                            continue                                # clamped at zero: stays while saturated
+                        sg = np.sign(u0[c])
+                        a, b = -D0[p][c] * sg, -D1[p][c] * sg
+                        if b > 0 or a > 1e-13:
+                            if 0 <= a < 1e-13:   # h_c = 0 at the start (just impacted): an impact only if falling
+                                de0, _ = self.demand_rate(y, t, inp, f0, p)
+                                if -de0[c] * sg <= 0:
+                                    continue
+                            cands.append(("impact", p, c, a, b))
+                    else:                                           # regulating axis of a saturated phase: freezes when it turns outward
+                        if u1[c] * u0[c] < 0:
+                            cands.append(("clamp", p, c, -abs(u0[c]), abs(u1[c])))
+                        elif abs(u1[c]) > abs(u0[c]) * (1 + 1e-9) + 1e-15:
+                            cands.append(("freeze", p, c, -1.0, 1.0))
+            if not cands:
+                y, t = y1, t + hh
+                self.after_step(y, t, inp)
+                continue
+            # -- the earliest one, located by the secant on the step length (two refinements)
+            best = None
+            for kind, p, c, a, b in cands:
+                th = 0.0 if a >= 0 else a / (a - b)
+                if kind == "freeze":
+                    th = 0.0
+                if best is None or th < best[0]:
+                    best = (th, kind, p, c, a, b)
+            th, kind, p, c, a, b = best
+            if kind not in ("freeze",) and th > 0:
+                lo, flo, hi, fhi = 0.0, a, 1.0, b
+                for _ in range(3):
+                    yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
+                    val = self.event_value(kind, p, c, y, yt, t + hh * th, inp)
+                    if val > 0: hi, fhi = th, val
+                    else: lo, flo = th, val
+                    if abs(val) < 1e-13: break
+                    th = lo + (hi - lo) * (-flo) / (fhi - flo)
+                yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
+            elif th > 0:
+                yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
+            else:
+                yt = y.copy()
+            y, t = yt, t + hh * th
+            self.apply_event(kind, p, c, y, t, inp, at_start=(th == 0.0))
+            self.after_step(y, t, inp, exclude=(p, c) if kind == "impact" else (-1, -1))
+        return y
+
+    def event_value(self, kind, p, c, y0, y, t, inp):
+        if kind == "entry":
+            return self.s_of(y, p)
+        if kind == "impact":
+            f, D = self.demand(y, t, inp)
+            return -D[p][c] * np.sign(y0[6 * p + 4 + c])
+        if kind == "clamp":
+            return -y[6 * p + 4 + c] * np.sign(y0[6 * p + 4 + c])
+        return 1.0
+
+    def apply_event(self, kind, p, c, y, t, inp, at_start=False):
+        K, m = self.K, self.m
+        self.ev[kind] += 1
+        f, D = self.demand(y, t, inp)
+        x, u = self.xu(y, p)
+        if kind == "entry":
+            # onto the circle (the located point is within the secant's tolerance of it); components whose demand points outward freeze
+            mm = x + K * u
+            sc = m.m_limit / np.hypot(mm[0], mm[1])
+            y[6 * p + 4], y[6 * p + 5] = (mm * sc - x) / K
+            x, u = self.xu(y, p)
+            md = 0
+            for cc in range(2):
+                if D[p][cc] * u[cc] > 0 or u[cc] == 0.0:
+                    md |= 1 << cc
+            self.modes[p] = md
+            self.sat[p] = md != 0
+            if self.verbose: print("  t %.6f entry   phase %d modes %d" % (t, p, md))
+            return
+        if kind == "clamp":
+            y[6 * p + 4 + c] = 0.0
+            self.modes[p] |= 1 << c
+            if self.verbose: print("  t %.6f clamp   phase %d axis %d" % (t, p, c))
+            return
+        if kind == "freeze":
+            self.modes[p] |= 1 << c
+            if self.verbose: print("  t %.6f freeze  phase %d axis %d" % (t, p, c))
+            return
+        # impact: the released axis' closed loop, zeta = inward displacement of u_c, v = -h_c (> 0: released):
+        #   zeta' = wp v,  v' = r - g K zeta - zeta'   ->   zeta'' + wp zeta' + wp g K zeta = wp r,   zeta(0) = 0, zeta'(0) = wp v0
+        # frozen again at the first t* > 0 with zeta' = 0 (v = 0); v0 = 0 (a located crossing): zeta(t*) = (1 + rho) r / (g K)
+        de, o = self.demand_rate(y, t, inp, f, p)
+        sg = np.sign(u[c])
+        r = -de[c] * sg                                   # rate at which h_c falls
+        v0 = max(-D[p][c] * sg, 0.0) if at_start else 0.0      # (a LOCATED crossing is on the surface: what is left is the secant's tolerance)
+        g, rho = self.loop_of(y, t, inp, p, c, de)
+        wp = m.wp
+        w0 = np.sqrt(wp * K * g); sig = 0.5 * wp; wd = np.sqrt(w0 * w0 - sig * sig)
+        zeq = r / (g * K)
+        A = -zeq; B = (wp * v0 + sig * A) / wd
+        # zeta'(t) = e^{-sig t} [ (wd B - sig A) cos - (wd A + sig B) sin ]
+        num, den = wd * B - sig * A, wd * A + sig * B
+        ts = np.arctan2(num, den) / wd
+        if ts <= 1e-12: ts += np.pi / wd
+        zeta = zeq + np.exp(-sig * ts) * (A * np.cos(wd * ts) + B * np.sin(wd * ts))
+        dm = K * zeta
+        if v0 < 1e-12 and dm < self.contact_dm:
+            if r <= 0:
+                return
+            # the impacts' Zeno limit: the axis regulates from here on
+            self.modes[p] &= ~(1 << c)
+            self.ev["contact"] += 1
+            if self.verbose: print("  t %.6f contact phase %d axis %d (r %.3e)" % (t, p, c, r))
+            return
+        du = max(zeta, 0.0)
+        m_from = x[c] + K * u[c]
+        if du >= abs(u[c]):
+            y[6 * p + 4 + c] = 0.0
+            self.ev["clamp"] += 1
+        else:
+            y[6 * p + 4 + c] = u[c] - sg * du
+            # frozen again ON the surface h_c = 0: what the current moved during the swing (<= 1e-6)
+            y[6 * p + c] -= -(D[p][c] + sg * du)
+        if not self.follow_circle(y, p, D[p], mover=c, m_from=m_from):
+            self.sat[p] = False; self.modes[p] = 0; self.ev["exit"] += 1
+            if self.verbose: print("  t %.6f exit    phase %d (behind the impact: nothing holds |m| at the limit)" % (t, p))
+        if self.verbose: print("  t %.6f impact  phase %d axis %d  r %.4f  K du %.3e -> K u %.6f" % (t, p, c, r, dm, K * y[6 * p + 4 + c]))
+
+    def after_step(self, y, t, inp, exclude=(-1, -1)):
+        """the circle constraint of saturated phases behind the slow motion of a step, and their exit"""
+        for p in range(3):
+            if not self.sat[p]:
+                continue
+            if self.s_of(y, p) < -1e-13:
+                f, D = self.demand(y, t, inp)
+                if not self.follow_circle(y, p, D[p], exclude=exclude[1] if exclude[0] == p else -1):
+                    self.sat[p] = False
+                    self.modes[p] = 0
+                    self.ev["exit"] += 1
+                    if self.verbose: print("  t %.6f exit    phase %d" % (t, p))
+
+
+def ramp_test(env=1, steps=160, quiet=1, verbose=False):
+    from switched_proto import run_ramp
+    R = Hybrid(verbose=verbose)
+    R.step_sw = lambda y, t, h, inp: R.advance(y, t, h, inp)
+    err = run_ramp(R, env=env, steps=steps, quiet=quiet)
+    return R, err
+
+
+def load_ck(e=1):
+    import pickle
+    return pickle.load(open(os.path.join(ROOT, ".scratch", "sub_e%d.pkl" % e), "rb"))
+
+
+def window_test(k0, s0, k1, s1, nsteps_per_sub=1, verbose=True, e=1):
+    """start from the golden state at (env step k0, sim step s0) with modes from the oracle's regions, integrate to (k1, s1), compare"""
+    from oracle import bridge
+    ck = load_ck(e)
+    R = Hybrid(verbose=verbose)
+    y_d, reg, inp = ck[(k0, s0)]
+    t = (15 * k0 + s0) * DT
+    y = bridge.to_wte(y_d, t)
+    f, D = R.demand(y, t, inp)
+    for p in range(3):
+        if reg[p] != 0:
+            x, u = R.xu(y, p)
+            md = 0
+            for c in range(2):
+                if D[p][c] * u[c] > 0 or u[c] == 0.0: md |= 1 << c
+            R.modes[p], R.sat[p] = md, True
+    print("start modes", R.modes, "sat", R.sat, "regions", reg)
+    k, s = k0, s0
+    while (k, s) != (k1, s1):
+        y_d, reg, inp = ck[(k, s)]
+        t = (15 * k + s) * DT
+        for j in range(nsteps_per_sub):
+            y = R.advance(y, t + j * DT / nsteps_per_sub, DT / nsteps_per_sub, inp)
+        s += 1
+        if s == 15: k, s = k + 1, 0
+        if (k, s) in ck:
+            want = bridge.to_wte(ck[(k, s)][0], (15 * k + s) * DT)
+            d = y - want
+            wi = np.abs(d[[0, 1, 6, 7, 12, 13]]).max()
+            if verbose:
+                print("      per phase |di| %s  K du %s" % (" ".join("(%.1e,%.1e)" % (abs(d[6 * p]), abs(d[6 * p + 1])) for p in range(3)),
+                                                           " ".join("(%+.1e,%+.1e)" % (R.K * d[6 * p + 4], R.K * d[6 * p + 5]) for p in range(3))))
+            print("(%d,%2d) modes %s sat %s oracle %s  max|di| %.2e  dVdc %.2e  max|K du| %.2e  |dx| %.2e" % (
+                k, s, R.modes, [int(b) for b in R.sat], ck[(k, s)][1], wi, abs(d[18]), R.K * np.abs(d[[4, 5, 10, 11, 16, 17]]).max(),
+                np.abs(d[[2, 3, 8, 9, 14, 15]]).max()), flush=True)
+    print(R.ev)
+    return R
+
+
+if __name__ == "__main__" and sys.argv[1:2] == ["ramp"]:
+    e = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    R, err = ramp_test(env=e, quiet=int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    print("env %d: worst env step by 5-step block from 106: %s" % (e, " ".join("%.1e" % err[k:k + 5].max() for k in range(106, 160, 5))))
+    print("max %.2e  median beyond 116 %.2e   events %s" % (err.max(), np.median(err[116:]), R.ev))
+elif __name__ == "__main__":
+    a = [int(v) for v in sys.argv[1:5]] if len(sys.argv) >= 5 else [116, 4, 117, 0]
+    window_test(*a, nsteps_per_sub=int(sys.argv[5]) if len(sys.argv) > 5 else 1)
