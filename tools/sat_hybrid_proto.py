@@ -48,6 +48,8 @@ class Hybrid(SwRK):
         self.contact_dm = contact_dm
         self.ev = {"entry": 0, "impact": 0, "contact": 0, "freeze": 0, "exit": 0, "clamp": 0, "follow": 0}
         self.K = self.m.Kp_GCC
+        self.last_impact = None
+        self.jump_margin = 4e-3          # an input jump counts as an entry when |m|^2 > (1 - margin) limit^2
 
     # ---- pieces of the state
     def xu(self, y, p):
@@ -93,7 +95,9 @@ class Hybrid(SwRK):
         # together: dm_o = -(m_c / m_o) dm_c
         mm = self.mvec(y, p); o_ = 1 - c
         x, u = self.xu(y, p)
-        if (self.modes[p] >> o_) & 1 and mm[c] * u[c] > 0 and mm[o_] != 0.0:
+        Dp = np.array([self.f_free(y, t, inp)[6 * p + 4 + k] for k in range(2)]) / self.m.wp
+        follows = (self.modes[p] >> o_) & 1 and Dp[o_] * u[o_] > 0
+        if follows and mm[c] * u[c] > 0 and abs(mm[o_]) > 1e-3:
             y2[6 * p + 4 + o_] += -(mm[c] / mm[o_]) * 1e-9
         f2 = self.f_free(y2, t, inp)
         de2, _ = self.demand_rate(y2, t, inp, f2, p)
@@ -150,8 +154,8 @@ class Hybrid(SwRK):
         for c in range(2):
             if c == mover or c == exclude or not (self.modes[p] >> c) & 1:
                 continue
-            if (u[c] == 0.0 and D[c] != 0.0) or D[c] * u[c] > 1e-12 * abs(u[c]):
-                cand.append(c)
+            if D[c] * u[c] > 1e-12 * abs(u[c]):          # (a component AT zero is no pusher: once nothing holds the phase at the limit it
+                cand.append(c)                            #  runs free with the rest -- exit, and `input_jump` finds where that ends)
         if mover >= 0:
             o = 1 - mover
             m0, m1 = m_from, mm[mover]
@@ -189,6 +193,7 @@ class Hybrid(SwRK):
         """from (t, y) over h; returns y(t + h).  Events split the step."""
         K, m = self.K, self.m
         t_end = t + h
+        self.input_jump(y, t, inp)
         guard = 0
         while t < t_end - 1e-15:
             guard += 1
@@ -214,8 +219,10 @@ class Hybrid(SwRK):
                             continue                                # clamped at zero: stays while saturated
                         sg = np.sign(u0[c])
                         a, b = -D0[p][c] * sg, -D1[p][c] * sg
-                        if b > 0 or a > 1e-13:
-                            if 0 <= a < 1e-13:   # h_c = 0 at the start (just impacted): an impact only if falling
+                        if a >= 0 and self.last_impact == (p, c, t):
+                            continue                                # it has just been frozen ON h_c = 0
+                        if b > 0 or a > 1e-9:
+                            if 0 <= a <= 1e-9:   # h_c = 0 at the start (just impacted): an impact only if falling
                                 de0, _ = self.demand_rate(y, t, inp, f0, p)
                                 if -de0[c] * sg <= 0:
                                     continue
@@ -240,13 +247,23 @@ class Hybrid(SwRK):
             th, kind, p, c, a, b = best
             if kind not in ("freeze",) and th > 0:
                 lo, flo, hi, fhi = 0.0, a, 1.0, b
-                for _ in range(3):
+                side = 0
+                for _ in range(12):                                   # regula falsi, Illinois variant (a slow approach is convex)
                     yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
                     val = self.event_value(kind, p, c, y, yt, t + hh * th, inp)
-                    if val > 0: hi, fhi = th, val
-                    else: lo, flo = th, val
-                    if abs(val) < 1e-13: break
+                    if val > 0:
+                        hi, fhi = th, val
+                        if side == 1: flo *= 0.5
+                        side = 1
+                    else:
+                        lo, flo = th, val
+                        if side == -1: fhi *= 0.5
+                        side = -1
+                    if (hi - lo) * hh < 2e-7: break
                     th = lo + (hi - lo) * (-flo) / (fhi - flo)
+                th = hi
+                # end on the FAR side of the crossing (the event has happened there: what handles it must see it), a hair beyond the
+                # secant's estimate or at the bracket's upper end
                 yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
             elif th > 0:
                 yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
@@ -256,6 +273,31 @@ class Hybrid(SwRK):
             self.apply_event(kind, p, c, y, t, inp, at_start=(th == 0.0))
             self.after_step(y, t, inp, exclude=(p, c) if kind == "impact" else (-1, -1))
         return y
+
+    def input_jump(self, y, t, inp):
+        """An action moves iref by 0.0012: the low-pass state of a FREE phase would follow within 5 us -- a move of 7 in m: every
+        action takes every phase to the limit within nanoseconds.  Clear of the limit the phase leaves it again
+        within 0.05-1 ms and ignoring the episode costs 1e-5; NEAR the limit it may stay -- the entry then happens HERE, along the
+        demand, and the usual rules (impact of the components released inward, clamp, exit) take it from there."""
+        f, D = self.demand(y, t, inp)
+        for p in range(3):
+            if self.sat[p]:
+                continue
+            x, u = self.xu(y, p)
+            if self.K * np.hypot(*D[p]) < 1e-3:
+                continue
+            mv = x + self.K * (u + D[p])
+            lim2 = self.m.m_limit ** 2
+            mm = x + self.K * u
+            if mv @ mv <= lim2 or mm @ mm < lim2 * (1.0 - self.jump_margin):
+                continue                     # (clear of the limit the phase is back inside within |d iref| / (g (1 - |m|)) < 1 ms: 1e-5)
+            dm = self.K * D[p]
+            qa, qb, qc = dm @ dm, 2 * (mm @ dm), mm @ mm - lim2
+            beta = (-qb + np.sqrt(qb * qb - 4 * qa * qc)) / (2 * qa)
+            y[6 * p + 4], y[6 * p + 5] = u + beta * D[p]
+            self.sat[p], self.modes[p] = True, 3
+            self.ev["entry"] += 1
+            if self.verbose: print("  t %.6f entry   phase %d behind an input jump (beta %.3e)" % (t, p, beta))
 
     def event_value(self, kind, p, c, y0, y, t, inp):
         if kind == "entry":
@@ -301,7 +343,8 @@ class Hybrid(SwRK):
         de, o = self.demand_rate(y, t, inp, f, p)
         sg = np.sign(u[c])
         r = -de[c] * sg                                   # rate at which h_c falls
-        v0 = max(-D[p][c] * sg, 0.0) if at_start else 0.0      # (a LOCATED crossing is on the surface: what is left is the secant's tolerance)
+        v0 = max(-D[p][c] * sg, 0.0) if at_start else 0.0
+        if v0 <= 1e-9: v0 = 0.0      # (a LOCATED crossing is on the surface: what is left is the secant's tolerance)
         g, rho = self.loop_of(y, t, inp, p, c, de)
         wp = m.wp
         w0 = np.sqrt(wp * K * g); sig = 0.5 * wp; wd = np.sqrt(w0 * w0 - sig * sig)
@@ -309,19 +352,23 @@ class Hybrid(SwRK):
         A = -zeq; B = (wp * v0 + sig * A) / wd
         # zeta'(t) = e^{-sig t} [ (wd B - sig A) cos - (wd A + sig B) sin ]
         num, den = wd * B - sig * A, wd * A + sig * B
-        ts = np.arctan2(num, den) / wd
-        if ts <= 1e-12: ts += np.pi / wd
-        zeta = zeq + np.exp(-sig * ts) * (A * np.cos(wd * ts) + B * np.sin(wd * ts))
+        if v0 == 0.0:
+            zeta = (1.0 + rho) * zeq                      # (half a damped period: the closed form of the docstring)
+        else:
+            ts = np.arctan2(num, den) / wd
+            if ts <= 1e-12: ts += np.pi / wd
+            zeta = zeq + np.exp(-sig * ts) * (A * np.cos(wd * ts) + B * np.sin(wd * ts))
         dm = K * zeta
-        if v0 < 1e-12 and dm < self.contact_dm:
+        if v0 == 0.0 and dm < self.contact_dm:
             if r <= 0:
                 return
             # the impacts' Zeno limit: the axis regulates from here on
             self.modes[p] &= ~(1 << c)
             self.ev["contact"] += 1
-            if self.verbose: print("  t %.6f contact phase %d axis %d (r %.3e)" % (t, p, c, r))
+            if self.verbose: print("  t %.6f contact phase %d axis %d (r %.3e, g %.1f rho %.3f)" % (t, p, c, r, g, rho))
             return
         du = max(zeta, 0.0)
+        self.last_impact = (p, c, t)
         m_from = x[c] + K * u[c]
         if du >= abs(u[c]):
             y[6 * p + 4 + c] = 0.0
@@ -333,6 +380,7 @@ class Hybrid(SwRK):
         if not self.follow_circle(y, p, D[p], mover=c, m_from=m_from):
             self.sat[p] = False; self.modes[p] = 0; self.ev["exit"] += 1
             if self.verbose: print("  t %.6f exit    phase %d (behind the impact: nothing holds |m| at the limit)" % (t, p))
+            self.input_jump(y, t, inp)
         if self.verbose: print("  t %.6f impact  phase %d axis %d  r %.4f  K du %.3e -> K u %.6f" % (t, p, c, r, dm, K * y[6 * p + 4 + c]))
 
     def after_step(self, y, t, inp, exclude=(-1, -1)):
@@ -347,11 +395,183 @@ class Hybrid(SwRK):
                     self.modes[p] = 0
                     self.ev["exit"] += 1
                     if self.verbose: print("  t %.6f exit    phase %d" % (t, p))
+                    self.input_jump(y, t, inp)
 
 
-def ramp_test(env=1, steps=160, quiet=1, verbose=False):
+class HybridMicro(Hybrid):
+    """The same macro scheme -- large exponential steps, the slow-time-scale events located inside them -- with every discrete happening
+    (an axis released, an input jump, the circle constraint violated, entry) resolved by ONE routine: `settle`, a micro-integration of the
+    phase's FAST pair (D_p, u_p) -- 4 real states, the slow ones frozen, linearised where it starts -- under the oracle's own rules
+    (oracle/pvder_bridge_filippov.h: regions IN / OUT / SLIDE, G masks, Filippov's alpha, components put on zero), until nothing fast is
+    left.  No closed-form impact map, no follower rules: the swing, the restitution, the ratchet, ping-pong between the axes, the clamp
+    and the exit all come out of the same 4-state integration (0.25 us steps, 5.4 us per swing)."""
+
+    hmic = 0.25e-6
+    tau_about = 20e-6            # a held component that will be released within this time keeps the micro-integration going
+    max_micro = 4000
+
+    def settle(self, y, t, inp, p, why="", trust_u=False):
+        m, K = self.m, self.K
+        lim2 = m.m_limit ** 2
+        f, D = self.demand(y, t, inp)
+        if trust_u:
+            # a phase that arrives from a LARGE free step carries its current to 1e-5 -- nothing for the current, a demand of K 1e-5 =
+            # 0.06 in m for the low-pass state.  On the slow manifold D = (du/dt) / wp ~ 1e-9: put the current there.
+            y[6 * p] += D[p][0]; y[6 * p + 1] += D[p][1]
+            f, D = self.demand(y, t, inp)
+        de0, o = self.demand_rate(y, t, inp, f, p)
+        x, u0 = self.xu(y, p)
+        # linearisation of d(e)/dt in u (2 x 2: -g K on the diagonal, the reference's own feedback and the cross terms beside it)
+        Ge = np.zeros((2, 2))
+        for c in range(2):
+            y2 = y.copy(); y2[6 * p + 4 + c] += 1e-9
+            f2 = self.f_free(y2, t, inp)
+            de2, _ = self.demand_rate(y2, t, inp, f2, p)
+            Ge[:, c] = (de2 - de0) / 1e-9
+        wp = m.wp
+        u, Dm = u0.copy(), D[p].copy()
+        h = self.hmic
+
+        def decide(u, Dm):
+            """the region from the state alone (fil_decide) and the G masks"""
+            fu = wp * Dm
+            mm = x + K * u
+            sv = mm @ mm - lim2
+            G = [(u[c] == 0.0) or (fu[c] * u[c] > 0) for c in range(2)]
+            if sv > 1e-11: return 1, G
+            if sv < -1e-11: return 0, G
+            N = 2 * K * (mm @ fu)
+            Dn = 2 * K * sum(mm[c] * fu[c] for c in range(2) if G[c])
+            if N <= 0: return 0, G
+            if N - Dn >= 0: return 1, G
+            return 2, G
+
+        def field(u, Dm, reg):
+            """(u', D') with the region held over the step (as the oracle holds it: fil_rhs)"""
+            fu = wp * Dm
+            up = fu.copy()
+            if reg != 0:
+                mm = x + K * u
+                G = [(u[c] == 0.0) or (fu[c] * u[c] > 0) for c in range(2)]
+                if reg == 1:
+                    for c in range(2):
+                        if G[c]: up[c] = 0.0
+                else:
+                    N = 2 * K * (mm @ fu)
+                    Dn = 2 * K * sum(mm[c] * fu[c] for c in range(2) if G[c])
+                    al = min(max(N / Dn, 0.0), 1.0) if Dn > 0 else 0.0
+                    for c in range(2):
+                        if G[c]: up[c] *= (1.0 - al)
+            Dp = de0 + Ge @ (u - u0) - up
+            return up, Dp
+
+        n, quiet = 0, 0
+        while n < self.max_micro:
+            reg, G = decide(u, Dm)
+            up1, Dp1 = field(u, Dm, reg)
+            # quiet: nothing moves fast, and no held component is about to be released (h_c = 0 and falling)
+            fast = K * np.abs(up1).max() * 5e-6 >= 1e-7
+            about = False
+            for c in range(2):
+                if reg != 0 and G[c] and u[c] != 0.0:
+                    sg = np.sign(u[c])
+                    if Dp1[c] * sg < 0 and Dm[c] * sg < max(1e-10, -Dp1[c] * sg * self.tau_about): about = True
+            if not fast and not about:
+                quiet += 1
+                if quiet >= 2: break
+            else:
+                quiet = 0
+            up2, Dp2 = field(u + 0.5 * h * up1, Dm + 0.5 * h * Dp1, reg)
+            up3, Dp3 = field(u + 0.5 * h * up2, Dm + 0.5 * h * Dp2, reg)
+            up4, Dp4 = field(u + h * up3, Dm + h * Dp3, reg)
+            du = (h / 6) * (up1 + 2 * up2 + 2 * up3 + up4)
+            dD = (h / 6) * (Dp1 + 2 * Dp2 + 2 * Dp3 + Dp4)
+            th = 1.0
+            mm0 = x + K * u
+            s0 = mm0 @ mm0 - lim2
+            dmm = K * du
+            qa, qb = dmm @ dmm, 2 * (mm0 @ dmm)
+            s1 = s0 + qb + qa
+            if qa > 0 and ((reg == 0 and s1 > 0) or (reg == 1 and s1 < 0)):     # onto the circle (from inside / from outside): stop ON it
+                disc = qb * qb - 4 * qa * s0
+                if disc >= 0:
+                    r1, r2 = (-qb - np.sqrt(disc)) / (2 * qa), (-qb + np.sqrt(disc)) / (2 * qa)
+                    roots = [r for r in (r1, r2) if 1e-14 < r <= 1.0]
+                    if roots: th = min(roots)
+            zc = -1
+            if reg != 0:
+                for c in range(2):                              # a component through zero while the phase is not inside: onto zero
+                    if u[c] != 0.0 and (u[c] + du[c]) * u[c] < 0:
+                        tz = u[c] / (-du[c])
+                        if tz < th: th, zc = tz, c
+            un, Dn_ = u + th * du, Dm + th * dD
+            if zc >= 0: un[zc] = 0.0
+            if reg == 2:                                        # sliding: back onto the circle along the components that moved
+                mm1 = x + K * un
+                sv = mm1 @ mm1 - lim2
+                gr = np.array([2 * K * mm1[c] if du[c] != 0.0 else 0.0 for c in range(2)])
+                if gr @ gr > 0: un = un - sv * gr / (gr @ gr)
+            u, Dm = un, Dn_
+            n += 1
+        # the current moved by what the demand did not account for: e = D + u
+        de_total = (Dm + u) - (D[p] + u0)
+        y[6 * p + 4], y[6 * p + 5] = u
+        y[6 * p] += (de0[0] + f[6 * p]) * n * h - de_total[0]              # d i = d iref - d e
+        y[6 * p + 1] += (de0[1] + f[6 * p + 1]) * n * h - de_total[1]
+        # classification for the macro step
+        reg, G = decide(u, Dm)
+        md = 0
+        if reg != 0:
+            for c in range(2):
+                if G[c]: md |= 1 << c
+        self.modes[p] = md
+        self.sat[p] = reg != 0
+        self.ev["settle"] = self.ev.get("settle", 0) + 1
+        self.ev["micro"] = self.ev.get("micro", 0) + n
+        if self.verbose:
+            print("  t %.6f settle  phase %d (%s): %d micro steps -> modes %d sat %d  K u (%+.6f, %+.6f)  K D (%+.2e, %+.2e)" % (
+                t, p, why, n, self.modes[p], self.sat[p], K * u[0], K * u[1], K * Dm[0], K * Dm[1]))
+
+    def input_jump(self, y, t, inp):
+        f, D = self.demand(y, t, inp)
+        lim2 = self.m.m_limit ** 2
+        for p in range(3):
+            x, u = self.xu(y, p)
+            mm = x + self.K * u
+            if self.sat[p]:
+                # a saturated phase whose frozen components are released by the jump (h_c < 0 by a finite amount)
+                rel = any(((self.modes[p] >> c) & 1) and u[c] != 0.0 and -D[p][c] * np.sign(u[c]) > 1e-9 for c in range(2))
+                if rel: self.settle(y, t, inp, p, "released by an input jump")
+                continue
+            if self.K * np.hypot(*D[p]) < 0.5:       # (an action moves K iref by 7; what a large free step leaves: K 1e-5)
+                continue
+            mv = x + self.K * (u + D[p])
+            if mv @ mv <= lim2 or mm @ mm < lim2 * (1.0 - self.jump_margin):
+                continue
+            self.settle(y, t, inp, p, "input jump near the limit")
+
+    def apply_event(self, kind, p, c, y, t, inp, at_start=False):
+        self.ev[kind] += 1
+        if kind == "freeze":
+            self.modes[p] |= 1 << c
+            if self.verbose: print("  t %.6f freeze  phase %d axis %d" % (t, p, c))
+            return
+        if kind == "clamp":
+            y[6 * p + 4 + c] = 0.0
+            self.modes[p] |= 1 << c
+            return
+        self.settle(y, t, inp, p, kind + " axis %d" % c, trust_u=(kind == "entry"))
+        self.last_impact = (p, c, t)
+
+    def after_step(self, y, t, inp, exclude=(-1, -1)):
+        for p in range(3):
+            if self.sat[p] and self.s_of(y, p) < -1e-12:
+                self.settle(y, t, inp, p, "inside the limit behind a step")
+
+
+def ramp_test(env=1, steps=160, quiet=1, verbose=False, cls=None):
     from switched_proto import run_ramp
-    R = Hybrid(verbose=verbose)
+    R = (cls or HybridMicro)(verbose=verbose)
     R.step_sw = lambda y, t, h, inp: R.advance(y, t, h, inp)
     err = run_ramp(R, env=env, steps=steps, quiet=quiet)
     return R, err
@@ -366,7 +586,7 @@ def window_test(k0, s0, k1, s1, nsteps_per_sub=1, verbose=True, e=1):
     """start from the golden state at (env step k0, sim step s0) with modes from the oracle's regions, integrate to (k1, s1), compare"""
     from oracle import bridge
     ck = load_ck(e)
-    R = Hybrid(verbose=verbose)
+    R = HybridMicro(verbose=verbose)
     y_d, reg, inp = ck[(k0, s0)]
     t = (15 * k0 + s0) * DT
     y = bridge.to_wte(y_d, t)
