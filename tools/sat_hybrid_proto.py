@@ -247,20 +247,14 @@ class Hybrid(SwRK):
             th, kind, p, c, a, b = best
             if kind not in ("freeze",) and th > 0:
                 lo, flo, hi, fhi = 0.0, a, 1.0, b
-                side = 0
-                for _ in range(12):                                   # regula falsi, Illinois variant (a slow approach is convex)
+                for it in range(60):                                  # secant and bisection in turns: the bracket ends below 0.1 us
                     yt = self.etd(y, t, hh * th, inp, modes0, self.xmask_of(y))
                     val = self.event_value(kind, p, c, y, yt, t + hh * th, inp)
-                    if val > 0:
-                        hi, fhi = th, val
-                        if side == 1: flo *= 0.5
-                        side = 1
-                    else:
-                        lo, flo = th, val
-                        if side == -1: fhi *= 0.5
-                        side = -1
-                    if (hi - lo) * hh < 2e-7: break
-                    th = lo + (hi - lo) * (-flo) / (fhi - flo)
+                    if val > 0: hi, fhi = th, val
+                    else: lo, flo = th, val
+                    if (hi - lo) * hh < 1e-7: break
+                    th = lo + (hi - lo) * (-flo) / (fhi - flo) if it % 2 else 0.5 * (lo + hi)
+                    th = min(max(th, lo + 0.02 * (hi - lo)), hi - 0.02 * (hi - lo))
                 th = hi
                 # end on the FAR side of the crossing (the event has happened there: what handles it must see it), a hair beyond the
                 # secant's estimate or at the bracket's upper end
@@ -408,7 +402,7 @@ class HybridMicro(Hybrid):
 
     hmic = 0.25e-6
     tau_about = 20e-6            # a held component that will be released within this time keeps the micro-integration going
-    max_micro = 4000
+    max_micro = 20000
 
     def settle(self, y, t, inp, p, why="", trust_u=False):
         m, K = self.m, self.K
@@ -582,7 +576,7 @@ def load_ck(e=1):
     return pickle.load(open(os.path.join(ROOT, ".scratch", "sub_e%d.pkl" % e), "rb"))
 
 
-def window_test(k0, s0, k1, s1, nsteps_per_sub=1, verbose=True, e=1):
+def window_test(k0, s0, k1, s1, nsteps_per_sub=1, verbose=True, e=int(os.environ.get("ENV", "1"))):
     """start from the golden state at (env step k0, sim step s0) with modes from the oracle's regions, integrate to (k1, s1), compare"""
     from oracle import bridge
     ck = load_ck(e)
