@@ -219,8 +219,8 @@ class Hybrid(SwRK):
                             continue                                # clamped at zero: stays while saturated
                         sg = np.sign(u0[c])
                         a, b = -D0[p][c] * sg, -D1[p][c] * sg
-                        if a >= 0 and self.last_impact == (p, c, t):
-                            continue                                # it has just been frozen ON h_c = 0
+                        if a >= 0 and (self.last_impact == (p, c, t) or getattr(self, "last_settle", {}).get(p) == t):
+                            continue                                # it has just been frozen ON h_c = 0 / the phase has just been settled
                         if b > 0 or a > 1e-9:
                             if 0 <= a <= 1e-9:   # h_c = 0 at the start (just impacted): an impact only if falling
                                 de0, _ = self.demand_rate(y, t, inp, f0, p)
@@ -409,9 +409,12 @@ class HybridMicro(Hybrid):
         lim2 = m.m_limit ** 2
         f, D = self.demand(y, t, inp)
         if trust_u:
-            # a phase that arrives from a LARGE free step carries its current to 1e-5 -- nothing for the current, a demand of K 1e-5 =
-            # 0.06 in m for the low-pass state.  On the slow manifold D = (du/dt) / wp ~ 1e-9: put the current there.
-            y[6 * p] += D[p][0]; y[6 * p + 1] += D[p][1]
+            # an axis that arrives from a LARGE step with its loop closed (a free phase; the regulating axis of a saturated one) carries
+            # its current to 1e-5 -- nothing for the current, a demand of K 1e-5 = 0.06 in m for the low-pass state.  On the slow
+            # manifold D = (du/dt) / wp ~ 1e-9: put the current there.
+            for c in range(2):
+                if not (self.modes[p] >> c) & 1:
+                    y[6 * p + c] += D[p][c]
             f, D = self.demand(y, t, inp)
         de0, o = self.demand_rate(y, t, inp, f, p)
         x, u0 = self.xu(y, p)
@@ -459,7 +462,7 @@ class HybridMicro(Hybrid):
             Dp = de0 + Ge @ (u - u0) - up
             return up, Dp
 
-        n, quiet = 0, 0
+        n, quiet, elapsed = 0, 0, 0.0
         while n < self.max_micro:
             reg, G = decide(u, Dm)
             up1, Dp1 = field(u, Dm, reg)
@@ -475,6 +478,8 @@ class HybridMicro(Hybrid):
                 if quiet >= 2: break
             else:
                 quiet = 0
+            # a component that moves fast (a violent release: r ~ 50 /s) takes the step in pieces: K |du| <= 1e-3 per micro step
+            h = self.hmic / max(1.0, np.ceil(K * np.abs(up1).max() * self.hmic / 1e-3))
             up2, Dp2 = field(u + 0.5 * h * up1, Dm + 0.5 * h * Dp1, reg)
             up3, Dp3 = field(u + 0.5 * h * up2, Dm + 0.5 * h * Dp2, reg)
             up4, Dp4 = field(u + h * up3, Dm + h * Dp3, reg)
@@ -507,19 +512,31 @@ class HybridMicro(Hybrid):
                 if gr @ gr > 0: un = un - sv * gr / (gr @ gr)
             u, Dm = un, Dn_
             n += 1
+            elapsed += th * h
         # the current moved by what the demand did not account for: e = D + u
         de_total = (Dm + u) - (D[p] + u0)
         y[6 * p + 4], y[6 * p + 5] = u
-        y[6 * p] += (de0[0] + f[6 * p]) * n * h - de_total[0]              # d i = d iref - d e
-        y[6 * p + 1] += (de0[1] + f[6 * p + 1]) * n * h - de_total[1]
+        y[6 * p] += (de0[0] + f[6 * p]) * elapsed - de_total[0]              # d i = d iref - d e
+        y[6 * p + 1] += (de0[1] + f[6 * p + 1]) * elapsed - de_total[1]
         # classification for the macro step
         reg, G = decide(u, Dm)
         md = 0
         if reg != 0:
+            up1, Dp1 = field(u, Dm, reg)
             for c in range(2):
-                if G[c]: md |= 1 << c
+                if not G[c]:
+                    continue
+                # held -- unless it sits ON its release surface with the demand still falling: it regulates (the impacts' Zeno limit;
+                # the macro step carries it with its loop closed and freezes it when it turns outward)
+                sg = np.sign(u[c])
+                if u[c] != 0.0 and K * abs(Dm[c]) < 1e-4 and Dp1[c] * sg < 0:
+                    self.ev["contact"] += 1
+                    continue
+                md |= 1 << c
         self.modes[p] = md
         self.sat[p] = reg != 0
+        if not hasattr(self, "last_settle"): self.last_settle = {}
+        self.last_settle[p] = t
         self.ev["settle"] = self.ev.get("settle", 0) + 1
         self.ev["micro"] = self.ev.get("micro", 0) + n
         if self.verbose:
@@ -554,13 +571,13 @@ class HybridMicro(Hybrid):
             y[6 * p + 4 + c] = 0.0
             self.modes[p] |= 1 << c
             return
-        self.settle(y, t, inp, p, kind + " axis %d" % c, trust_u=(kind == "entry"))
+        self.settle(y, t, inp, p, kind + " axis %d" % c, trust_u=True)
         self.last_impact = (p, c, t)
 
     def after_step(self, y, t, inp, exclude=(-1, -1)):
         for p in range(3):
             if self.sat[p] and self.s_of(y, p) < -1e-12:
-                self.settle(y, t, inp, p, "inside the limit behind a step")
+                self.settle(y, t, inp, p, "inside the limit behind a step", trust_u=True)
 
 
 def ramp_test(env=1, steps=160, quiet=1, verbose=False, cls=None):
