@@ -554,12 +554,26 @@ class HybridMicro(Hybrid):
                 rel = any(((self.modes[p] >> c) & 1) and u[c] != 0.0 and -D[p][c] * np.sign(u[c]) > 1e-9 for c in range(2))
                 if rel: self.settle(y, t, inp, p, "released by an input jump")
                 continue
-            if self.K * np.hypot(*D[p]) < 0.5:       # (an action moves K iref by 7; what a large free step leaves: K 1e-5)
+            # where the phase's closed loop is heading: the rest point of the fast pair, D = 0 and dD/dt = 0 -- an action moves D by
+            # 0.0012 (K D = 7), a grid-voltage event moves de/dt by g dm_needed.  Beyond the limit: the phase is about to enter and
+            # stay -- the fast pair takes it there (an entry within microseconds, which a large free step cannot locate)
+            if self.K * np.hypot(*D[p]) < 1e-3 * 0 + 0.0 and False:
                 continue
-            mv = x + self.K * (u + D[p])
-            if mv @ mv <= lim2 or mm @ mm < lim2 * (1.0 - self.jump_margin):
+            de0, o = self.demand_rate(y, t, inp, f, p)
+            jump = self.K * np.hypot(*D[p]) > 0.5 or np.hypot(*de0) > 0.5
+            if not jump:
+                continue                      # (a slow approach: the entry is located inside the step as usual)
+            # where the phase ENDS once its current has caught up (0.05 - 1 ms): the duty cycle that holds the current on its new
+            # reference.  Inside the limit: the phase visits the limit and leaves again, which costs 1e-5 to ignore; at or beyond it:
+            # the phase enters now and stays
+            g = o.Vdc / (2.0 * self.m.Lf)
+            y2 = y.copy()
+            y2[6 * p] += D[p][0]; y2[6 * p + 1] += D[p][1]               # i := iref - u
+            f2 = self.f_free(y2, t, inp)
+            mq = x + self.K * u - np.array([f2[6 * p], f2[6 * p + 1]]) / g
+            if mq @ mq <= lim2 * (1.0 - self.jump_margin):
                 continue
-            self.settle(y, t, inp, p, "input jump near the limit")
+            self.settle(y, t, inp, p, "input jump that ends beyond the limit")
 
     def apply_event(self, kind, p, c, y, t, inp, at_start=False):
         self.ev[kind] += 1
