@@ -220,7 +220,11 @@ class Hybrid(SwRK):
                         sg = np.sign(u0[c])
                         a, b = -D0[p][c] * sg, -D1[p][c] * sg
                         if a >= 0 and (self.last_impact == (p, c, t) or getattr(self, "last_settle", {}).get(p) == t):
-                            continue                                # it has just been frozen ON h_c = 0 / the phase has just been settled
+                            # it has just been frozen ON h_c = 0 / the phase has just been settled: no second release at this
+                            # instant -- but it may well come back later in the step
+                            if b <= 0:
+                                continue
+                            a = -1e-30
                         if b > 0 or a > 1e-9:
                             if 0 <= a <= 1e-9:   # h_c = 0 at the start (just impacted): an impact only if falling
                                 de0, _ = self.demand_rate(y, t, inp, f0, p)
