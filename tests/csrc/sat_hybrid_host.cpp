@@ -1,0 +1,15 @@
+// TEST HARNESS (tests/ only): gym-solarpvder-environment_amd/csrc/pvder_sat_hybrid.hpp compiled for the HOST with g++ -- the very
+// source the step kernels' 23-state tail runs on the device for envs at the duty-cycle limit -- behind a C entry point, so that
+// tests/test_sat_hybrid_host.py can drive it through the action-4 episodes against the converged golden without a GPU.
+#include "pvder_sat_hybrid.hpp"
+
+extern "C" int sat_hybrid_env_step_host(const double *k /* HybK, 23 doubles in declaration order */, double *y, double qref, double vdcref,
+                                        const double *vg, const double *si, int n_sub, int first_div, int *stats /* 4 */) {
+    pvder::hyb::HybK P;
+    double *dst = reinterpret_cast<double *>(&P);
+    for (int j = 0; j < (int)(sizeof(P) / sizeof(double)); ++j) dst[j] = k[j];
+    pvder::hyb::Stats st;
+    pvder::hyb::env_step(P, y, qref, vdcref, vg, si, n_sub, first_div, &st);
+    if (stats) { stats[0] = st.settles; stats[1] = st.micro; stats[2] = st.events; stats[3] = st.capped; }
+    return (int)(sizeof(P) / sizeof(double));
+}
