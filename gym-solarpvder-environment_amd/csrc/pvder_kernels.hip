@@ -38,6 +38,7 @@
 #include "pvder_model.hpp"
 #include "pvder_model_pk.hpp"
 #include "pvder_etdlin.hpp"
+#include "pvder_sat_hybrid.hpp"
 #include "pvder_agent.h"
 #include "pvder_agent_dev.hpp"
 
@@ -659,6 +660,9 @@ struct EtdArgs {
     int n_env;
     int force_full;          // A/B and tests: every env takes the 23-state path
     int rk4_fallback;        // A/B and tests: steps at the duty-cycle limit by classic RK4 micro-steps (round 2's way)
+    int sat_hybrid;          // 1 (set per launch): step_sat_hybrid_kernel follows this launch -- the 23-state tail hands it the envs at /
+                             // near the duty-cycle limit (status kDeferred) instead of stepping them on the held operator sets
+    int *hyb_flag;           // device-addressable HOST word: written 1 by a workgroup that meets an env beyond kHybFlag2 (auto mode)
     int ph1_micro;           // single phase: classic RK4 micro-steps per sim time step of the envs the fast path hands over
                              // (8192: poles at 1.0e6 rad/s) -- the tail of the step kernel (rk4_tail_1ph)
 };
@@ -1194,6 +1198,12 @@ typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
 // LP (step_etdrk4_lane_kernel): every env with its OWN values of the parameters that stay outside the exponential operator
 // (lane_par: [PVDER_LPF_ROWS][n_env] folded constants, pvder_fold_lane_params) -- the lane's ModelK is the launch's with
 // those seven fields replaced (VGPRs instead of SGPRs); stats_fresh: this pass starts the step's statistics.
+// ---- envs at / near the duty-cycle limit (round 6): the hybrid scheme of pvder_sat_hybrid.hpp, in a kernel of its own behind the step
+// kernel -- fp64, 6 KB of private arrays per lane: inside the step kernels it would cost every launch their occupancy and a scratch ring.
+constexpr float kHybNear2 = 0.95f * 0.95f;          // an env of the 23-state tail with |m_p|^2 beyond this fraction of the limit's: hybrid
+constexpr int kHybMaxSub = 64;
+constexpr int kHybHoldLaunches = 256;               // auto mode: the hybrid kernel follows this many step launches behind the last sighting
+
 template <bool LP = false, bool T3 = false>
 __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, const uint8_t *act = nullptr,
                                                  long long out_off = 0, const float *__restrict__ lane_par = nullptr,
@@ -1258,8 +1268,27 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
     // time only.  (Side by side they need 16 registers more than the 256 two waves per SIMD leave each -- spilled into the
     // kernel's entry block, 7.65 -> 8.16 us on the standard path: hence a kernel of its own, one wave per SIMD, where they
     // sit in AGPRs: profiles/r04_ab_tail3_in_step_kernel.txt.)
+    // (sat_hybrid: an env at / near the duty-cycle limit is NOT stepped here -- step_sat_hybrid_kernel, which follows this launch,
+    //  takes it: marked kDeferred by the lane-per-env form below, which a workgroup that holds such an env therefore takes)
+    bool any_hyb = false;
     if constexpr (T3 && !LP) {
-        if (n_def <= kBlock / 4) {
+        if (A.sat_hybrid && n_def <= kBlock / 4) {
+            const int q = (int)(threadIdx.x >> 2), ph = (int)(threadIdx.x & 3);
+            bool near = false;
+            if (q < n_def && ph < 3) {
+                const size_t e = (size_t)(blockIdx.x * kBlock) + (size_t)packed[q];
+                if (e < N && istate[(size_t)PVDER_I_STATUS * N + e] == 0) {
+                    const float xr = fstate[(size_t)(6 * ph + 2) * N + e], xi = fstate[(size_t)(6 * ph + 3) * N + e];
+                    const float ur = fstate[(size_t)(6 * ph + 4) * N + e], ui = fstate[(size_t)(6 * ph + 5) * N + e];
+                    const float mr = __builtin_fmaf(P0.KpG, ur, xr), mi = __builtin_fmaf(P0.KpG, ui, xi);
+                    near = __builtin_fmaf(mi, mi, mr * mr) > kHybNear2 * P0.mlim2;
+                }
+            }
+            any_hyb = __syncthreads_or((int)near) != 0;
+        }
+    }
+    if constexpr (T3 && !LP) {
+        if (n_def <= kBlock / 4 && !any_hyb) {
             const int q = (int)(threadIdx.x >> 2);
             etd_tail3<false>(A, Msw, (int)(blockIdx.x * kBlock) + (q < n_def ? packed[q] : (int)threadIdx.x), q < n_def, nullptr, stats,
                              stats_fresh, action, out);
@@ -1287,6 +1316,19 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
 #if defined(PVDER_TRACE) && defined(PVDER_TRACE_COLD)
     const unsigned long long trc_c0 = clock64(), trc_w0 = wall_clock64();      // (shader cycles / 100 MHz wall clock at the loop's start)
 #endif
+    if (A.sat_hybrid && L.run) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float mr = __builtin_fmaf(P.KpG, ys[6 * p + 4], ys[6 * p + 2]), mi = __builtin_fmaf(P.KpG, ys[6 * p + 5], ys[6 * p + 3]);
+            m2 = fmaxf(m2, __builtin_fmaf(mi, mi, mr * mr));
+        }
+        if (m2 > kHybNear2 * P.mlim2) {
+            istate[(size_t)PVDER_I_STATUS * N + L.e] = kDeferred;        // step_sat_hybrid_kernel advances it (this launch stores nothing of it)
+            L.run = false;
+            L.live = false;
+        }
+    }
     if (L.run) {
         v2 y[NP], comp[NP];
         to_pairs(ys, y);
@@ -1469,6 +1511,52 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
 __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const uint8_t *act = nullptr, long long out_off = 0) {
     rk4_body<float, 1>(A.P, A.C, A.ph1_micro, A.R, A.fstate, A.istate, A.ev_vg, A.ev_si, act ? act : A.action, A.out + out_off,
                        A.stats, A.n_env, 0, 0, true, defer);
+}
+
+// The follow-up launch of the step kernels (etdlin, ETDRK4; three-phase): advances the envs their 23-state tail marked kDeferred --
+// envs at / near the duty-cycle limit -- by ONE env step of the hybrid scheme (pvder_sat_hybrid.hpp::env_step: fp64 between the fp32
+// rows), then the same epilogue as every step kernel (reward, done, observation, same-step auto-reset, statistics added to the
+// step's).  A workgroup without such an env returns at once.
+__global__ __launch_bounds__(kBlock) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par) {
+    using namespace pvder::hyb;
+    const int n_env = A.n_env;
+    const size_t N = (size_t)n_env;
+    {
+        const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
+        const bool mine = e < n_env && A.istate[(size_t)PVDER_I_STATUS * N + (size_t)e] == kDeferred;
+        if (!__syncthreads_or((int)mine)) return;
+    }
+    Lane<float> L;
+    float ys[23];
+    prologue<float, 23>(A.C, A.fstate, A.istate, A.action, n_env, L, ys, kDeferred);
+    ModelK<float> P = A.P;
+    if (lane_par) {
+        const float *__restrict__ lp = lane_par + L.ec;
+        P.iC = lp[(size_t)PVDER_LPF_IC * N];
+        P.KpDC = lp[(size_t)PVDER_LPF_KP_DC * N]; P.KiDC = lp[(size_t)PVDER_LPF_KI_DC * N];
+        P.KpQ = lp[(size_t)PVDER_LPF_KP_Q * N];   P.KiQ = lp[(size_t)PVDER_LPF_KI_Q * N];
+        P.pvA = lp[(size_t)PVDER_LPF_PVA * N];    P.pvB = lp[(size_t)PVDER_LPF_PVB * N];
+    }
+    if (L.run) {
+        const StepK<float> &C = A.C;
+        HybK H;
+        H.Rf = P.Rf; H.iLf = P.iLf; H.iC = P.iC; H.kviR = P.kviR; H.kviI = P.kviI; H.GR = P.GR; H.GI = P.GI; H.KpG = P.KpG; H.KiG = P.KiG;
+        H.KpDC = P.KpDC; H.KiDC = P.KiDC; H.KpQ = P.KpQ; H.KiQ = P.KiQ; H.wp = P.wp; H.KpP = P.KpP; H.KiP = P.KiP; H.mlim2 = P.mlim2;
+        H.ilim2 = P.ilim2; H.iwb = P.iwb; H.pvA = P.pvA; H.pvB = P.pvB; H.pvK = P.pvK; H.vdc_ref0 = P.vdc_ref0;
+        double y[23], vg[kHybMaxSub], si[kHybMaxSub];
+        for (int k = 0; k < 23; ++k) y[k] = (double)ys[k];
+        const int n_sub = C.n_sub < kHybMaxSub ? C.n_sub : kHybMaxSub;      // (plans with longer env steps never set sat_hybrid)
+        for (int s = 0; s < n_sub; ++s) {
+            const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
+            vg[s] = (double)A.ev_vg[(size_t)row * N + L.ec];
+            si[s] = (double)A.ev_si[(size_t)row * N + L.ec];
+        }
+        env_step(H, y, (double)L.qref, (double)L.vdcref, vg, si, n_sub, C.graded ? C.micro : 1, nullptr);
+        for (int k = 0; k < 23; ++k) ys[k] = (float)y[k];
+        L.ksub += C.n_sub;
+        L.steps += 1;
+    }
+    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats, n_env, 0, false, 0.f, 0.f, lane_par);
 }
 
 // =============================================================================================
@@ -4166,6 +4254,10 @@ struct pvder_plan {
     const float *lane_par;           // etdrk4 / etdlin: [PVDER_LPF_ROWS][n_env] folded per-lane constants (pvder_plan_lane_params), or NULL
     const float *k4lane = nullptr;   // etdlin: the two Krogstad blocks of step_etdlin_lane_kernel (pvder_lin_coef.k4 & 2), or NULL
     int lane_steps = 2;              // ... and the Krogstad steps per env step they were folded for (pvder_lin_coef.k4 bits 8-15; 0 = 2)
+    int hyb_mode = 0;                // pvder_step_cfg.off_range: 0 = the hybrid kernel when an env comes near the duty-cycle limit (auto),
+                                     // 1 = terminate, 2 = held operator sets (rounds 3-5), 3 = the hybrid kernel behind EVERY step launch
+    int *hyb_flag_host = nullptr;    // auto: pinned host word the step kernels write when an env comes near the limit
+    mutable int hyb_hold = 0;        // auto: step launches the hybrid kernel still follows (re-armed whenever the flag is seen)
     bool graph_hints = false;        // pvder_plan_graph_hints: a CAPTURED pvder_plan_rollout keeps the clock hints it was captured with
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
@@ -4175,6 +4267,7 @@ struct pvder_plan {
     mutable hipStream_t chain_stream = nullptr;
     mutable hipEvent_t chain_fork = nullptr, chain_join = nullptr;
     ~pvder_plan() {
+        if (hyb_flag_host) (void)hipHostFree(hyb_flag_host);
         if (chain) (void)hipFree(chain);
         if (chain_fork) (void)hipEventDestroy(chain_fork);
         if (chain_join) (void)hipEventDestroy(chain_join);
@@ -4234,9 +4327,16 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
     A.coef = coef;
     A.n_env = n_env;
     // PVDER_ETD_VARIANT=full / cfg->reserved bit 0 send every env down the 23-state path (A/B, tests)
+    p.hyb_mode = cfg->off_range;
+    if (const char *v = getenv("PVDER_SAT_HYBRID")) {                  // (A/B: 0 = held operator sets, 3 = the hybrid kernel always)
+        if (v[0] == '0' && p.hyb_mode != PVDER_OFF_RANGE_TERMINATE) p.hyb_mode = 2;
+        if (v[0] == '3' && p.hyb_mode != PVDER_OFF_RANGE_TERMINATE) p.hyb_mode = 3;
+    }
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
     A.rk4_fallback = (cfg->reserved & 2) ? 1 : 0;
+    A.sat_hybrid = 0;                // (set per launch: launch_plan)
+    A.hyb_flag = nullptr;
     A.ph1_micro = p.C4.micro;
     if (integrator == PVDER_INT_ETDLIN) {
         if (!lin || !lin->sets || !lin->sched || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
@@ -4319,6 +4419,20 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         EtdArgs &A = G.A;
         A.fstate = (float *)fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
         A.action = action; A.out = (float *)out; A.stats = stats; A.stats_fresh = fresh;
+        // the hybrid kernel behind this launch? (hyb_mode 3: always; 0: while an env is, or lately was, near the duty-cycle limit)
+        bool hyb = false;
+        if (p.ph == 3 && p.n_sub <= kHybMaxSub && (p.hyb_mode == 0 || p.hyb_mode == 3)) {
+            if (p.hyb_mode == 3) hyb = true;
+            else {
+                if (p.hyb_flag_host && __atomic_load_n(p.hyb_flag_host, __ATOMIC_RELAXED) != 0) {
+                    __atomic_store_n(p.hyb_flag_host, 0, __ATOMIC_RELAXED);
+                    p.hyb_hold = kHybHoldLaunches;
+                }
+                hyb = p.hyb_hold > 0;
+                if (p.hyb_hold > 0) --p.hyb_hold;
+            }
+        }
+        A.sat_hybrid = hyb ? 1 : 0;
         // ONE launch -- the fast path, whose workgroups themselves run the 23-state path (three-phase) / classic RK4
         // micro-steps, 8192 per 1/60 s (single phase: the "balanced" kernel IS the model) for the envs they must defer
         // (none in PVDER-v0 rollouts).
@@ -4355,6 +4469,7 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             else if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
         }
+        if (hyb) hipLaunchKernelGGL(step_sat_hybrid_kernel, grid, block, 0, st, A, p.lane_par);
         break;
     }
     case PVDER_INT_RK4: {

@@ -34,6 +34,8 @@ DEFAULT_MICRO = {"etdlin": 32, "etdrk4": 32, "rk4": 4096, "rk45": 1, "etdlin64":
 # ETDRK4 step schedule: a sim time step that starts at an input jump (new action / event) takes a first
 # step of 1/(60*micro) s and one more over the remainder (graded), every other one DEFAULT_MICRO_COARSE
 DEFAULT_MICRO_COARSE = 1
+# pvder_step_cfg.off_range (include/pvder_hip.h): what happens to an env at the duty-cycle limit
+OFF_RANGE = {"integrate": 0, "terminate": 1, "held_modes": 2, "integrate_always": 3}
 # etdlin lane path: validated range of (Np / group Np) x Sinsol_scale (profiles/r05_lane_etdlin_envelope.txt)
 LANE_OP_RANGE = (0.8, 1.0)
 
@@ -184,8 +186,8 @@ class PVDERVec(EnvSpecMixin):
         its slowest workgroup; bench.py `fixed_policy`) -- or its episode ``"terminate"``s (done, reward -100, the reference's
         failure branch PVDER_env.py:169-172).  Envs at the CURRENT limit are not off range: they stay on the
         matrix-core path (careful pass) and are never terminated."""
-        if off_range not in ("integrate", "terminate"):
-            raise ValueError("off_range must be 'integrate' or 'terminate'")
+        if off_range not in OFF_RANGE:
+            raise ValueError("off_range must be one of %s" % (sorted(OFF_RANGE),))
         self.off_range = off_range
         if not isinstance(num_envs, int) or num_envs < 1:
             raise ValueError("num_envs must be a positive integer")
@@ -497,7 +499,7 @@ class PVDERVec(EnvSpecMixin):
         c.q_target = self.env_reward_spec['reference_values']['Q_ref'] / der_model.SBASE   # :241
         c.rtol, c.atol = self.rtol, self.atol
         c.reserved = self._debug_knob
-        c.off_range = 1 if self.off_range == "terminate" else 0
+        c.off_range = OFF_RANGE[self.off_range]
         # reward types beyond the goal's required one: env_goal_spec[goal]['reward']['my_spec'] (:249; the
         # reference only ever fills it with the 'required' list, :448-452 -- its update path is "under
         # construction", :454-456 -- but reward_calc honours whatever it holds)
