@@ -621,6 +621,8 @@ struct EtdK {
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
+    float sat2_flag;        // (0.93 m_limit)^2: beyond it an env leaves the LEAN pass (same arithmetic in the second pass, which raises
+                            // the plan's hybrid flag: the hybrid kernel is then in place well before the duty cycle saturates)
     int rk4_sub[3];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
     float hset[3];          // step sizes [s]: 1/(60 micro), 1/(60 micro_coarse), (1 - 1/micro)/60
     float i2_to_m2;         // balanced kernel: |iref|^2 * i2_to_m2 > guard  <=>  |iref| within 10 % of its limit
@@ -1328,6 +1330,16 @@ __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, c
             L.run = false;
             L.live = false;
         }
+    } else if (A.hyb_flag && L.run) {
+        // (the hybrid kernel does not follow this launch, yet here is an env that wants it -- an event took it to the limit
+        //  in one step: this one step on the held operator sets, and the flag)
+        float m2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float mr = __builtin_fmaf(P.KpG, ys[6 * p + 4], ys[6 * p + 2]), mi = __builtin_fmaf(P.KpG, ys[6 * p + 5], ys[6 * p + 3]);
+            m2 = fmaxf(m2, __builtin_fmaf(mi, mi, mr * mr));
+        }
+        if (m2 > Ec.sat2_flag) *(volatile int *)A.hyb_flag = 1;
     }
     if (L.run) {
         v2 y[NP], comp[NP];
@@ -2077,7 +2089,7 @@ __device__ __forceinline__ void lin_to_rows(const pvder::v4f (&Y)[3], float *ys)
 // must be handed to the 23-state path (|m| guard at the start, the middle -- stage a --, the end of the step;
 // embedded error indicator, |m| beyond the hard guard); near_ilim: |iref| at the start of the step is within 5 % of the
 // current limit, or |m| beyond the smooth-step guard at the start, middle or end (careful pass)
-template <int PH>
+template <int PH, bool LEAN = false>
 __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSetRegs &Ac, const pvder::v4f (&Y)[3],
                                            const pvder::SubPk &S, float qref, float vdcref, v2 kpo, v2 kio, float irg,
                                            float msc, pvder::v4f (&Yn)[3], bool traced, bool &near_ilim) {
@@ -2119,7 +2131,7 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
     // (msc: 1, or the (1 + r)^2 of an env carried by its positive-sequence component, lin_seq_split)
     const float mmax = msc * fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
     // the current reference or the duty cycle comes near its limit: the careful pass redoes the env step
-    near_ilim = ir2a > irg || mmax > Ec.sat2_smooth;
+    near_ilim = ir2a > irg || mmax > (LEAN ? Ec.sat2_flag : Ec.sat2_smooth);
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -2182,7 +2194,7 @@ __device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs 
                             fabsf(Yn[1].z - acc2[0][1].z));
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     const float mmax = msc * fmaxf(fmaxf(fmaxf(m2a, m2x), fmaxf(m2y, m2b)), __builtin_fmaf(mn.y, mn.y, mn.x * mn.x));
-    near_ilim = ir2a > irg || ir2y > irg || mmax > Ec.sat2_smooth;
+    near_ilim = ir2a > irg || ir2y > irg || mmax > (EARLY ? Ec.sat2_smooth : Ec.sat2_flag);     // (EARLY = the second pass)
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -2320,7 +2332,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
             bool trip = pk2 > G.Lk.sat2_hard;
             if (run) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
-                else defer |= pk2 > Ec.sat2_smooth || ir2a > irg;
+                else defer |= pk2 > Ec.sat2_flag || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
             }
             // (a wave whose envs all sit at the current limit -- a policy that holds one Q_ref action -- goes
@@ -2343,7 +2355,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
                 if (trace_step == 0 && st == 1) PVDER_TRACE_AT(4);
                 v4f Yn[3];
                 bool near;
-                trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, trace_step == 0 && st == 1, near);
+                trip = lin_etd3rk<PH, !SPLIT>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, trace_step == 0 && st == 1, near);
                 if (run) {
                     if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                     Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -2373,7 +2385,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
             const bool trip = pk2 > G.Lk.sat2_hard;
             if (start && !done) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
-                else defer |= pk2 > Ec.sat2_smooth || ir2a > irg;
+                else defer |= pk2 > Ec.sat2_flag || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 start = false;
             }
@@ -2388,7 +2400,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
         if (__builtin_amdgcn_readfirstlane(__any((int)(todo && sidx != cur))) == 0) {
             v4f Yn[3];
             bool near;
-            const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, trace_step == 0 && it == 1, near);
+            const bool trip = lin_etd3rk<PH, !SPLIT>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, trace_step == 0 && it == 1, near);
             if (todo) {
                 if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                 Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -2405,7 +2417,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
                 }
                 v4f Yn[3];
                 bool near;
-                const bool trip = lin_etd3rk<PH>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, false, near);
+                const bool trip = lin_etd3rk<PH, !SPLIT>(G, Ac, Y, S, qref, vdcref, kpo, kio, irg, msc, Yn, false, near);
                 if (todo && sidx == s_now) {
                     if constexpr (SPLIT) { careful |= near; defer |= trip && !careful; } else defer |= trip || near;
                     Y[0] = Yn[0]; Y[1] = Yn[1]; Y[2] = Yn[2];
@@ -2784,6 +2796,19 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
     else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
     const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
     PVDER_TRACE_AT(1);
+    if constexpr (PH == 3) {
+        // an env whose duty cycle is beyond 93 % of its limit: the plan's hybrid flag (a word of pinned HOST memory; the next step
+        // launches are followed by step_sat_hybrid_kernel -- in place well before an env saturates: sat2_flag)
+        if (A.hyb_flag && L.run) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float mr = __builtin_fmaf(A.P.KpG, ys[6 * p + 4], ys[6 * p + 2]), mi = __builtin_fmaf(A.P.KpG, ys[6 * p + 5], ys[6 * p + 3]);
+                m2 = fmaxf(m2, __builtin_fmaf(mi, mi, mr * mr));
+            }
+            if (m2 > A.Ec.sat2_flag) *(volatile int *)A.hyb_flag = 1;
+        }
+    }
     bool defer = PH == 3 && A.force_full != 0;
     bool seq = false;                   // off balance, carried by its positive-sequence component (lin_seq_split)
     float msc = 1.f;
@@ -3132,7 +3157,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
                 lin_mfma1(At, F, acc);
                 const float pk2 = lin_tick_peak2(Pl, Y, acc, m2a);
                 if (mine) {
-                    leave |= pk2 > A.Ec.sat2_smooth || ir2a > irg;
+                    leave |= pk2 > A.Ec.sat2_flag || ir2a > irg;
                     Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 }
             }
@@ -4178,6 +4203,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float 
     const double ge = 0.97 * par[PVDER_PAR_M_LIMIT], gs = 0.998 * par[PVDER_PAR_M_LIMIT];
     E.sat2_event = (float)(ge * ge);
     E.sat2_smooth = (float)(gs * gs);
+    E.sat2_flag = (float)(0.93 * 0.93 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
     E.i2_to_m2 = (float)(ge * ge / (0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]));
     return E;
 }
@@ -4332,11 +4358,21 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         if (v[0] == '0' && p.hyb_mode != PVDER_OFF_RANGE_TERMINATE) p.hyb_mode = 2;
         if (v[0] == '3' && p.hyb_mode != PVDER_OFF_RANGE_TERMINATE) p.hyb_mode = 3;
     }
+    A.hyb_flag = nullptr;
+    if (p.hyb_mode == 0 && p.ph == 3 && cfg->n_sub <= kHybMaxSub) {
+        void *dev = nullptr;
+        if (hipHostMalloc((void **)&p.hyb_flag_host, 64, hipHostMallocMapped) != hipSuccess || !p.hyb_flag_host
+            || hipHostGetDevicePointer(&dev, p.hyb_flag_host, 0) != hipSuccess || !dev) {
+            (void)hipGetLastError();
+            return PVDER_EINVAL;
+        }
+        *p.hyb_flag_host = 0;
+        A.hyb_flag = (int *)dev;
+    }
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
     A.rk4_fallback = (cfg->reserved & 2) ? 1 : 0;
     A.sat_hybrid = 0;                // (set per launch: launch_plan)
-    A.hyb_flag = nullptr;
     A.ph1_micro = p.C4.micro;
     if (integrator == PVDER_INT_ETDLIN) {
         if (!lin || !lin->sets || !lin->sched || lin->n_sets < 2 || lin->n_sets > pvder::kLinMaxSets) return PVDER_EINVAL;
