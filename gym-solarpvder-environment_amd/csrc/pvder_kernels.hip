@@ -1203,7 +1203,7 @@ typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
 // ---- envs at / near the duty-cycle limit (round 6): the hybrid scheme of pvder_sat_hybrid.hpp, in a kernel of its own behind the step
 // kernel -- fp64, 6 KB of private arrays per lane: inside the step kernels it would cost every launch their occupancy and a scratch ring.
 constexpr float kHybNear2 = 0.95f * 0.95f;          // an env of the 23-state tail with |m_p|^2 beyond this fraction of the limit's: hybrid
-constexpr int kHybMaxSub = 64;
+constexpr int kHybMaxSub = 16;                      // sim time steps per env step the hybrid kernel takes (PVDER-v0: 15)
 constexpr int kHybHoldLaunches = 256;               // auto mode: the hybrid kernel follows this many step launches behind the last sighting
 
 template <bool LP = false, bool T3 = false>
@@ -1528,19 +1528,27 @@ __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const
 // The follow-up launch of the step kernels (etdlin, ETDRK4; three-phase): advances the envs their 23-state tail marked kDeferred --
 // envs at / near the duty-cycle limit -- by ONE env step of the hybrid scheme (pvder_sat_hybrid.hpp::env_step: fp64 between the fp32
 // rows), then the same epilogue as every step kernel (reward, done, observation, same-step auto-reset, statistics added to the
-// step's).  A workgroup without such an env returns at once.
-__global__ __launch_bounds__(kBlock) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par) {
+// step's).  64 lanes per workgroup, ONE env per lane, the scheme's twelve 23-vectors + the state in the lane's own 2.4 KB of LDS
+// (153 KB of the CU's 160: as private arrays they make a 6 KB scratch frame per lane, which the runtime serves by allocating scratch
+// per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  A workgroup without such an env returns at once.
+constexpr int kHybBlock = 64;
+constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
+constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
+__global__ __launch_bounds__(kHybBlock) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par) {
     using namespace pvder::hyb;
+    extern __shared__ __attribute__((aligned(16))) double hyb_lds[];
     const int n_env = A.n_env;
     const size_t N = (size_t)n_env;
+    const int e_mine = (int)(blockIdx.x * kHybBlock + threadIdx.x);
     {
-        const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
-        const bool mine = e < n_env && A.istate[(size_t)PVDER_I_STATUS * N + (size_t)e] == kDeferred;
+        const bool mine = e_mine < n_env && A.istate[(size_t)PVDER_I_STATUS * N + (size_t)e_mine] == kDeferred;
         if (!__syncthreads_or((int)mine)) return;
     }
     Lane<float> L;
     float ys[23];
-    prologue<float, 23>(A.C, A.fstate, A.istate, A.action, n_env, L, ys, kDeferred);
+    prologue<float, 23>(A.C, A.fstate, A.istate, A.action, n_env, L, ys, kDeferred, e_mine < n_env ? e_mine : n_env - 1);
+    L.live = L.live && e_mine < n_env;
+    L.run = L.run && e_mine < n_env;
     ModelK<float> P = A.P;
     if (lane_par) {
         const float *__restrict__ lp = lane_par + L.ec;
@@ -1555,20 +1563,24 @@ __global__ __launch_bounds__(kBlock) void step_sat_hybrid_kernel(const EtdArgs A
         H.Rf = P.Rf; H.iLf = P.iLf; H.iC = P.iC; H.kviR = P.kviR; H.kviI = P.kviI; H.GR = P.GR; H.GI = P.GI; H.KpG = P.KpG; H.KiG = P.KiG;
         H.KpDC = P.KpDC; H.KiDC = P.KiDC; H.KpQ = P.KpQ; H.KiQ = P.KiQ; H.wp = P.wp; H.KpP = P.KpP; H.KiP = P.KiP; H.mlim2 = P.mlim2;
         H.ilim2 = P.ilim2; H.iwb = P.iwb; H.pvA = P.pvA; H.pvB = P.pvB; H.pvK = P.pvK; H.vdc_ref0 = P.vdc_ref0;
-        double y[23], vg[kHybMaxSub], si[kHybMaxSub];
+        double *arena = hyb_lds + (size_t)threadIdx.x * kHybLaneDoubles;
+        double *y = arena + kArenaDoubles;
+        float *vg = (float *)(hyb_lds + (size_t)kHybBlock * kHybLaneDoubles) + (size_t)threadIdx.x * (2 * kHybMaxSub), *si = vg + kHybMaxSub;
         for (int k = 0; k < 23; ++k) y[k] = (double)ys[k];
         const int n_sub = C.n_sub < kHybMaxSub ? C.n_sub : kHybMaxSub;      // (plans with longer env steps never set sat_hybrid)
         for (int s = 0; s < n_sub; ++s) {
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
-            vg[s] = (double)A.ev_vg[(size_t)row * N + L.ec];
-            si[s] = (double)A.ev_si[(size_t)row * N + L.ec];
+            vg[s] = A.ev_vg[(size_t)row * N + L.ec];
+            si[s] = A.ev_si[(size_t)row * N + L.ec];
         }
-        env_step(H, y, (double)L.qref, (double)L.vdcref, vg, si, n_sub, C.graded ? C.micro : 1, nullptr);
+        env_step(H, y, (double)L.qref, (double)L.vdcref, vg, si, n_sub, C.graded ? C.micro : 1, (Stats *)nullptr, arena);
         for (int k = 0; k < 23; ++k) ys[k] = (float)y[k];
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats, n_env, 0, false, 0.f, 0.f, lane_par);
+    // (this workgroup IS wave e / 64 of the step kernels' numbering: its statistics slot)
+    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats ? A.stats + 4 * (size_t)blockIdx.x : nullptr,
+                       n_env, 0, false, 0.f, 0.f, lane_par, true);
 }
 
 // =============================================================================================
@@ -4508,7 +4520,17 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             else if (p.ph == 3) hipLaunchKernelGGL(step_etdrk4_bal_kernel<3>, grid, block, 0, st, A);
             else hipLaunchKernelGGL(step_etdrk4_bal_kernel<1>, grid, block, 0, st, A);
         }
-        if (hyb) hipLaunchKernelGGL(step_sat_hybrid_kernel, grid, block, 0, st, A, p.lane_par);
+        if (hyb) {
+            static size_t lds_ok[64] = {0};          // (beyond 64 KB of dynamic LDS the kernel has to be told: once per device)
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PVDER_EINVAL;
+            if (lds_ok[dev] < kHybLdsBytes) {
+                const hipError_t e = hipFuncSetAttribute((const void *)step_sat_hybrid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHybLdsBytes);
+                if (e != hipSuccess) return hip_rc(e);
+                lds_ok[dev] = kHybLdsBytes;
+            }
+            hipLaunchKernelGGL(step_sat_hybrid_kernel, dim3((n_env + kHybBlock - 1) / kHybBlock), dim3(kHybBlock), kHybLdsBytes, st, A, p.lane_par);
+        }
         break;
     }
     case PVDER_INT_RK4: {

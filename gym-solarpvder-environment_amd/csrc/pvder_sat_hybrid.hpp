@@ -50,6 +50,16 @@ struct Stats {                 // what an env step did (tests, counters)
     int settles, micro, events, capped;
 };
 
+// Every 23-vector the scheme needs at one time, as slots of ONE block the caller provides: on the device a lane's own stretch of LDS
+// (step_sat_hybrid_kernel: 64 lanes per workgroup, 2.4 KB each -- private arrays of this size would give the kernel a 6 KB scratch
+// frame per lane, which the runtime can only serve by allocating scratch per dispatch: 0.2 ms per LAUNCH), on the host an array.
+enum { A_N1 = 0, A_N2, A_N4, A_N5, A_YT, A_E2Y, A_EY, A_TMP, A_F0, A_F1, A_Y1, A_YT2, A_COUNT };
+constexpr int kArenaDoubles = A_COUNT * 23;
+struct Arena {
+    double *base;
+    PVDER_HD double *operator[](int k) const { return base + 23 * k; }
+};
+
 constexpr double kH3 = 0.86602540378443864676;
 constexpr double kTwoPiD = 6.283185307179586476925;
 
@@ -249,14 +259,15 @@ PVDER_HD inline void apply_phi(const Loop &L, const Phi &F, int k, int modes, co
     }
 }
 
-// one Hochbruck-Ostermann ETDRK4 step of length h from (y, th0 = 2 theta in turns at its start) with the modes held
-PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const double *y, double th0, double h, double qref, double vdcref,
-                              int modes, int xmask, double *yn) {
+// one Hochbruck-Ostermann ETDRK4 step of length h from (y, th0 = 2 theta in turns at its start) with the modes held.
+// yn may be any slot but the eight this function works in (A_N1 .. A_TMP); y must not be one of them either.
+PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const Arena &W, const double *y, double th0, double h, double qref,
+                              double vdcref, int modes, int xmask, double *yn) {
     Phi Fh, Fg;
     make_phi(L, h, Fh);
     make_phi(L, 0.5 * h, Fg);
     const double tq = 120.0 * h;
-    double N1[23], N23[23], N4[23], N5[23], yt[23], tmp[23], tmp2[23], e2y[23];
+    double *N1 = W[A_N1], *N2 = W[A_N2], *N4 = W[A_N4], *N5 = W[A_N5], *yt = W[A_YT], *e2y = W[A_E2Y], *ey = W[A_EY], *tmp = W[A_TMP];
     // N(y) = F(y) - L y on the closed pairs
     auto Nof = [&](const double *yy, double th, double *N) {
         masked(P, S, yy, th, qref, vdcref, modes, xmask, N);
@@ -267,69 +278,44 @@ PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const 
             N[i1] -= L.c * yy[i0] + L.d * yy[i1];
         }
     };
+    // dst += w * phi_k(.) v   through tmp
+    auto acc = [&](const Phi &F, int k, const double *v, double w, double *dst) {
+        apply_phi(L, F, k, modes, v, tmp);
+        for (int j = 0; j < 23; ++j) dst[j] += w * tmp[j];
+    };
     Nof(y, th0, N1);
     apply_phi(L, Fg, 0, modes, y, e2y);
+    apply_phi(L, Fh, 0, modes, y, ey);
     // U2 = e2y + h 0.5 g1 N1
-    apply_phi(L, Fg, 1, modes, N1, tmp);
-    for (int j = 0; j < 23; ++j) yt[j] = e2y[j] + h * 0.5 * tmp[j];
-    double N2[23];
+    for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
+    acc(Fg, 1, N1, 0.5 * h, yt);
     Nof(yt, th0 + 0.5 * tq, N2);
     // U3 = e2y + h ((0.5 g1 - g2) N1 + g2 N2)
-    apply_phi(L, Fg, 2, modes, N1, tmp2);
-    for (int j = 0; j < 23; ++j) yt[j] = e2y[j] + h * (0.5 * tmp[j] - tmp2[j]);
-    apply_phi(L, Fg, 2, modes, N2, tmp2);
-    for (int j = 0; j < 23; ++j) yt[j] += h * tmp2[j];
-    Nof(yt, th0 + 0.5 * tq, N23);
-    for (int j = 0; j < 23; ++j) N23[j] += N2[j];                    // N2 + N3
+    for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
+    acc(Fg, 1, N1, 0.5 * h, yt);
+    acc(Fg, 2, N1, -h, yt);
+    acc(Fg, 2, N2, h, yt);
+    Nof(yt, th0 + 0.5 * tq, N5);                                     // N3 (in N5's slot)
+    for (int j = 0; j < 23; ++j) N2[j] += N5[j];                     // N2 + N3
     // U4 = f0 y + h ((f1 - 2 f2) N1 + f2 (N2 + N3))
-    double ey[23];
-    apply_phi(L, Fh, 0, modes, y, ey);
-    apply_phi(L, Fh, 1, modes, N1, tmp);
-    apply_phi(L, Fh, 2, modes, N1, tmp2);
-    for (int j = 0; j < 23; ++j) yt[j] = ey[j] + h * (tmp[j] - 2.0 * tmp2[j]);
-    apply_phi(L, Fh, 2, modes, N23, tmp2);
-    for (int j = 0; j < 23; ++j) yt[j] += h * tmp2[j];
+    for (int j = 0; j < 23; ++j) yt[j] = ey[j];
+    acc(Fh, 1, N1, h, yt);
+    acc(Fh, 2, N1, -2.0 * h, yt);
+    acc(Fh, 2, N2, h, yt);
     Nof(yt, th0 + tq, N4);
-    // a52 = 0.5 g2 - f3 + 0.25 f2 - 0.5 g3;  a54 = 0.25 g2 - a52;  a51 = 0.5 g1 - 2 a52 - a54
-    // U5 = e2y + h (a51 N1 + a52 (N2 + N3) + a54 N4)
-    auto a52 = [&](const double *v, double *o) {
-        double t1[23];
-        apply_phi(L, Fg, 2, modes, v, t1);
-        for (int j = 0; j < 23; ++j) o[j] = 0.5 * t1[j];
-        apply_phi(L, Fh, 3, modes, v, t1);
-        for (int j = 0; j < 23; ++j) o[j] -= t1[j];
-        apply_phi(L, Fh, 2, modes, v, t1);
-        for (int j = 0; j < 23; ++j) o[j] += 0.25 * t1[j];
-        apply_phi(L, Fg, 3, modes, v, t1);
-        for (int j = 0; j < 23; ++j) o[j] -= 0.5 * t1[j];
-    };
-    {
-        double a[23], g2v[23], g1v[23];
-        for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
-        // a51 N1
-        a52(N1, a);
-        apply_phi(L, Fg, 2, modes, N1, g2v);
-        apply_phi(L, Fg, 1, modes, N1, g1v);
-        for (int j = 0; j < 23; ++j) yt[j] += h * (0.5 * g1v[j] - 2.0 * a[j] - (0.25 * g2v[j] - a[j]));
-        // a52 (N2 + N3)
-        a52(N23, a);
-        for (int j = 0; j < 23; ++j) yt[j] += h * a[j];
-        // a54 N4
-        a52(N4, a);
-        apply_phi(L, Fg, 2, modes, N4, g2v);
-        for (int j = 0; j < 23; ++j) yt[j] += h * (0.25 * g2v[j] - a[j]);
-    }
+    // U5 = e2y + h (a51 N1 + a52 (N2 + N3) + a54 N4),  a52 = 0.5 g2 - 0.5 g3 + 0.25 f2 - f3,  a54 = 0.25 g2 - a52,
+    // a51 = 0.5 g1 - 2 a52 - a54 = 0.5 g1 - 0.75 g2 + 0.5 g3 - 0.25 f2 + f3
+    for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
+    acc(Fg, 1, N1, 0.5 * h, yt); acc(Fg, 2, N1, -0.75 * h, yt); acc(Fg, 3, N1, 0.5 * h, yt); acc(Fh, 2, N1, -0.25 * h, yt); acc(Fh, 3, N1, h, yt);
+    acc(Fg, 2, N2, 0.5 * h, yt); acc(Fg, 3, N2, -0.5 * h, yt); acc(Fh, 2, N2, 0.25 * h, yt); acc(Fh, 3, N2, -h, yt);
+    acc(Fg, 2, N4, -0.25 * h, yt); acc(Fg, 3, N4, 0.5 * h, yt); acc(Fh, 2, N4, -0.25 * h, yt); acc(Fh, 3, N4, h, yt);
     Nof(yt, th0 + 0.5 * tq, N5);
     // y+ = f0 y + h ((f1 - 3 f2 + 4 f3) N1 + (-f2 + 4 f3) N4 + (4 f2 - 8 f3) N5)
-    {
-        double f1v[23], f2v[23], f3v[23];
-        apply_phi(L, Fh, 1, modes, N1, f1v); apply_phi(L, Fh, 2, modes, N1, f2v); apply_phi(L, Fh, 3, modes, N1, f3v);
-        for (int j = 0; j < 23; ++j) yn[j] = ey[j] + h * (f1v[j] - 3.0 * f2v[j] + 4.0 * f3v[j]);
-        apply_phi(L, Fh, 2, modes, N4, f2v); apply_phi(L, Fh, 3, modes, N4, f3v);
-        for (int j = 0; j < 23; ++j) yn[j] += h * (-f2v[j] + 4.0 * f3v[j]);
-        apply_phi(L, Fh, 2, modes, N5, f2v); apply_phi(L, Fh, 3, modes, N5, f3v);
-        for (int j = 0; j < 23; ++j) yn[j] += h * (4.0 * f2v[j] - 8.0 * f3v[j]);
-    }
+    for (int j = 0; j < 23; ++j) yt[j] = ey[j];
+    acc(Fh, 1, N1, h, yt); acc(Fh, 2, N1, -3.0 * h, yt); acc(Fh, 3, N1, 4.0 * h, yt);
+    acc(Fh, 2, N4, -h, yt); acc(Fh, 3, N4, 4.0 * h, yt);
+    acc(Fh, 2, N5, 4.0 * h, yt); acc(Fh, 3, N5, -8.0 * h, yt);
+    for (int j = 0; j < 23; ++j) yn[j] = yt[j];
     for (int k = 0; k < 6; ++k) {          // held components are held exactly
         const int p = k >> 1, c = k & 1;
         if ((modes >> k) & 1) yn[6 * p + 4 + c] = y[6 * p + 4 + c];
@@ -339,10 +325,10 @@ PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const 
 
 // ---- settle: the micro-integration of phase p's fast pair (see the header).  trust_u: the axes whose loop was closed over a large
 // step carry their current to 1e-5 -- a demand of K 1e-5 = 0.06 in m: their current is put on the slow manifold (D_c = 0) first.
-PVDER_HD inline void settle(const HybK &P, const Sub &S, double *y, double th2t, double qref, double vdcref, int p, bool trust_u, Run &R,
-                            double tnow) {
+PVDER_HD inline void settle(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, int p,
+                            bool trust_u, Run &R, double tnow) {
     const double K = P.KpG, wp = P.wp, lim2 = P.mlim2;
-    double f[23];
+    double *f = W[A_F0];                 // (free here: a settle comes behind a committed state, never inside a step)
     Alg A;
     field(P, S, y, th2t, qref, vdcref, f, A);
     if (trust_u) {
@@ -502,8 +488,9 @@ PVDER_HD inline void settle(const HybK &P, const Sub &S, double *y, double th2t,
 }
 
 // modes and sat from the state alone (the oracle does the same at the start of every sim time step: fil_settle)
-PVDER_HD inline void derive_modes(const HybK &P, const Sub &S, const double *y, double th2t, double qref, double vdcref, Run &R) {
-    double f[23];
+PVDER_HD inline void derive_modes(const HybK &P, const Sub &S, const Arena &W, const double *y, double th2t, double qref, double vdcref,
+                                  Run &R) {
+    double *f = W[A_F0];
     Alg A;
     field(P, S, y, th2t, qref, vdcref, f, A);
     R.modes = 0; R.sat = 0;
@@ -522,10 +509,11 @@ PVDER_HD inline void derive_modes(const HybK &P, const Sub &S, const double *y, 
 
 // at the start of a macro step: a held axis released by a jump of the inputs; a free phase whose closed loop is heading beyond the
 // limit for good (an action near the limit, a grid-voltage event: the quasi-static duty cycle ends at or beyond it)
-PVDER_HD inline void input_jump(const HybK &P, const Sub &S, double *y, double th2t, double qref, double vdcref, Run &R, double tnow) {
+PVDER_HD inline void input_jump(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, Run &R,
+                                double tnow) {
     const double K = P.KpG, jump_margin = 4e-3;
     for (int p = 0; p < 3; ++p) {
-        double f[23];
+        double *f = W[A_F1];
         Alg A;
         field(P, S, y, th2t, qref, vdcref, f, A);
         const double D[2] = {f[6 * p + 4] / P.wp, f[6 * p + 5] / P.wp};
@@ -535,7 +523,7 @@ PVDER_HD inline void input_jump(const HybK &P, const Sub &S, double *y, double t
                 const double u = y[6 * p + 4 + c];
                 if (((R.modes >> (2 * p + c)) & 1) && u != 0.0 && -D[c] * sgn(u) > 1e-9) rel = true;
             }
-            if (rel) settle(P, S, y, th2t, qref, vdcref, p, false, R, tnow);
+            if (rel) settle(P, S, W, y, th2t, qref, vdcref, p, false, R, tnow);
             continue;
         }
         double de0[2];
@@ -544,14 +532,14 @@ PVDER_HD inline void input_jump(const HybK &P, const Sub &S, double *y, double t
         if (!jump) continue;
         // where the phase ends once its current has caught up: the duty cycle that holds the current on its new reference
         const double g = 0.5 * y[18] * P.iLf;
-        double y2[23], f2[23];
+        double *y2 = W[A_Y1], *f2 = W[A_YT2];
         for (int j = 0; j < 23; ++j) y2[j] = y[j];
         y2[6 * p] += D[0]; y2[6 * p + 1] += D[1];
         Alg A2;
         field(P, S, y2, th2t, qref, vdcref, f2, A2);
         const double mqR = y[6 * p + 2] + K * y[6 * p + 4] - f2[6 * p] / g, mqI = y[6 * p + 3] + K * y[6 * p + 5] - f2[6 * p + 1] / g;
         if (mqR * mqR + mqI * mqI <= P.mlim2 * (1.0 - jump_margin)) continue;
-        settle(P, S, y, th2t, qref, vdcref, p, false, R, tnow);
+        settle(P, S, W, y, th2t, qref, vdcref, p, false, R, tnow);
     }
 }
 
@@ -574,9 +562,9 @@ PVDER_HD inline double cubic_root(double a, double b, double sa, double sb, doub
 enum { EV_NONE = 0, EV_ENTRY, EV_IMPACT, EV_CLAMP, EV_FREEZE };
 
 // value / slope of an event function at a state (positive side = the event has happened)
-PVDER_HD inline double event_value(const HybK &P, const Sub &S, int kind, int p, int c, double sg0, const double *y, double th2t, double qref,
-                                   double vdcref, double *slope) {
-    double f[23];
+PVDER_HD inline double event_value(const HybK &P, const Sub &S, const Arena &W, int kind, int p, int c, double sg0, const double *y, double th2t,
+                                   double qref, double vdcref, double *slope) {
+    double *f = W[A_F1];                 // (the field at the end of the full step is not needed any more while an event is located)
     Alg A;
     field(P, S, y, th2t, qref, vdcref, f, A);
     if (kind == EV_ENTRY) {
@@ -596,31 +584,31 @@ PVDER_HD inline double event_value(const HybK &P, const Sub &S, int kind, int p,
 }
 
 // the circle constraint of saturated phases behind the slow motion of a step
-PVDER_HD inline void after_step(const HybK &P, const Sub &S, double *y, double th2t, double qref, double vdcref, Run &R, double tnow) {
+PVDER_HD inline void after_step(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, Run &R,
+                                double tnow) {
     for (int p = 0; p < 3; ++p)
-        if (((R.sat >> p) & 1) && s_of(P, y, p) < -1e-12) settle(P, S, y, th2t, qref, vdcref, p, true, R, tnow);
+        if (((R.sat >> p) & 1) && s_of(P, y, p) < -1e-12) settle(P, S, W, y, th2t, qref, vdcref, p, true, R, tnow);
 }
 
 // from (tnow, y, th0) over h with the events inside located and resolved; tnow is only a label (seconds within the env step)
-PVDER_HD inline void advance(const HybK &P, const Sub &S, const Loop &L, double *y, double th0, double h, double qref, double vdcref, Run &R,
-                             double tnow) {
-    input_jump(P, S, y, th0, qref, vdcref, R, tnow);
+PVDER_HD inline void advance(const HybK &P, const Sub &S, const Loop &L, const Arena &W, double *y, double th0, double h, double qref,
+                             double vdcref, Run &R, double tnow) {
+    input_jump(P, S, W, y, th0, qref, vdcref, R, tnow);
+    double *f0 = W[A_F0], *f1 = W[A_F1], *y1 = W[A_Y1], *yt = W[A_YT2];
     double t = 0.0;                       // time into this macro step
     int guard = 0;
     while (t < h * (1.0 - 1e-13)) {
         const double hh = h - t, th_s = th0 + 120.0 * t;
         if (++guard > 48) {               // (never in the prototype's runs: the step is completed with what holds now)
-            double y1[23];
-            etd_step(P, S, L, y, th_s, hh, qref, vdcref, R.modes, xmask_of(y, R.sat), y1);
+            etd_step(P, S, L, W, y, th_s, hh, qref, vdcref, R.modes, xmask_of(y, R.sat), y1);
             for (int j = 0; j < 23; ++j) y[j] = y1[j];
             R.st.capped += 1;
             return;
         }
         const int modes0 = R.modes, xm = xmask_of(y, R.sat);
-        double f0[23], f1[23], y1[23];
         Alg A0, A1;
         field(P, S, y, th_s, qref, vdcref, f0, A0);
-        etd_step(P, S, L, y, th_s, hh, qref, vdcref, modes0, xm, y1);
+        etd_step(P, S, L, W, y, th_s, hh, qref, vdcref, modes0, xm, y1);
         field(P, S, y1, th_s + 120.0 * hh, qref, vdcref, f1, A1);
         // the earliest event: (kind, p, c, value at the start a, at the end b); an event = a <= 0 < b
         int ek = EV_NONE, ep = 0, ec = 0;
@@ -669,22 +657,21 @@ PVDER_HD inline void advance(const HybK &P, const Sub &S, const Loop &L, double 
         if (ek == EV_NONE) {
             for (int j = 0; j < 23; ++j) y[j] = y1[j];
             t = h;
-            after_step(P, S, y, th0 + 120.0 * h, qref, vdcref, R, tnow + h);
+            after_step(P, S, W, y, th0 + 120.0 * h, qref, vdcref, R, tnow + h);
             continue;
         }
         R.st.events += 1;
         double th = eth;
         const double sg0 = ec >= 0 ? sgn(y[6 * ep + 4 + ec]) : 0.0;
-        double yt[23];
         if (ek == EV_IMPACT && th > 0.0) {
             double de0[2], de1[2];
             demand_rate(P, A0, y, f0, ep, de0);
             demand_rate(P, A1, y1, f1, ep, de1);
             th = cubic_root(ea, eb, -de0[ec] * sg0 * hh, -de1[ec] * sg0 * hh, th);
             for (int it = 0; it < 2; ++it) {
-                etd_step(P, S, L, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
+                etd_step(P, S, L, W, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
                 double sl;
-                const double val = event_value(P, S, ek, ep, ec, sg0, yt, th_s + 120.0 * hh * th, qref, vdcref, &sl);
+                const double val = event_value(P, S, W, ek, ep, ec, sg0, yt, th_s + 120.0 * hh * th, qref, vdcref, &sl);
                 sl *= hh;
                 if (sl <= 0.0) break;
                 const double dth = -val / sl;
@@ -692,19 +679,19 @@ PVDER_HD inline void advance(const HybK &P, const Sub &S, const Loop &L, double 
                 th = fmin(fmax(th + dth, 1e-9), 1.0);
             }
             th = fmin(th + 5e-8 / hh, 1.0);          // the event must have HAPPENED where it is handled
-            etd_step(P, S, L, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
+            etd_step(P, S, L, W, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
         } else if (ek != EV_FREEZE && th > 0.0) {
             double lo = 0.0, flo = ea, hi = 1.0, fhi = eb;
             for (int it = 0; it < 8; ++it) {                                    // secant and bisection in turns, values only
-                etd_step(P, S, L, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
-                const double val = event_value(P, S, ek, ep, ec, sg0, yt, th_s + 120.0 * hh * th, qref, vdcref, nullptr);
+                etd_step(P, S, L, W, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
+                const double val = event_value(P, S, W, ek, ep, ec, sg0, yt, th_s + 120.0 * hh * th, qref, vdcref, nullptr);
                 if (val > 0.0) { hi = th; fhi = val; } else { lo = th; flo = val; }
                 if ((hi - lo) * hh < 1e-7) break;
                 th = (it & 1) ? lo + (hi - lo) * (-flo) / (fhi - flo) : 0.5 * (lo + hi);
                 th = fmin(fmax(th, lo + 0.02 * (hi - lo)), hi - 0.02 * (hi - lo));
             }
             th = hi;
-            etd_step(P, S, L, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
+            etd_step(P, S, L, W, y, th_s, hh * th, qref, vdcref, modes0, xm, yt);
         } else {
             for (int j = 0; j < 23; ++j) yt[j] = y[j];
             th = 0.0;
@@ -727,17 +714,21 @@ PVDER_HD inline void advance(const HybK &P, const Sub &S, const Loop &L, double 
                 R.t_rep[q] = te;
                 if (R.n_rep[q] > 4) { R.modes &= ~(1 << q); contact = true; }
             }
-            if (!contact) settle(P, S, y, th_e, qref, vdcref, ep, true, R, te);
+            if (!contact) settle(P, S, W, y, th_e, qref, vdcref, ep, true, R, te);
         }
-        after_step(P, S, y, th_e, qref, vdcref, R, te);
+        after_step(P, S, W, y, th_e, qref, vdcref, R, te);
     }
 }
 
 // ONE env step of an env at / near the duty-cycle limit: ys[23] in pvder order with the PLL state in its relative form
 // (delta = wte - wbase t), n_sub sim time steps of 1/60 s, the first in two macro steps (1/first_div, the rest).
 // vg[s], si[s]: the inputs of sim time step s.
-PVDER_HD inline void env_step(const HybK &P, double *y, double qref, double vdcref, const double *vg, const double *si, int n_sub, int first_div,
-                              Stats *st_out) {
+// arena: kArenaDoubles doubles of working memory (see Arena).
+template <typename TV>
+PVDER_HD inline void env_step(const HybK &P, double *y, double qref, double vdcref, const TV *vg, const TV *si, int n_sub, int first_div,
+                              Stats *st_out, double *arena) {
+    Arena W;
+    W.base = arena;
     Loop L;
     make_loop(P, L);
     Run R;
@@ -748,16 +739,16 @@ PVDER_HD inline void env_step(const HybK &P, double *y, double qref, double vdcr
     Sub S;
     const double dt = 1.0 / 60.0;
     for (int s = 0; s < n_sub; ++s) {
-        make_sub(P, vg[s], si[s], S);
-        if (s == 0) derive_modes(P, S, y, 0.0, qref, vdcref, R);
+        make_sub(P, (double)vg[s], (double)si[s], S);
+        if (s == 0) derive_modes(P, S, W, y, 0.0, qref, vdcref, R);
         const double t0 = s * dt;
         const bool jump = s == 0 || vg[s] != vg[s - 1] || si[s] != si[s - 1];      // a new action / a new event row: the graded pair
         if (jump && first_div > 1) {
             const double h1 = dt / first_div;
-            advance(P, S, L, y, 0.0, h1, qref, vdcref, R, t0);
-            advance(P, S, L, y, 120.0 * h1, dt - h1, qref, vdcref, R, t0 + h1);
+            advance(P, S, L, W, y, 0.0, h1, qref, vdcref, R, t0);
+            advance(P, S, L, W, y, 120.0 * h1, dt - h1, qref, vdcref, R, t0 + h1);
         } else {
-            advance(P, S, L, y, 0.0, dt, qref, vdcref, R, t0);
+            advance(P, S, L, W, y, 0.0, dt, qref, vdcref, R, t0);
         }
     }
     if (st_out) *st_out = R.st;

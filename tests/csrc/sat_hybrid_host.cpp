@@ -9,7 +9,8 @@ extern "C" int sat_hybrid_env_step_host(const double *k /* HybK, 23 doubles in d
     double *dst = reinterpret_cast<double *>(&P);
     for (int j = 0; j < (int)(sizeof(P) / sizeof(double)); ++j) dst[j] = k[j];
     pvder::hyb::Stats st;
-    pvder::hyb::env_step(P, y, qref, vdcref, vg, si, n_sub, first_div, &st);
+    double arena[pvder::hyb::kArenaDoubles];
+    pvder::hyb::env_step(P, y, qref, vdcref, vg, si, n_sub, first_div, &st, arena);
     if (stats) { stats[0] = st.settles; stats[1] = st.micro; stats[2] = st.events; stats[3] = st.capped; }
     return (int)(sizeof(P) / sizeof(double));
 }
