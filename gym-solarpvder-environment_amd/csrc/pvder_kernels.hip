@@ -621,7 +621,7 @@ struct EtdK {
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
-    float sat2_flag;        // (0.93 m_limit)^2: beyond it an env leaves the LEAN pass (same arithmetic in the second pass, which raises
+    float sat2_flag;        // (0.97 m_limit)^2: beyond it an env leaves the LEAN pass (same arithmetic in the second pass, which raises
                             // the plan's hybrid flag: the hybrid kernel is then in place well before the duty cycle saturates)
     int rk4_sub[3];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
     float hset[3];          // step sizes [s]: 1/(60 micro), 1/(60 micro_coarse), (1 - 1/micro)/60
@@ -1534,7 +1534,7 @@ __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const
 constexpr int kHybBlock = 64;
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
 constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
-__global__ __launch_bounds__(kHybBlock) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par) {
+__global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par) {
     using namespace pvder::hyb;
     extern __shared__ __attribute__((aligned(16))) double hyb_lds[];
     const int n_env = A.n_env;
@@ -2809,7 +2809,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
     const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
     PVDER_TRACE_AT(1);
     if constexpr (PH == 3) {
-        // an env whose duty cycle is beyond 93 % of its limit: the plan's hybrid flag (a word of pinned HOST memory; the next step
+        // an env whose duty cycle is beyond 97 % of its limit: the plan's hybrid flag (a word of pinned HOST memory; the next step
         // launches are followed by step_sat_hybrid_kernel -- in place well before an env saturates: sat2_flag)
         if (A.hyb_flag && L.run) {
             float m2 = 0.f;
@@ -4215,7 +4215,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float 
     const double ge = 0.97 * par[PVDER_PAR_M_LIMIT], gs = 0.998 * par[PVDER_PAR_M_LIMIT];
     E.sat2_event = (float)(ge * ge);
     E.sat2_smooth = (float)(gs * gs);
-    E.sat2_flag = (float)(0.93 * 0.93 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
+    E.sat2_flag = (float)(0.97 * 0.97 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
     E.i2_to_m2 = (float)(ge * ge / (0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]));
     return E;
 }

@@ -38,9 +38,17 @@
 namespace pvder {
 namespace hyb {
 
-struct HybK {                  // the model's constants (pvder_model.hpp::ModelK, in double; pvK in the exp2 form)
-    double Rf, iLf, iC, kviR, kviI, GR, GI, KpG, KiG, KpDC, KiDC, KpQ, KiQ, wp, KpP, KiP, mlim2, ilim2, iwb, pvA, pvB, pvK, vdc_ref0;
+// the model's constants (pvder_model.hpp::ModelK; pvK in the exp2 form).  TK = float on the device: they ARE the step kernels' fp32
+// constants, and 23 doubles that every function reads are 184 bytes of private memory the kernel cannot afford (see Arena)
+template <typename TK>
+struct HybKT {
+    TK Rf, iLf, iC, kviR, kviI, GR, GI, KpG, KiG, KpDC, KiDC, KpQ, KiQ, wp, KpP, KiP, mlim2, ilim2, iwb, pvA, pvB, pvK, vdc_ref0;
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef HybKT<float> HybK;
+#else
+typedef HybKT<double> HybK;
+#endif
 
 struct Sub {                   // per sim time step: grid voltage phasors and the PV constant
     double AR[3], AI[3], pv1;
