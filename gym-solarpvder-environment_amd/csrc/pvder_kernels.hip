@@ -111,7 +111,12 @@ using pvder::v2;
 #ifndef PVDER_BLOCK
 #define PVDER_BLOCK 256
 #endif
-constexpr int kBlock = PVDER_BLOCK;   // 4 waves: one per SIMD of a CU
+constexpr int kBlock = PVDER_BLOCK;   // 4 waves
+#ifdef PVDER_NO_HYB_FLAG            // (A/B: the lean pass without the hybrid flag's term)
+#define PVDER_HYB_LEAN(x)
+#else
+#define PVDER_HYB_LEAN(x) x
+#endif: one per SIMD of a CU
 constexpr int kDeferred = -1; // transient istate status (etdlin64 only): "advance me in the follow-up launch" (step_rk45_kernel)
 
 template <typename T>
@@ -2145,7 +2150,7 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
     // the current reference or the duty cycle comes near its limit: the careful pass redoes the env step
     // (LEAN: the duty cycle at the START of the step beyond 97 % of its limit sends the env to the second pass, which raises the plan's
     //  hybrid flag -- not the peak, which every action's transient lifts)
-    near_ilim = ir2a > irg || mmax > Ec.sat2_smooth || (LEAN && msc * m2a > Ec.sat2_flag);
+    near_ilim = ir2a > irg || mmax > Ec.sat2_smooth PVDER_HYB_LEAN(|| (LEAN && msc * m2a > Ec.sat2_flag));
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -2208,7 +2213,7 @@ __device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs 
                             fabsf(Yn[1].z - acc2[0][1].z));
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     const float mmax = msc * fmaxf(fmaxf(fmaxf(m2a, m2x), fmaxf(m2y, m2b)), __builtin_fmaf(mn.y, mn.y, mn.x * mn.x));
-    near_ilim = ir2a > irg || ir2y > irg || mmax > Ec.sat2_smooth || (!EARLY && msc * m2a > Ec.sat2_flag);     // (EARLY = the second pass)
+    near_ilim = ir2a > irg || ir2y > irg || mmax > Ec.sat2_smooth PVDER_HYB_LEAN(|| (!EARLY && msc * m2a > Ec.sat2_flag));     // (EARLY = the second pass)
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -2346,7 +2351,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
             bool trip = pk2 > G.Lk.sat2_hard;
             if (run) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
-                else defer |= pk2 > Ec.sat2_smooth || msc * m2a > Ec.sat2_flag || ir2a > irg;
+                else defer |= pk2 > Ec.sat2_smooth PVDER_HYB_LEAN(|| msc * m2a > Ec.sat2_flag) || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
             }
             // (a wave whose envs all sit at the current limit -- a policy that holds one Q_ref action -- goes
@@ -2399,7 +2404,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
             const bool trip = pk2 > G.Lk.sat2_hard;
             if (start && !done) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
-                else defer |= pk2 > Ec.sat2_smooth || msc * m2a > Ec.sat2_flag || ir2a > irg;
+                else defer |= pk2 > Ec.sat2_smooth PVDER_HYB_LEAN(|| msc * m2a > Ec.sat2_flag) || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 start = false;
             }
@@ -3171,7 +3176,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
                 lin_mfma1(At, F, acc);
                 const float pk2 = lin_tick_peak2(Pl, Y, acc, m2a);
                 if (mine) {
-                    leave |= pk2 > A.Ec.sat2_smooth || m2a > A.Ec.sat2_flag || ir2a > irg;
+                    leave |= pk2 > A.Ec.sat2_smooth PVDER_HYB_LEAN(|| m2a > A.Ec.sat2_flag) || ir2a > irg;
                     Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 }
             }
