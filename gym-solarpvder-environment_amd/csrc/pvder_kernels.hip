@@ -626,8 +626,11 @@ struct EtdK {
     float c0kp;             // c0 * Kp_GCC  (for N_i)
     float sat2_event;       // guard on the step that follows an input jump:  (0.97 *m_limit)^2
     float sat2_smooth;      // guard on all other steps:                       (0.998*m_limit)^2
-    float sat2_flag;        // (0.97 m_limit)^2: beyond it an env leaves the LEAN pass (same arithmetic in the second pass, which raises
-                            // the plan's hybrid flag: the hybrid kernel is then in place well before the duty cycle saturates)
+    float sat2_flag;        // (0.9875 m_limit)^2: an env whose duty cycle STARTS a step beyond it leaves the lean pass (same arithmetic in the
+                            // second pass, which raises the plan's hybrid flag: the hybrid kernel is in place 14 env steps of the
+                            // reference's Vdc_ref ramp before the duty cycle saturates).  Ordinary PVDER-v0 rollouts -- 65 536 envs,
+                            // random actions, both event kinds, three episodes -- reach 0.9817 at worst (tools/m_distribution.py): a
+                            // lower threshold has some env leave the lean pass in one step of three, 2.2 us on EVERY launch
     int rk4_sub[3];         // classic RK4 micro-steps replacing one ETD step in the fallback (per set)
     float hset[3];          // step sizes [s]: 1/(60 micro), 1/(60 micro_coarse), (1 - 1/micro)/60
     float i2_to_m2;         // balanced kernel: |iref|^2 * i2_to_m2 > guard  <=>  |iref| within 10 % of its limit
@@ -2816,7 +2819,7 @@ __device__ __forceinline__ void lin_step_body(const LinArgs &G, int lane, LinReg
     const float vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec], si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
     PVDER_TRACE_AT(1);
     if constexpr (PH == 3) {
-        // an env whose duty cycle is beyond 97 % of its limit: the plan's hybrid flag (a word of pinned HOST memory; the next step
+        // an env whose duty cycle is beyond 98.75 % of its limit: the plan's hybrid flag (a word of pinned HOST memory; the next step
         // launches are followed by step_sat_hybrid_kernel -- in place well before an env saturates: sat2_flag)
         if (A.hyb_flag && L.run) {
             float m2 = 0.f;
@@ -4222,7 +4225,7 @@ EtdK make_etd(const double *par, int micro, int micro_coarse, int graded, float 
     const double ge = 0.97 * par[PVDER_PAR_M_LIMIT], gs = 0.998 * par[PVDER_PAR_M_LIMIT];
     E.sat2_event = (float)(ge * ge);
     E.sat2_smooth = (float)(gs * gs);
-    E.sat2_flag = (float)(0.97 * 0.97 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
+    E.sat2_flag = (float)(0.9875 * 0.9875 * par[PVDER_PAR_M_LIMIT] * par[PVDER_PAR_M_LIMIT]);
     E.i2_to_m2 = (float)(ge * ge / (0.81 * par[PVDER_PAR_IREF_LIMIT] * par[PVDER_PAR_IREF_LIMIT]));
     return E;
 }
@@ -4303,6 +4306,12 @@ struct pvder_plan {
                                      // 1 = terminate, 2 = held operator sets (rounds 3-5), 3 = the hybrid kernel behind EVERY step launch
     int *hyb_flag_host = nullptr;    // auto: pinned host word the step kernels write when an env comes near the limit
     mutable int hyb_hold = 0;        // auto: step launches the hybrid kernel still follows (re-armed whenever the flag is seen)
+    // auto: the host must SEE the flag before the duty cycle gets from 0.9875 to its limit (14 env steps of the reference's ramp):
+    // never more than 16 step launches of this plan in flight (an event every 8 launches; the one recorded 16 launches ago is
+    // waited for -- by polling, the queue holds 8 launches of work meanwhile)
+    mutable hipEvent_t thr_ev[2] = {nullptr, nullptr};
+    mutable bool thr_set[2] = {false, false};
+    mutable unsigned thr_n = 0;
     bool graph_hints = false;        // pvder_plan_graph_hints: a CAPTURED pvder_plan_rollout keeps the clock hints it was captured with
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
@@ -4313,6 +4322,7 @@ struct pvder_plan {
     mutable hipEvent_t chain_fork = nullptr, chain_join = nullptr;
     ~pvder_plan() {
         if (hyb_flag_host) (void)hipHostFree(hyb_flag_host);
+        for (int k = 0; k < 2; ++k) if (thr_ev[k]) (void)hipEventDestroy(thr_ev[k]);
         if (chain) (void)hipFree(chain);
         if (chain_fork) (void)hipEventDestroy(chain_fork);
         if (chain_join) (void)hipEventDestroy(chain_join);
@@ -4590,6 +4600,18 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
                                    ev_vg, ev_si, (const uint8_t *)nullptr, (double *)out, n_env);
         }
     }
+    }
+    if (p.hyb_mode == 0 && p.hyb_flag_host) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+        if (!capturing && ((++p.thr_n) & 7u) == 0u) {
+            const int slot = (int)((p.thr_n >> 3) & 1u);
+            if (!p.thr_ev[slot] && hipEventCreateWithFlags(&p.thr_ev[slot], hipEventDisableTiming) != hipSuccess) p.thr_ev[slot] = nullptr;
+            if (p.thr_ev[slot]) {
+                if (p.thr_set[slot]) while (hipEventQuery(p.thr_ev[slot]) == hipErrorNotReady) { }
+                p.thr_set[slot] = hipEventRecord(p.thr_ev[slot], st) == hipSuccess;
+            }
+        }
     }
     return hip_rc(hipGetLastError());
 }
