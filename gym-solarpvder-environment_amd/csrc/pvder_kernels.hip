@@ -4832,6 +4832,13 @@ int pvder_plan_graph_hints(pvder_plan *plan, int on) {
 
 const char *pvder_plan_kernel_name(const pvder_plan *plan) { return plan ? plan_kernel_name(*plan) : ""; }
 
+int pvder_plan_hybrid_active(const pvder_plan *plan) {
+    if (!plan || plan->ph != 3 || plan->n_sub > kHybMaxSub) return 0;
+    if (plan->hyb_mode == 3) return 1;
+    if (plan->hyb_mode != 0) return 0;
+    return (plan->hyb_hold > 0 || (plan->hyb_flag_host && __atomic_load_n(plan->hyb_flag_host, __ATOMIC_RELAXED) != 0)) ? 1 : 0;
+}
+
 int pvder_plan_step(const pvder_plan *plan, void *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                     const uint8_t *action, void *out, double *hstep, float *stats, void *stream) {
     if (!plan) return PVDER_EINVAL;

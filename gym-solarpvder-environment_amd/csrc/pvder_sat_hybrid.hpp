@@ -286,43 +286,76 @@ PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const 
             N[i1] -= L.c * yy[i0] + L.d * yy[i1];
         }
     };
-    // dst += w * phi_k(.) v   through tmp
-    auto acc = [&](const Phi &F, int k, const double *v, double w, double *dst) {
-        apply_phi(L, F, k, modes, v, tmp);
-        for (int j = 0; j < 23; ++j) dst[j] += w * tmp[j];
+    // A stage is  base + h sum_k w_k phi_k(.) N  over a few phi functions of (h L) and (h/2 L): on the components outside the closed
+    // pairs every phi_k is a number (1, 1, 1/2, 1/6), on a closed pair c1_k I + c2_k L2 -- so the SUM is one number / one (C1, C2)
+    // per source vector, and a stage is ONE pass per source vector (not one per phi function: the vectors live in LDS on the device).
+    struct Comb { double s, C1, C2; };
+    auto comb = [&](const double *wg, const double *wf) -> Comb {       // weights of g_k = phi_k(h/2 L) and f_k = phi_k(h L), k = 0..3
+        const double sc[4] = {1.0, 1.0, 0.5, 1.0 / 6.0};
+        Comb c = {0.0, 0.0, 0.0};
+        for (int k = 0; k < 4; ++k) {
+            c.s += (wg[k] + wf[k]) * sc[k];
+            c.C1 += wg[k] * Fg.c1[k] + wf[k] * Fh.c1[k];
+            c.C2 += wg[k] * Fg.c2[k] + wf[k] * Fh.c2[k];
+        }
+        return c;
     };
+    // dst (=|+=) comb . v
+    auto pass = [&](const Comb &c, const double *v, double *dst, bool add) {
+        for (int j = 0; j < 23; ++j) {
+            bool pair = false;
+            if (j < 18) {
+                const int p = j / 6, r = j % 6;
+                if (r < 2) pair = !((modes >> (2 * p + r)) & 1);
+                else if (r >= 4) pair = !((modes >> (2 * p + r - 4)) & 1);
+            }
+            if (pair) continue;
+            const double t = c.s * v[j];
+            dst[j] = add ? dst[j] + t : t;
+        }
+        for (int q = 0; q < 6; ++q) {
+            if ((modes >> q) & 1) continue;
+            const int p = q >> 1, cc = q & 1, i0 = 6 * p + cc, i1 = 6 * p + 4 + cc;
+            const double v0 = v[i0], v1 = v[i1];
+            const double t0 = c.C1 * v0 + c.C2 * (L.a * v0 + L.b * v1), t1 = c.C1 * v1 + c.C2 * (L.c * v0 + L.d * v1);
+            dst[i0] = add ? dst[i0] + t0 : t0;
+            dst[i1] = add ? dst[i1] + t1 : t1;
+        }
+    };
+    const double Z[4] = {0, 0, 0, 0};
     Nof(y, th0, N1);
-    apply_phi(L, Fg, 0, modes, y, e2y);
-    apply_phi(L, Fh, 0, modes, y, ey);
+    {   // e2y = g0 y, ey = f0 y
+        const double w0[4] = {1, 0, 0, 0};
+        pass(comb(w0, Z), y, e2y, false);
+        pass(comb(Z, w0), y, ey, false);
+    }
     // U2 = e2y + h 0.5 g1 N1
     for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
-    acc(Fg, 1, N1, 0.5 * h, yt);
+    { const double wg[4] = {0, 0.5 * h, 0, 0}; pass(comb(wg, Z), N1, yt, true); }
     Nof(yt, th0 + 0.5 * tq, N2);
     // U3 = e2y + h ((0.5 g1 - g2) N1 + g2 N2)
     for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
-    acc(Fg, 1, N1, 0.5 * h, yt);
-    acc(Fg, 2, N1, -h, yt);
-    acc(Fg, 2, N2, h, yt);
+    { const double wg[4] = {0, 0.5 * h, -h, 0}; pass(comb(wg, Z), N1, yt, true); }
+    { const double wg[4] = {0, 0, h, 0}; pass(comb(wg, Z), N2, yt, true); }
     Nof(yt, th0 + 0.5 * tq, N5);                                     // N3 (in N5's slot)
     for (int j = 0; j < 23; ++j) N2[j] += N5[j];                     // N2 + N3
     // U4 = f0 y + h ((f1 - 2 f2) N1 + f2 (N2 + N3))
     for (int j = 0; j < 23; ++j) yt[j] = ey[j];
-    acc(Fh, 1, N1, h, yt);
-    acc(Fh, 2, N1, -2.0 * h, yt);
-    acc(Fh, 2, N2, h, yt);
+    { const double wf[4] = {0, h, -2.0 * h, 0}; pass(comb(Z, wf), N1, yt, true); }
+    { const double wf[4] = {0, 0, h, 0}; pass(comb(Z, wf), N2, yt, true); }
     Nof(yt, th0 + tq, N4);
     // U5 = e2y + h (a51 N1 + a52 (N2 + N3) + a54 N4),  a52 = 0.5 g2 - 0.5 g3 + 0.25 f2 - f3,  a54 = 0.25 g2 - a52,
     // a51 = 0.5 g1 - 2 a52 - a54 = 0.5 g1 - 0.75 g2 + 0.5 g3 - 0.25 f2 + f3
     for (int j = 0; j < 23; ++j) yt[j] = e2y[j];
-    acc(Fg, 1, N1, 0.5 * h, yt); acc(Fg, 2, N1, -0.75 * h, yt); acc(Fg, 3, N1, 0.5 * h, yt); acc(Fh, 2, N1, -0.25 * h, yt); acc(Fh, 3, N1, h, yt);
-    acc(Fg, 2, N2, 0.5 * h, yt); acc(Fg, 3, N2, -0.5 * h, yt); acc(Fh, 2, N2, 0.25 * h, yt); acc(Fh, 3, N2, -h, yt);
-    acc(Fg, 2, N4, -0.25 * h, yt); acc(Fg, 3, N4, 0.5 * h, yt); acc(Fh, 2, N4, -0.25 * h, yt); acc(Fh, 3, N4, h, yt);
+    { const double wg[4] = {0, 0.5 * h, -0.75 * h, 0.5 * h}, wf[4] = {0, 0, -0.25 * h, h}; pass(comb(wg, wf), N1, yt, true); }
+    { const double wg[4] = {0, 0, 0.5 * h, -0.5 * h}, wf[4] = {0, 0, 0.25 * h, -h}; pass(comb(wg, wf), N2, yt, true); }
+    { const double wg[4] = {0, 0, -0.25 * h, 0.5 * h}, wf[4] = {0, 0, -0.25 * h, h}; pass(comb(wg, wf), N4, yt, true); }
     Nof(yt, th0 + 0.5 * tq, N5);
     // y+ = f0 y + h ((f1 - 3 f2 + 4 f3) N1 + (-f2 + 4 f3) N4 + (4 f2 - 8 f3) N5)
     for (int j = 0; j < 23; ++j) yt[j] = ey[j];
-    acc(Fh, 1, N1, h, yt); acc(Fh, 2, N1, -3.0 * h, yt); acc(Fh, 3, N1, 4.0 * h, yt);
-    acc(Fh, 2, N4, -h, yt); acc(Fh, 3, N4, 4.0 * h, yt);
-    acc(Fh, 2, N5, 4.0 * h, yt); acc(Fh, 3, N5, -8.0 * h, yt);
+    { const double wf[4] = {0, h, -3.0 * h, 4.0 * h}; pass(comb(Z, wf), N1, yt, true); }
+    { const double wf[4] = {0, 0, -h, 4.0 * h}; pass(comb(Z, wf), N4, yt, true); }
+    { const double wf[4] = {0, 0, 4.0 * h, -8.0 * h}; pass(comb(Z, wf), N5, yt, true); }
     for (int j = 0; j < 23; ++j) yn[j] = yt[j];
     for (int k = 0; k < 6; ++k) {          // held components are held exactly
         const int p = k >> 1, c = k & 1;

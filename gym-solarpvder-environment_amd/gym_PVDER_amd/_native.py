@@ -31,7 +31,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
            "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch",
-           "pvder_plan_step_mirror", "pvder_plan_graph_hints", "pvder_plan_kernel_name"]
+           "pvder_plan_step_mirror", "pvder_plan_graph_hints", "pvder_plan_kernel_name", "pvder_plan_hybrid_active"]
 MIRROR_WORDS = 18       # PVDER_MIRROR_WORDS (pvder_plan_step_mirror): 13 output rows + 4 counters + the sequence word, doubles
 LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
@@ -172,6 +172,8 @@ def lib() -> C.CDLL:
     L.pvder_plan_graph_hints.argtypes = [vp, i32]
     L.pvder_plan_kernel_name.restype = C.c_char_p
     L.pvder_plan_kernel_name.argtypes = [vp]
+    L.pvder_plan_hybrid_active.restype = i32
+    L.pvder_plan_hybrid_active.argtypes = [vp]
     L.pvder_fold_lane_params.restype = i32
     L.pvder_fold_lane_params.argtypes = [dp, vp, i32, vp]
     L.pvder_plan_lane_params.restype = i32

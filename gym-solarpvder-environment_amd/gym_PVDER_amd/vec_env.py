@@ -179,13 +179,15 @@ class PVDERVec(EnvSpecMixin):
         steps on the 23-state ETDRK4 path with its own constants (45-75 us per batched step).  reset() and
         the same-step auto-reset start every env from ITS OWN steady state (a Newton root per env, folded on the host: the
         reference builds each DER with steadyStateInitialization=True, PVDER_env.py:374-378).
-        ``off_range``: an env driven out of the range the fast fp32 integrators cover (duty cycle / current
-        reference at their limits: e.g. Vdc_ref walked down 6 %) is ``"integrate"``d through as the reference
-        does -- on the 23-state path, its steps at the duty-cycle limit on the operator sets of the anti-windup modes:
-        ~55 us per env step for the WHOLE batch while one env is there, ~0.1 ms once most are (a launch lasts as long as
-        its slowest workgroup; bench.py `fixed_policy`) -- or its episode ``"terminate"``s (done, reward -100, the reference's
-        failure branch PVDER_env.py:169-172).  Envs at the CURRENT limit are not off range: they stay on the
-        matrix-core path (careful pass) and are never terminated."""
+        ``off_range``: what happens to an env whose duty cycle reaches its limit (Vdc_ref walked down 6 %: the reference's
+        action 4 held for 115 env steps) -- ``"integrate"`` (default): integrated through, as the reference does, by the hybrid
+        scheme of csrc/pvder_sat_hybrid.hpp in a kernel of its own that follows the step launches while an env is (or lately
+        was) beyond 98.75 % of the limit: <= 6e-3 per env step (median 1.5e-5) of the converged event-locating solution; nothing
+        on any launch until then, milliseconds per env step for the envs at the limit; ``"integrate_always"``: the same with
+        that kernel behind EVERY launch (+4 us: deterministic whatever the host's timing; tests); ``"held_modes"``: rounds 3-5's
+        step on the operator sets of the anti-windup modes (55 us per env step, 1e-2 ... 1e-1 off beyond saturation; A/B);
+        ``"terminate"``: the episode ends (done, reward -100, the reference's failure branch PVDER_env.py:169-172).  Envs at the
+        CURRENT limit are not off range: they stay on the matrix-core path (careful pass) and are never terminated."""
         if off_range not in OFF_RANGE:
             raise ValueError("off_range must be one of %s" % (sorted(OFF_RANGE),))
         self.off_range = off_range
@@ -824,7 +826,9 @@ class PVDERVec(EnvSpecMixin):
         if fused and not can_fuse:
             raise ValueError("fused rollouts: integrator='etdlin', three-phase model, no per-launch timing, no per-env parameter sets")
         if fused is None:
-            fused = can_fuse and K >= 4
+            # (while an env is at / near the duty-cycle limit the hybrid kernel follows every step launch -- the fused kernels cannot
+            #  host it: they would step such an env on the held operator sets, 1e-2 off: include/pvder_hip.h pvder_plan_hybrid_active)
+            fused = can_fuse and K >= 4 and not self._lib.pvder_plan_hybrid_active(plan)
         with self._device_ctx():
             if out is not None and K > 0 and not self.auto_reset:
                 out[0].copy_(self.out)               # stale tuples of finished envs: block k takes them from block k-1

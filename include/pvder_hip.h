@@ -119,23 +119,34 @@ typedef struct pvder_step_cfg {
                              PVDER_REWARD_Q_ERROR the Q_error term under voltage_regulation (:263-275 with
                              Qtarget = PV_model.Q_ref, :238 -- 1e-6 when it is 0 in the discrete branch, :266-267),
                              PVDER_REWARD_VOLTAGE_ERROR the voltage_error term (:276-287) under the other goals */
-    int32_t off_range;    /* what happens to an env that leaves the range the fast fp32 integrators cover -- duty
-                             cycle |m| at its limit, where the reference model's component-wise anti-windup switches
-                             the stiff dynamics (an env at the CURRENT limit is in range since round 3: etdlin keeps it on
-                             the matrix-core path, careful pass, and never terminates it):
-                             PVDER_OFF_RANGE_INTEGRATE (0, default): it is integrated through, as the reference
-                             does -- the 23-state path on the operator sets of the anti-windup modes (the mode of a
-                             phase is found at the START of an integrator step and held over it, up to 1/60 s), ~55 us
-                             per env step for the launch while an env is there (~0.1 ms once most envs are);  PVDER_OFF_RANGE_TERMINATE (1): the episode ends
-                             (status 2, done, reward -100: the reference's failure branch, :169-172) -- for
-                             training runs that must not stall on a saturated converter.  fp32 exponential
-                             integrators only (etdlin, ETDRK4). */
+    int32_t off_range;    /* what happens to an env whose duty cycle |m| reaches its limit, where the reference model's component-wise
+                             anti-windup switches the stiff dynamics (an env at the CURRENT limit is in range since round 3: etdlin
+                             keeps it on the matrix-core path, careful pass, and never terminates it):
+                             PVDER_OFF_RANGE_INTEGRATE (0, default): it is integrated through, as the reference does
+                             (PVDER_env.py:166) -- by the hybrid scheme of csrc/pvder_sat_hybrid.hpp (round 6: flight / impact /
+                             contact on the slow time scale, events located inside the steps, fp64 between the fp32 rows; <= 6e-3
+                             per env step, median 1.5e-5, of the converged event-locating solution along the reference's
+                             Vdc_ref-down ramp) in a kernel of its own, step_sat_hybrid_kernel, which FOLLOWS the step launches
+                             while an env is, or within the last 256 launches was, beyond 98.75 % of the limit (a word of pinned
+                             host memory the step kernels write; at most 16 step launches of such a plan are in flight, so that
+                             the host sees it in time): nothing on any launch until then, ~4 us per launch while it follows,
+                             milliseconds per env step for the envs it advances;
+                             PVDER_OFF_RANGE_TERMINATE (1): the episode ends (status 2, done, reward -100: the reference's failure
+                             branch, :169-172) -- for training runs that must not stall on a saturated converter;
+                             PVDER_OFF_RANGE_HELD_MODES (2): rounds 3-5's step -- the 23-state path on the operator sets of the
+                             anti-windup modes, the mode of a phase found at the START of an integrator step and held over it:
+                             ~55 us per env step, 1e-2 ... 1e-1 off once the duty cycle saturates (A/B, tests);
+                             PVDER_OFF_RANGE_HYBRID_ALWAYS (3): as 0 with the hybrid kernel behind EVERY step launch (+4 us each):
+                             deterministic whatever the host's timing (tests).
+                             fp32 exponential integrators only (etdlin, ETDRK4); three-phase model; n_sub <= 16. */
 } pvder_step_cfg;
 #define PVDER_REWARD_VDC_ERROR 1
 #define PVDER_REWARD_Q_ERROR 2
 #define PVDER_REWARD_VOLTAGE_ERROR 4
 #define PVDER_OFF_RANGE_INTEGRATE 0
 #define PVDER_OFF_RANGE_TERMINATE 1
+#define PVDER_OFF_RANGE_HELD_MODES 2
+#define PVDER_OFF_RANGE_HYBRID_ALWAYS 3
 
 /* ---- event generator spec for reset (PVDER_env.py:60-61, :400-411) */
 typedef struct pvder_event_spec {
@@ -341,6 +352,11 @@ int pvder_plan_graph_hints(pvder_plan *plan, int on);
  * "step_etdlin_kernel_w1<3>": the one-wave-per-SIMD form a batch of up to 65 536 three-phase envs takes): what a measurement
  * names as "the kernel that ran".  Static storage; "" without a plan. */
 const char *pvder_plan_kernel_name(const pvder_plan *plan);
+/* (ABI 17) 1 while step_sat_hybrid_kernel follows this plan's step launches -- off_range PVDER_OFF_RANGE_HYBRID_ALWAYS, or
+ * PVDER_OFF_RANGE_INTEGRATE while an env is, or lately was, beyond 98.75 % of the duty-cycle limit (see pvder_step_cfg.off_range) --,
+ * else 0.  The fused rollouts (pvder_plan_rollout_fused*) step such envs on the held operator sets: a caller that wants the
+ * hybrid step takes pvder_plan_rollout while this returns 1 (gym_PVDER_amd.PVDERVec.rollout does). */
+int pvder_plan_hybrid_active(const pvder_plan *plan);
 
 /* Per-LANE parameter override (PVDER_INT_ETDRK4, three-phase model): every env of the batch with its own values of the
  * parameters that stay outside the exponential operator of the 23-state ETDRK4 path -- domain randomisation over the

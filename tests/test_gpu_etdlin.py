@@ -753,12 +753,13 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
     tests/bridge_cases.py): whole trajectory and worst single env step.  Action 4 is compared over ALL 160 steps
     (VERDICT r3 #3): up to the first saturated step at the parity bar; beyond it against the round-5 golden -- the
     EVENT-LOCATING integrator's run (oracle/pvder_bridge_filippov.h: the sliding solution itself; its OWN spread over all 160
-    steps is 5.1e-6, rtol 1e-9 against 1e-12: profiles/r05_filippov_convergence.txt).  The golden is converged now; the
-    DEVICE is not there: its switched steps hold an anti-windup mode over a whole integrator step and are 1e-2 ... 1e-1 off
-    in the env steps in which a phase enters, leaves or re-locks at the limit (median 8e-4) -- and a scheme of that kind does
-    not converge under step refinement (fp64 prototype at 480 steps per env step: still 7e-2): a clamped
-    duty cycle leaves the current loop OPEN, and the open loop integrates a duty-cycle error dm into a current error 276 dm t.
-    The bounds below are the measured ones (profiles/r05_a4_saturated_numbers.txt), a waiver that says what it waives."""
+    steps is 5.1e-6, rtol 1e-9 against 1e-12: profiles/r05_filippov_convergence.txt).  Round 6: the DEFAULT
+    constructor -- off_range="integrate" -- hands the envs at the limit to step_sat_hybrid_kernel (csrc/pvder_sat_hybrid.hpp:
+    flight / impact / contact on the slow time scale, events located inside the steps, fp64 between the fp32 rows), which the
+    plan launches behind the step kernel from the moment an env passes 98.75 % of the limit: worst env step 6.4e-3, MEDIAN
+    1.5e-5 beyond saturation (rounds 3-5, "held_modes": 9.1e-2 / 8.0e-4 -- kept below as the A/B).  The worst step sits where an
+    event grazes its surface (4e-3 ... 6e-3 between the fp64 host build of the same source, the fp64 prototype and the device:
+    profiles/r06_sat_hybrid_proto.txt, tests/test_sat_hybrid_host.py)."""
     import bridge_cases
     name = "ramp_a%d" % action
     g = bridge_cases.load(name)
@@ -767,6 +768,7 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
     env = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"])
     assert env.integrator == "etdlin" and env.off_range == "integrate"
     env.reset()
+    assert not env._lib.pvder_plan_hybrid_active(env._plan or env._make_plan())
     # the device generator reproduces the golden's event tables bit for bit
     assert np.array_equal(env.ev_vg.cpu().numpy(), vg.astype(np.float32)) and np.array_equal(env.ev_si.cpu().numpy(), si.astype(np.float32))
     a = torch.full((c["N"],), action, dtype=torch.uint8, device=gpu_device)
@@ -805,22 +807,33 @@ def test_fixed_action_ramps_vs_converged_bridge(gpu_device, action):
         e_sat = rel_l2(got[last:], want[last:], axis=2)
         spread = rel_l2(g["obs_coarser"][last:], want[last:], axis=2)
         assert float(g["rtol"]) <= 1e-12 and str(g["method"]) == "filippov" and spread.max() < 1e-5, spread.max()
-        # measured (tools/a4_saturated_numbers.py, profiles/r05_a4_saturated_numbers.txt): worst env step 9.1e-2 (where a phase
-        # enters or leaves the limit), MEDIAN 8.0e-4
-        assert e_sat.max() < 1.5e-1, (last + int(e_sat.max(axis=1).argmax()), e_sat.max())
-        assert np.median(e_sat) < 5e-3, np.median(e_sat)
-        # ... and the quantities a policy is rewarded on stay close: Vdc (obs 6: worst 1.4e-2, median 2.8e-4) and P_PCC
-        # (obs 4: worst 4.2e-2, median 8.3e-4)
-        assert np.abs(got[last:, :, 6] / want[last:, :, 6] - 1.0).max() < 2.5e-2
-        assert np.abs(got[last:, :, 4] / want[last:, :, 4] - 1.0).max() < 8e-2
-        assert np.median(np.abs(got[last:, :, 6] / want[last:, :, 6] - 1.0)) < 1e-3
+        # measured (tools/a4_hybrid_numbers.py, profiles/r06_a4_hybrid_numbers.txt): worst env step per env 5.0e-4 / 4.1e-3 / 6.4e-3 /
+        # 3.8e-4, MEDIAN 1.5e-5 (VERDICT r5 #1 asked for 5e-3 / 2e-4; rounds 3-5: 9.1e-2 / 8.0e-4)
+        assert env._lib.pvder_plan_hybrid_active(env._plan)            # the hybrid kernel followed the step launches
+        assert e_sat.max() < 1e-2, (last + int(e_sat.max(axis=1).argmax()), e_sat.max())
+        assert np.median(e_sat) < 2e-4, np.median(e_sat)
+        assert np.sort(e_sat.max(axis=0))[1] < 5e-3, e_sat.max(axis=0)           # (two of the four envs well inside 5e-3)
+        # ... and the quantities a policy is rewarded on: Vdc (obs 6) and P_PCC (obs 4)
+        assert np.abs(got[last:, :, 6] / want[last:, :, 6] - 1.0).max() < 2e-3
+        assert np.abs(got[last:, :, 4] / want[last:, :, 4] - 1.0).max() < 1e-2
+        assert np.median(np.abs(got[last:, :, 6] / want[last:, :, 6] - 1.0)) < 2e-5
         # an env that has left the limit again finds its way back to the converged solution (fp64 prototype of the
         # switched steps: 1e-2 two env steps behind a saturated stretch, 1e-3 after six)
         e_all = rel_l2(got, want, axis=2)
         clear = np.array([g["m_abs"][max(0, t - 8):t + 1].max(axis=0) < 0.985 for t in range(c["steps"])])     # [steps, N]
         sel = clear[last:]
         if sel.any():
-            assert e_all[last:][sel].max() < 2e-2, e_all[last:][sel].max()
+            assert e_all[last:][sel].max() < 5e-3, e_all[last:][sel].max()
+        # A/B: rounds 3-5's held operator sets on the same episode -- an order of magnitude and more behind (what the hybrid kernel is for)
+        old = make_vec(c["N"], gpu_device, seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], off_range="held_modes")
+        old.reset()
+        held = []
+        for t in range(c["steps"]):
+            obs, _, _, _ = old.step(a)
+            held.append(obs.cpu().numpy().astype(np.float64))
+        e_held = rel_l2(np.stack(held)[last:], want[last:], axis=2)
+        assert e_held.max() > 5 * e_sat.max() and np.median(e_held) > 10 * np.median(e_sat), (e_held.max(), np.median(e_held))
+        assert np.array_equal(np.stack(held)[:last - 30], got[:last - 30])       # the same bits until an env comes near the limit
 
 
 
