@@ -565,21 +565,27 @@ def desynchronised_leg(torch, dev, N, n_sub, steps=640, warm=160):
     for k in range(ep):               # after these ep steps env e is (ep - 1 - phase[e]) steps behind its last masked reset
         env.step(acts[k], return_tensors=False)
         env.reset(phase == k)
-    env.rollout(acts[:warm], fused=False)
+    def timed():
+        env.rollout(acts[:warm], fused=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0.record(); env.rollout(acts[:steps], fused=False); e1.record()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3 / steps
     spread = int(torch.unique(env.istate[0]).numel())
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    e0.record(); env.rollout(acts[:steps], fused=False); e1.record()
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    per = e0.elapsed_time(e1) * 1e-3 / steps
+    el_u, per_u = timed()                              # the envs where the resets left them: every wave mixes clocks
+    env.sort_lanes(lane_io=True)                       # ... and re-ordered in the buffers by clock (round 6: PVDERVec.sort_lanes)
+    el, per = timed()
     return {"value": N * steps / el, "unit": "env-steps/s", "steps": steps, "us_per_step": 1e6 * el / steps,
             "region_us_per_step": per * 1e6, "distinct_clocks_in_the_batch": spread, "episode_steps": ep,
             "hbm_frac": BYTES_PER_ENV_STEP["f32"] * N / per / HBM_PEAK, "kernel": env.kernel_name(),
             "n_nonfinite": env.step_stats()["n_nonfinite"],
+            "unsorted": {"value": N * steps / el_u, "us_per_step": 1e6 * el_u / steps, "region_us_per_step": per_u * 1e6,
+                         "note": "the same batch before sort_lanes(): waves mix quiet and event lanes, 64 event rows per wave and load"},
             "workload": "%d envs, events on, random actions, auto-reset, episode phases spread over all %d clocks by staggered masked "
-                        "resets: waves mix quiet and event lanes, the clock hint misses, a few envs end their episode in every step" % (N, ep)}
+                        "resets (a few envs end their episode in every step; the clock hint misses), the envs re-ordered in the buffers "
+                        "by clock (PVDERVec.sort_lanes: homogeneous waves, one event row per wave; bit-identical per env id)" % (N, ep)}
 
 
 def large_batch_leg(torch, dev, n_sub, N=1 << 20, steps=300, warm=60):

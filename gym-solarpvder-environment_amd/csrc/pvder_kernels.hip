@@ -131,6 +131,7 @@ struct ResetK {
     int enabled, keep_events;
     uint64_t seed;
     int64_t env_id_base;
+    const int32_t *env_ids;      // device, or NULL: the env a lane carries (pvder_autoreset.env_ids: a batch whose envs were re-ordered)
     pvder_event_spec spec;
     double y0[23];
 };
@@ -399,7 +400,7 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
             const int episode = istate[PVDER_I_EPISODE * N + e] + 1;
             istate[PVDER_I_EPISODE * N + e] = episode;
             if (!R.keep_events)
-                fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + e), (uint64_t)episode,
+                fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + (R.env_ids ? (int64_t)R.env_ids[e] : (int64_t)e)), (uint64_t)episode,
                             ev_vg, ev_si, N, e);
 #pragma unroll
             for (int q = 0; q < NS; ++q) y[q] = (T)R.y0[q];
@@ -3950,7 +3951,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(
     istate[PVDER_I_STATUS * N + e] = 0;
     istate[PVDER_I_EPISODE * N + e] = episode;
     if (!R.keep_events)
-        fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + e), (uint64_t)episode, ev_vg,
+        fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + (R.env_ids ? (int64_t)R.env_ids[e] : (int64_t)e)), (uint64_t)episode, ev_vg,
                     ev_si, N, e);
     if (out) {
         SubK<T, PH> S;
@@ -4027,14 +4028,14 @@ StepK<T> fold_cfg(const pvder_step_cfg *c) {
 }
 
 int fold_reset(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, ResetK &R) {
-    R.enabled = 0; R.keep_events = 1; R.seed = 0; R.env_id_base = 0;
+    R.enabled = 0; R.keep_events = 1; R.seed = 0; R.env_id_base = 0; R.env_ids = nullptr;
     R.spec = pvder_event_spec{};
     for (int k = 0; k < 23; ++k) R.y0[k] = 0.0;
     if (!ar) return 0;
     if (!ar->y0) return PVDER_EINVAL;
     if (ar->spec.ev_count != cfg->ev_count) return PVDER_EINVAL;
     const int ns = PVDER_NS((int)par[PVDER_PAR_PHASES]);
-    R.enabled = ar->enabled; R.keep_events = ar->keep_events; R.seed = ar->seed; R.env_id_base = ar->env_id_base;
+    R.enabled = ar->enabled; R.keep_events = ar->keep_events; R.seed = ar->seed; R.env_id_base = ar->env_id_base; R.env_ids = ar->env_ids;
     R.spec = ar->spec;
     for (int k = 0; k < ns; ++k) R.y0[k] = ar->y0[k];
     return 0;

@@ -61,7 +61,7 @@ class EventSpec(C.Structure):
 class AutoReset(C.Structure):
     """``struct pvder_autoreset`` (include/pvder_hip.h)."""
     _fields_ = [("enabled", C.c_int32), ("keep_events", C.c_int32), ("seed", C.c_uint64),
-                ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double))]
+                ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double)), ("env_ids", C.c_void_p)]
 
 
 class QAgentCfg(C.Structure):

@@ -268,6 +268,9 @@ class PVDERVec(EnvSpecMixin):
             self.set_lane_params(lane_params)
         self._needs_reset = True
         self._plan = None
+        self._env_of_lane = None     # sort_lanes(): int32 [N], the env id column l of every buffer carries (None = identity)
+        self._lane_of_env = None
+        self.lane_io = False         # True: step / rollout / reset take and return LANE order (no gathers); see sort_lanes
         self._ksub_hint = -1         # pvder_plan_hint: the clock the batch's envs are at (survives plan rebuilds; -1 = unknown)
 
     def __del__(self):
@@ -396,8 +399,9 @@ class PVDERVec(EnvSpecMixin):
 
     @property
     def obs(self) -> torch.Tensor:
-        """[N, 11] view of the SoA output block (valid until the next step/reset)."""
-        return self.out[:11].t()
+        """[N, 11] view of the SoA output block (valid until the next step/reset); a copy in env order behind sort_lanes() unless
+        ``lane_io``."""
+        return self.to_env_order(self.out[:11]).t() if self._mapped() else self.out[:11].t()
 
     @property
     def Q_ref(self) -> torch.Tensor:
@@ -685,6 +689,67 @@ class PVDERVec(EnvSpecMixin):
         if self._plan is not None:
             self._lib.pvder_plan_graph_hints(self._plan, 1 if on else 0)
 
+    # -- the order of the envs in the buffers (PVDER_env.py:316-334, :400-411: every env owns its clock and events) --
+    def sort_lanes(self, key: Optional[torch.Tensor] = None, lane_io: Optional[bool] = None):
+        """Re-order the envs IN the buffers -- by default by clock (``istate[0]``: sim time steps into the episode), stably -- so
+        that the 64 lanes of a wave hold envs at the same point of their episodes: one step schedule per wave (a quiet step OR a step
+        behind an event row, not both), ONE event row read per wave (4 cache lines instead of 64), i.e. a batch whose envs were reset
+        one by one steps at the lockstep rate again (bench.py `desynchronised`: 21.8 -> ~9 us).  The envs keep their identity:
+        ``env_of_lane`` ([N] int32) says which env column l carries, the event generator stays keyed by the env id (auto-resets
+        draw what they would have drawn), results are bit-identical PER ENV ID to the unsorted batch
+        (tests/test_gpu_etdlin.py::test_sorted_lanes_are_bit_identical_per_env_id).  I/O: with ``lane_io=False`` (default) step /
+        rollout / reset still take and return ENV order -- two gathers per call; with ``lane_io=True`` they take and return LANE
+        order (row l <-> env ``env_of_lane[l]``: what a vectorised policy, to which envs are exchangeable, wants).  Call again when
+        masked resets have changed the phases; envs whose episodes have one length keep their order for ever."""
+        if self._traj is not None:
+            raise RuntimeError("sort_lanes: not while a trajectory is recorded (record_trajectory names lanes)")
+        N = self.num_envs
+        with self._device_ctx():
+            k = self.istate[0] if key is None else key.to(self.device)
+            if k.shape != (N,):
+                raise ValueError("key must have shape (%d,)" % N)
+            order = torch.argsort(k.to(torch.int64), stable=True)              # lane l of the new order takes what lane order[l] holds
+            tensors = [self._state_and_out, self.istate, self.ev_vg, self.ev_si]
+            if self.hstep is not None:
+                tensors.append(self.hstep)
+            if self.__dict__.get("_lane_folded") is not None:
+                tensors.append(self._lane_folded)
+            if self.out.data_ptr() != self._state_and_out[self.ns + 2:].data_ptr():
+                tensors.append(self.out)                                       # (use_out: an output block of the caller's)
+            for t in tensors:
+                t.copy_(t.index_select(t.dim() - 1, order))
+            if self._env_of_lane is None:
+                object.__setattr__(self, "_env_of_lane", torch.arange(N, dtype=torch.int32, device=self.device))
+                self._drop_plan()              # (the reset block now names the env ids: pvder_autoreset.env_ids)
+            self._env_of_lane.copy_(self._env_of_lane.index_select(0, order))  # in place: plans keep the pointer
+            inv = torch.empty(N, dtype=torch.int64, device=self.device)
+            inv[self._env_of_lane.long()] = torch.arange(N, dtype=torch.int64, device=self.device)
+            object.__setattr__(self, "_lane_of_env", inv)
+            object.__setattr__(self, "_ksub_hint", -1)                         # no common clock any more
+            if self._plan is not None:
+                self._lib.pvder_plan_hint(self._plan, -1)
+        if lane_io is not None:
+            self.lane_io = bool(lane_io)
+
+    @property
+    def env_of_lane(self) -> Optional[torch.Tensor]:
+        return self._env_of_lane
+
+    @property
+    def lane_of_env(self) -> Optional[torch.Tensor]:
+        return self._lane_of_env
+
+    def to_lane_order(self, t: torch.Tensor) -> torch.Tensor:
+        """[..., N] in env order -> lane order (identity while the batch is unsorted)."""
+        return t if self._env_of_lane is None else t.index_select(t.dim() - 1, self._env_of_lane.long())
+
+    def to_env_order(self, t: torch.Tensor) -> torch.Tensor:
+        """[..., N] in lane order (``self.out``, ``self.fstate`` ...) -> env order."""
+        return t if self._lane_of_env is None else t.index_select(t.dim() - 1, self._lane_of_env)
+
+    def _mapped(self):
+        return self._env_of_lane is not None and not self.lane_io
+
     def _device_ctx(self):
         """``torch.cuda.device(self.device)``, or nothing when it is the current device already."""
         if torch.cuda.current_device() == self.device.index:
@@ -702,6 +767,8 @@ class PVDERVec(EnvSpecMixin):
         a.env_id_base = self.env_id_base
         a.spec = self._spec()
         a.y0 = C.cast(self._y0_c, C.POINTER(C.c_double))
+        eol = self.__dict__.get("_env_of_lane")
+        a.env_ids = eol.data_ptr() if eol is not None else None
         return a
 
     def _reset_launch(self, mask: Optional[torch.Tensor]):
@@ -729,6 +796,8 @@ class PVDERVec(EnvSpecMixin):
             if mask is not None:
                 mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
                 assert mask.shape == (self.num_envs,)
+                if self._mapped():
+                    mask = self.to_lane_order(mask).contiguous()
             self._reset_launch(mask)
             # the plan is checked at every reset (never inside a graph capture): specs edited in place
             # (env_events_spec[...]['ENABLE'], env_reward_spec['reference_values'], my_spec lists) take effect here at
@@ -766,6 +835,8 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("actions must have shape (%d,)" % self.num_envs)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        if self._mapped():
+            actions = self.to_lane_order(actions).contiguous()
         plan = self._plan or self._make_plan()      # cfg / reset block / coefficients folded once (C side)
         with self._device_ctx():
             timed = False
@@ -790,6 +861,9 @@ class PVDERVec(EnvSpecMixin):
                 self._traj_append()
             if not return_tensors:
                 return None
+            if self._mapped():
+                o = self.to_env_order(self.out)
+                return o[:11].t(), o[11], o[12] != 0, {}
             return self.obs, self.out[11], self.out[12] != 0, {}
 
     def rollout(self, actions: torch.Tensor, out: Optional[torch.Tensor] = None, fused: Optional[bool] = None):
@@ -807,6 +881,8 @@ class PVDERVec(EnvSpecMixin):
             raise ValueError("actions must have shape (K, %d)" % self.num_envs)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        if self._mapped():
+            actions = self.to_lane_order(actions).contiguous()
         K = int(actions.shape[0])
         stride = 0
         dst = self.out
@@ -846,6 +922,8 @@ class PVDERVec(EnvSpecMixin):
                 _native.check(rc, "pvder_plan_rollout")
             if out is not None and K > 0:
                 self.out.copy_(out[K - 1])
+                if self._mapped():
+                    out.copy_(out.index_select(2, self._lane_of_env))      # the caller's blocks in ENV order (self.out stays in lane order)
 
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,
@@ -861,6 +939,8 @@ class PVDERVec(EnvSpecMixin):
              "ev_si": self.ev_si.clone(), "out": self.out.clone(), "stats": self.stats.clone()}
         if self.hstep is not None:
             d["hstep"] = self.hstep.clone()
+        if self._env_of_lane is not None:
+            d["env_of_lane"] = self._env_of_lane.clone()
         return d
 
     def load_state_dict(self, d: Dict[str, torch.Tensor]):
@@ -872,6 +952,16 @@ class PVDERVec(EnvSpecMixin):
             t.copy_(d[k])
         if self.hstep is not None:
             self.hstep.copy_(d["hstep"])
+        if "env_of_lane" in d:
+            if self._env_of_lane is None:
+                object.__setattr__(self, "_env_of_lane", torch.arange(self.num_envs, dtype=torch.int32, device=self.device))
+                self._drop_plan()
+            self._env_of_lane.copy_(d["env_of_lane"])
+            inv = torch.empty(self.num_envs, dtype=torch.int64, device=self.device)
+            inv[self._env_of_lane.long()] = torch.arange(self.num_envs, dtype=torch.int64, device=self.device)
+            object.__setattr__(self, "_lane_of_env", inv)
+        elif self._env_of_lane is not None:
+            raise ValueError("this env's lanes are sorted (sort_lanes) and the state_dict holds no env_of_lane")
         self._needs_reset = False
         with self._device_ctx():
             hint = int(self.istate[0, 0].item())                 # (PVDER_I_KSUB of env 0: where a batch in lockstep is)

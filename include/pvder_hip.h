@@ -169,6 +169,11 @@ typedef struct pvder_autoreset {
     pvder_event_spec spec;
     const double *y0;        /* host, PVDER_NS doubles: steady state in the kernels' state order
                                 (last entry = delta = wte - wbase*t at t = 0) */
+    const int32_t *env_ids;  /* (ABI 17) device, int32[n_env], or NULL = identity: the env that column e of every buffer carries.  The
+                                envs of a batch are independent (PVDER_env.py:138-196) and a caller may ORDER them as it likes -- by
+                                clock, so that the lanes of a wave run one schedule and read one event row
+                                (gym_PVDER_amd.PVDERVec.sort_lanes: a desynchronised batch at the lockstep rate) --; what follows an
+                                env's identity is the event generator's key (seed, env_id_base + env_ids[e], episode, k). */
 } pvder_autoreset;
 
 int pvder_version(void);

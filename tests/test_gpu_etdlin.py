@@ -876,3 +876,54 @@ print("max |m_a| at the end", float(m.max()))
         files.append(f)
     a, b = np.load(files[0]), np.load(files[1])
     assert a.shape == b.shape and np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+def test_sorted_lanes_are_bit_identical_per_env_id(gpu_device):
+    """VERDICT r5 #3 (PVDER_env.py:316-334, :400-411: every env owns its clock and its events): a batch whose envs were reset one by
+    one -- phases spread over the episode -- with its envs RE-ORDERED in the buffers by clock (PVDERVec.sort_lanes: homogeneous
+    waves, one event row per wave) gives, env id by env id, the very bits of the unsorted batch: states, counters, event tables,
+    outputs -- through episode ends (the event generator stays keyed by the env id), in env-order I/O, in lane-order I/O and
+    through a rollout with per-step output blocks."""
+    from helpers import both_events_spec
+    N, ep = 1024, 16                                             # (max_sim_time 4 s: 16 env steps per episode)
+    kw = dict(seed=5, events_spec=both_events_spec(), auto_reset=True, max_sim_time=4.0)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(9)
+    acts = torch.randint(0, 5, (3 * ep + 40, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    phase = (torch.arange(N, device=gpu_device, dtype=torch.int64) * 7919) % ep
+    envs = [make_vec(N, gpu_device, **kw) for _ in range(3)]
+    for e in envs:
+        e.reset()
+        for k in range(ep):                                      # staggered masked resets: env e ends up (ep - 1 - phase[e]) steps in
+            e.step(acts[k], return_tensors=False)
+            e.reset(phase == k)
+    a, b, c = envs                                               # a: unsorted; b: sorted, env-order I/O; c: sorted, lane-order I/O
+    assert int(torch.unique(a.istate[0]).numel()) == ep
+    b.sort_lanes()
+    c.sort_lanes(lane_io=True)
+    assert bool((b.istate[0][1:] >= b.istate[0][:-1]).all()) and torch.equal(torch.sort(b.env_of_lane.long()).values, torch.arange(N, device=gpu_device))
+    for k in range(ep, ep + 40):
+        oa, ra, da, _ = a.step(acts[k])
+        ob, rb, db, _ = b.step(acts[k])
+        oc, rc, dc, _ = c.step(c.to_lane_order(acts[k]).contiguous())
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), k
+        assert torch.equal(oa, c.to_env_order(oc.t()).t()) and torch.equal(ra, c.to_env_order(rc)) and torch.equal(da, c.to_env_order(dc)), k
+    assert int(a.istate[2].max()) >= 4                           # several episode ends per env inside the run
+    for name in ("fstate", "istate", "ev_vg", "ev_si", "out"):
+        assert torch.equal(getattr(a, name), b.to_env_order(getattr(b, name))), name
+        assert torch.equal(getattr(a, name), c.to_env_order(getattr(c, name))), name
+    # a rollout with per-step blocks, and a masked reset given in env order
+    K = 2 * ep
+    outa = torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device); outb = torch.empty_like(outa)
+    a.rollout(acts[ep + 40:ep + 40 + K], out=outa, fused=False)
+    b.rollout(acts[ep + 40:ep + 40 + K], out=outb, fused=False)
+    assert torch.equal(outa, outb)
+    m = (torch.arange(N, device=gpu_device) % 7) == 3
+    assert torch.equal(a.reset(m), b.reset(m)) and torch.equal(a.fstate, b.to_env_order(b.fstate)) and torch.equal(a.ev_vg, b.to_env_order(b.ev_vg))
+    b.sort_lanes()                                               # the phases changed: sort again, same envs, same bits
+    oa, ra, da, _ = a.step(acts[0]); ob, rb, db, _ = b.step(acts[0])
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    # checkpoint: the order travels with the state
+    d = b.state_dict()
+    b2 = make_vec(N, gpu_device, **kw); b2.reset(); b2.load_state_dict(d)
+    o1 = b.step(acts[1])[0].clone(); o2 = b2.step(acts[1])[0]
+    assert torch.equal(o1, o2)
