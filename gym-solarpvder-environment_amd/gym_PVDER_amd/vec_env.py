@@ -705,10 +705,19 @@ class PVDERVec(EnvSpecMixin):
             raise RuntimeError("sort_lanes: not while a trajectory is recorded (record_trajectory names lanes)")
         N = self.num_envs
         with self._device_ctx():
-            k = self.istate[0] if key is None else key.to(self.device)
+            if key is None:
+                # by clock -- and, first, by the clock's position in the event grid: whether an env step starts at an event row (tick +
+                # two ETD3RK steps) or not (one Krogstad step) depends on (ksub - ev_s0) mod ev_ds alone, so the envs that take the
+                # SAME schedule in any given step are contiguous (an event every 4th env step: four runs of N / 4 envs; sorted by
+                # clock alone every 4th boundary between two clocks would sit inside a wave that then runs both schedules)
+                k = self.istate[0].to(torch.int64)
+                if self.ev_count > 0 and self.ev_ds > 0:
+                    k = ((k - self.ev_s0) % self.ev_ds) * (1 << 32) + k
+            else:
+                k = key.to(self.device).to(torch.int64)
             if k.shape != (N,):
                 raise ValueError("key must have shape (%d,)" % N)
-            order = torch.argsort(k.to(torch.int64), stable=True)              # lane l of the new order takes what lane order[l] holds
+            order = torch.argsort(k, stable=True)                              # lane l of the new order takes what lane order[l] holds
             tensors = [self._state_and_out, self.istate, self.ev_vg, self.ev_si]
             if self.hstep is not None:
                 tensors.append(self.hstep)

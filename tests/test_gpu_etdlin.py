@@ -900,7 +900,8 @@ def test_sorted_lanes_are_bit_identical_per_env_id(gpu_device):
     assert int(torch.unique(a.istate[0]).numel()) == ep
     b.sort_lanes()
     c.sort_lanes(lane_io=True)
-    assert bool((b.istate[0][1:] >= b.istate[0][:-1]).all()) and torch.equal(torch.sort(b.env_of_lane.long()).values, torch.arange(N, device=gpu_device))
+    kb = ((b.istate[0].long() - b.ev_s0) % b.ev_ds) * (1 << 32) + b.istate[0].long()      # by position in the event grid, then by clock
+    assert bool((kb[1:] >= kb[:-1]).all()) and torch.equal(torch.sort(b.env_of_lane.long()).values, torch.arange(N, device=gpu_device))
     for k in range(ep, ep + 40):
         oa, ra, da, _ = a.step(acts[k])
         ob, rb, db, _ = b.step(acts[k])
