@@ -132,6 +132,7 @@ struct ResetK {
     uint64_t seed;
     int64_t env_id_base;
     const int32_t *env_ids;      // device, or NULL: the env a lane carries (pvder_autoreset.env_ids: a batch whose envs were re-ordered)
+    int lazy;                    // pvder_autoreset.lazy_events: an auto-reset writes the rows its first step reads, every step the rows its successor reads
     pvder_event_spec spec;
     double y0[23];
 };
@@ -162,14 +163,13 @@ __device__ __forceinline__ float lerp_unfused(float lo, float hi, float u) {
 
 // create_random_events (PVDER_env.py:400-411): one event per grid time, type drawn from the ENABLEd
 // list (dict order: insolation, voltage -- :60-61), value U[min,max]; rows k = 0..K of env e
-__device__ __forceinline__ void fill_events(const pvder_event_spec &spec, float sinsol0, uint64_t seed,
-                                         uint64_t gid, uint64_t episode, float *__restrict__ ev_vg,
-                                         float *__restrict__ ev_si, size_t N, int e) {
-    float vg = 1.0f, si = sinsol0;
-    ev_vg[e] = vg;
-    ev_si[e] = si;
+// rows j0+1 .. j1 of env e from the values of row j0 (an event changes ONE of the two inputs: the other is carried)
+__device__ __forceinline__ void fill_event_rows(const pvder_event_spec &spec, uint64_t seed, uint64_t gid, uint64_t episode,
+                                                float *__restrict__ ev_vg, float *__restrict__ ev_si, size_t N, int e, int j0, int j1,
+                                                float vg, float si) {
     const int n_en = (spec.enable_insol != 0) + (spec.enable_voltage != 0);
-    for (int k = 1; k <= spec.ev_count; ++k) {
+    if (j1 > spec.ev_count) j1 = spec.ev_count;
+    for (int k = j0 + 1; k <= j1; ++k) {
         if (n_en > 0) {
             const float ut = counter_uniform(seed, gid, episode, k, 0);
             const float uv = counter_uniform(seed, gid, episode, k, 1);
@@ -182,6 +182,13 @@ __device__ __forceinline__ void fill_events(const pvder_event_spec &spec, float 
         ev_vg[(size_t)k * N + e] = vg;
         ev_si[(size_t)k * N + e] = si;
     }
+}
+__device__ __forceinline__ void fill_events(const pvder_event_spec &spec, float sinsol0, uint64_t seed,
+                                         uint64_t gid, uint64_t episode, float *__restrict__ ev_vg,
+                                         float *__restrict__ ev_si, size_t N, int e) {
+    ev_vg[e] = 1.0f;
+    ev_si[e] = sinsol0;
+    fill_event_rows(spec, seed, gid, episode, ev_vg, ev_si, N, e, 0, spec.ev_count, 1.0f, sinsol0);
 }
 
 // event-table row active at sim-time-step g (events at ksub = s0 + j*ds, j = 0..K-1; an event
@@ -361,19 +368,18 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
                                          T *__restrict__ out, float *__restrict__ stats, int n_env,
                                          int stats_fresh = 0, bool have_inputs = false, float vg_stop = 0.f,
                                          float si_stop = 0.f, const float *__restrict__ lane_par = nullptr,
-                                         bool stats_local = false) {
+                                         bool stats_local = false, int gen_j0 = -1, int gen_j1 = -1, int episode_now = -1) {
     // have_inputs: the caller fetched the event inputs in force at tStop ahead of the integration (same table
     // entries; a lone wave per SIMD would otherwise sit out a memory round trip right here)
     constexpr int NS = 6 * PH + 5;
     const size_t N = (size_t)n_env;
     const int ec = L.ec;
     SubK<T, PH> S;
-    if (have_inputs) {
-        pvder::make_sub<T, PH>(P, (T)vg_stop, (T)si_stop, S);
-    } else {
+    if (!have_inputs) {
         const int row = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count);
-        pvder::make_sub<T, PH>(P, (T)ev_vg[(size_t)row * N + ec], (T)ev_si[(size_t)row * N + ec], S);
+        vg_stop = ev_vg[(size_t)row * N + ec]; si_stop = ev_si[(size_t)row * N + ec];
     }
+    pvder::make_sub<T, PH>(P, (T)vg_stop, (T)si_stop, S);
     T iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms;
     pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
     T reward = reward_of<T>(C, P, vrms, Ppcc, Qpcc, y[6 * PH], L.vdcref, L.qref);
@@ -394,21 +400,49 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
         done_f = L.status != 0 ? 1.f : 0.f;
         T Vdc = y[6 * PH];
         T tfrac = (T)L.ksub * (T)(1.0 / 60.0) * C.inv_tmax;
-        if (AR && R.enabled && L.status != 0) {
+        const bool restart = AR && R.enabled && L.status != 0;
+        if (R.enabled && !R.keep_events && (restart || R.lazy)) {
+            // ---- the event tables of the generator (create_random_events, PVDER_env.py:400-411).  Whole at the auto-reset (the
+            // round-1 scheme: 38 rows x 2 counter hashes per env, serial in the lane -- 4.6 us for a wave whose envs end together,
+            // profiles/r06_desync_breakdown.txt), or AS THE EPISODE ADVANCES (lazy): a step leaves behind the rows its successor
+            // reads -- rows <= event_row(tStop + n_sub) --, carried from the tStop row it holds anyway; the auto-reset writes
+            // row 0 (and what the first step reads).  Rows beyond that are the previous episode's until their turn comes
+            // (pvder_complete_event_tables for a reader that wants them all).
+            // (gen_j0, gen_j1, episode_now: a caller that knew the clock at the start of the launch has them ready -- two integer
+            // divisions and a dependent load less behind the integration: lin_step_lean)
+            int j0 = 0, j1 = 0;
+            float cvg = 1.0f, csi = (float)P.sinsol0;
+            if (restart) {
+                j1 = R.lazy ? event_row(C.n_sub, C.ev_s0, C.ev_ds, C.ev_count) : R.spec.ev_count;
+            } else {
+                if (gen_j0 >= 0) { j0 = gen_j0; j1 = gen_j1; }
+                else { j0 = event_row(L.ksub, C.ev_s0, C.ev_ds, C.ev_count); j1 = event_row(L.ksub + C.n_sub, C.ev_s0, C.ev_ds, C.ev_count); }
+                cvg = vg_stop; csi = si_stop;
+            }
+            if (restart || j1 > j0) {
+                const int episode = (!restart && episode_now >= 0) ? episode_now : istate[PVDER_I_EPISODE * N + e] + (restart ? 1 : 0);
+                if (restart) {
+                    istate[PVDER_I_EPISODE * N + e] = episode;
+                    ev_vg[e] = cvg; ev_si[e] = csi;
+                }
+                fill_event_rows(R.spec, R.seed, (uint64_t)(R.env_id_base + (R.env_ids ? (int64_t)R.env_ids[e] : (int64_t)e)), (uint64_t)episode,
+                                ev_vg, ev_si, N, e, j0, j1, cvg, csi);
+            }
+        } else if (restart) {
+            istate[PVDER_I_EPISODE * N + e] += 1;
+        }
+        if (restart) {
             // same-step auto-reset: reward/done rows keep the transition that ended the episode,
             // the observation rows and the carried state restart from the steady state
-            const int episode = istate[PVDER_I_EPISODE * N + e] + 1;
-            istate[PVDER_I_EPISODE * N + e] = episode;
-            if (!R.keep_events)
-                fill_events(R.spec, (float)P.sinsol0, R.seed, (uint64_t)(R.env_id_base + (R.env_ids ? (int64_t)R.env_ids[e] : (int64_t)e)), (uint64_t)episode,
-                            ev_vg, ev_si, N, e);
 #pragma unroll
             for (int q = 0; q < NS; ++q) y[q] = (T)R.y0[q];
             if (lane_par) lane_steady_state<T, PH>(lane_par, N, e, y);      // the env's OWN operating point (PVDER_env.py:374-378)
             L.qref = (T)0;
             L.vdcref = P.vdc_ref0;
             L.ksub = 0; L.steps = 0; L.status = 0;
-            pvder::make_sub<T, PH>(P, (T)ev_vg[e], (T)ev_si[e], S);
+            // (row 0 of the tables: the generator's 1.0 pu / nominal insolation, or what an explicit table holds)
+            if (R.keep_events) pvder::make_sub<T, PH>(P, (T)ev_vg[e], (T)ev_si[e], S);
+            else pvder::make_sub<T, PH>(P, (T)1.0f, (T)(float)P.sinsol0, S);
             pvder::outputs<T, PH>(P, S, y, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ppv, vrms);
             Vdc = y[6 * PH];
             tfrac = (T)0;
@@ -2979,6 +3013,17 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
         else if (sg.until < A.C.n_sub) row_stop = event_row(ksub_hint + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
         vg_stop = A.ev_vg[(size_t)row_stop * N + ec0]; si_stop = A.ev_si[(size_t)row_stop * N + ec0];
     }
+    // (pvder_autoreset.lazy_events: the table rows this step leaves behind for its successor -- rows gen_j0+1 .. gen_j1, one step in
+    //  four at PVDER-v0's grid -- and the episode word their hash is keyed with, asked for here with everything else)
+    int gen_j0 = -1, gen_j1 = -1, episode_now = -1;
+    auto rows_to_leave = [&](const LinSeg &s0, int ec) {
+        if (!A.R.lazy) return;
+        const int n = A.C.n_sub, K = A.C.ev_count;
+        auto within = [&](int span) { return s0.until <= span ? 1 + (span - s0.until >= A.C.ev_ds ? (span - s0.until) / A.C.ev_ds : 0) : 0; };
+        gen_j0 = min(s0.row + within(n), K); gen_j1 = min(s0.row + within(2 * n), K);
+        if (gen_j1 > gen_j0) episode_now = istate[PVDER_I_EPISODE * N + ec];
+    };
+    if (hinted) rows_to_leave(sg, ec0);
     prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
     if (__builtin_amdgcn_readfirstlane(__any((int)(!hinted || (L.run && L.ksub != ksub_hint))))) {
         sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
@@ -2986,6 +3031,8 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
         if (sg.until == A.C.n_sub) row_stop = sg.row + 1 < A.C.ev_count ? sg.row + 1 : A.C.ev_count;
         else if (sg.until < A.C.n_sub) row_stop = event_row(L.ksub + A.C.n_sub, A.C.ev_s0, A.C.ev_ds, A.C.ev_count);
         vg_stop = A.ev_vg[(size_t)row_stop * N + L.ec]; si_stop = A.ev_si[(size_t)row_stop * N + L.ec];
+        episode_now = -1;
+        rows_to_leave(sg, L.ec);
     }
     PVDER_TRACE_AT(1);
     bool leave = PH == 3 && A.force_full != 0;
@@ -3008,8 +3055,11 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
     PVDER_LAUNDER_EPI(ka);
     const EtdArgs &E = *(const EtdArgs *)ka;
     if (leave) { L.run = false; L.live = false; }
+    // (a use the compiler cannot move: the episode word was asked for at the START of the launch and stays asked for there --
+    //  left alone, its load sinks into the one block that reads it, behind the integration: a memory round trip per generated row)
+    asm volatile("" : "+v"(episode_now));
     epilogue<float, PH>(E.P, E.C, E.R, L, ys, E.fstate, E.istate, E.ev_vg, E.ev_si, E.out, E.stats, E.n_env, stats_fresh, true,
-                        vg_stop, si_stop);
+                        vg_stop, si_stop, nullptr, false, gen_j0, gen_j1, episode_now);
     PVDER_TRACE_AT(21);
     return leave;
 }
@@ -4028,7 +4078,7 @@ StepK<T> fold_cfg(const pvder_step_cfg *c) {
 }
 
 int fold_reset(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, ResetK &R) {
-    R.enabled = 0; R.keep_events = 1; R.seed = 0; R.env_id_base = 0; R.env_ids = nullptr;
+    R.enabled = 0; R.keep_events = 1; R.seed = 0; R.env_id_base = 0; R.env_ids = nullptr; R.lazy = 0;
     R.spec = pvder_event_spec{};
     for (int k = 0; k < 23; ++k) R.y0[k] = 0.0;
     if (!ar) return 0;
@@ -4036,6 +4086,7 @@ int fold_reset(const double *par, const pvder_step_cfg *cfg, const pvder_autores
     if (ar->spec.ev_count != cfg->ev_count) return PVDER_EINVAL;
     const int ns = PVDER_NS((int)par[PVDER_PAR_PHASES]);
     R.enabled = ar->enabled; R.keep_events = ar->keep_events; R.seed = ar->seed; R.env_id_base = ar->env_id_base; R.env_ids = ar->env_ids;
+    R.lazy = ar->lazy_events != 0 && !ar->keep_events;
     R.spec = ar->spec;
     for (int k = 0; k < ns; ++k) R.y0[k] = ar->y0[k];
     return 0;
@@ -4252,6 +4303,17 @@ int reset_impl(const double *par, const pvder_step_cfg *cfg, const pvder_autores
         hipLaunchKernelGGL((reset_kernel<T, 1>), grid, block, 0, st, P, R, fstate, istate, ev_vg, ev_si, mask, out,
                            n_env, lane_par);
     return hip_rc(hipGetLastError());
+}
+
+// every row of the generator's tables for the episode each env is in (pvder_autoreset.lazy_events leaves the rows beyond an env's
+// clock to the steps that come to them: a reader that wants whole tables -- a test, a checkpoint meant to be read -- asks for them)
+__global__ __launch_bounds__(kBlock) void complete_events_kernel(const ResetK R, float sinsol0, const int32_t *__restrict__ istate,
+                                                                 float *__restrict__ ev_vg, float *__restrict__ ev_si, int n_env) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_env) return;
+    const size_t N = (size_t)n_env;
+    fill_events(R.spec, sinsol0, R.seed, (uint64_t)(R.env_id_base + (R.env_ids ? (int64_t)R.env_ids[e] : (int64_t)e)),
+                (uint64_t)istate[PVDER_I_EPISODE * N + e], ev_vg, ev_si, N, e);
 }
 
 // A finished env returns the stale tuple (PVDER_env.py:145-152) and the step kernels leave its rows of the
@@ -4668,6 +4730,21 @@ int pvder_reset_masked_f64(const double *par, const pvder_step_cfg *cfg, const p
     return reset_impl<double>(par, cfg, ar, fstate, istate, ev_vg, ev_si, mask, out, n_env, stream);
 }
 
+int pvder_complete_event_tables(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, const int32_t *istate,
+                                float *ev_vg, float *ev_si, int n_env, void *stream) {
+    int rc = check_common(par, cfg, n_env);
+    if (rc) return rc;
+    if (!ar || !istate || !ev_vg || !ev_si) return PVDER_EINVAL;
+    ResetK R;
+    rc = fold_reset(par, cfg, ar, R);
+    if (rc) return rc;
+    if (R.keep_events) return 0;                           // (explicit tables: nothing is generated, nothing to complete)
+    const ModelK<float> P = fold_params<float>(par, true);
+    hipLaunchKernelGGL(complete_events_kernel, dim3((n_env + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, R, (float)P.sinsol0,
+                       istate, ev_vg, ev_si, n_env);
+    return hip_rc(hipGetLastError());
+}
+
 int pvder_fetch_env(const void *out, const int32_t *istate, int n_env, int env, int fp64, void *host_out, int32_t *host_ist,
                     void *stream) {
     if (!out || !istate || !host_out || !host_ist || n_env < 1 || env < 0 || env >= n_env) return PVDER_EINVAL;
@@ -4973,6 +5050,12 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
     Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
     Rk.ag = pvder_agent::AgentK{}; Rk.q = nullptr; Rk.ag_state = nullptr; Rk.ag_action = nullptr; Rk.ag_alive = nullptr; Rk.ag_ret = nullptr;
+    if (A.R.lazy) {
+        // pvder_autoreset.lazy_events: the fused loop reads its event rows one env step AHEAD of the step that would leave them
+        // behind -- it runs on whole tables (completed here, one launch per rollout), and so do the auto-resets of its finish kernel
+        hipLaunchKernelGGL(complete_events_kernel, grid, block, 0, st, A.R, (float)A.P.sinsol0, istate, ev_vg, ev_si, n_env);
+        A.R.lazy = 0;
+    }
     // (fused kernel, finish kernel for ONE step) once per episode end a workgroup can meet inside the rollout,
     // then the finish kernel for whatever is left (workgroups with deferred / finished envs)
     const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;

@@ -34,6 +34,13 @@
 #else
 #define PVDER_HD
 #endif
+// The step functions below are CALLED on the device, not inlined: advance() holds six etd_step and four settle sites, env_step three
+// advance sites -- inlined, env_step was 2 MB of code for a 64 KB instruction cache and ran at the speed of its instruction fetches.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PVDER_HYB_CALL __attribute__((noinline))
+#else
+#define PVDER_HYB_CALL
+#endif
 
 namespace pvder {
 namespace hyb {
@@ -84,7 +91,7 @@ PVDER_HD inline void make_sub(const HybK &P, double vgm, double sinsol, Sub &S) 
 struct Alg {
     double vR[3], vI[3], iarR, iarI;
 };
-PVDER_HD inline void field(const HybK &P, const Sub &S, const double *y, double th2t, double qref, double vdcref, double *dy, Alg &A) {
+PVDER_HD PVDER_HYB_CALL inline void field(const HybK &P, const Sub &S, const double *y, double th2t, double qref, double vdcref, double *dy, Alg &A) {
     const double Vdc = y[18], xDC = y[19], xQ = y[20], xPLL = y[21], delta = y[22];
     const double hV = 0.5 * Vdc;
     double mR[3], mI[3], Pt = 0.0, Qp = 0.0;
@@ -269,7 +276,7 @@ PVDER_HD inline void apply_phi(const Loop &L, const Phi &F, int k, int modes, co
 
 // one Hochbruck-Ostermann ETDRK4 step of length h from (y, th0 = 2 theta in turns at its start) with the modes held.
 // yn may be any slot but the eight this function works in (A_N1 .. A_TMP); y must not be one of them either.
-PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const Arena &W, const double *y, double th0, double h, double qref,
+PVDER_HD PVDER_HYB_CALL inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const Arena &W, const double *y, double th0, double h, double qref,
                               double vdcref, int modes, int xmask, double *yn) {
     Phi Fh, Fg;
     make_phi(L, h, Fh);
@@ -366,7 +373,7 @@ PVDER_HD inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const 
 
 // ---- settle: the micro-integration of phase p's fast pair (see the header).  trust_u: the axes whose loop was closed over a large
 // step carry their current to 1e-5 -- a demand of K 1e-5 = 0.06 in m: their current is put on the slow manifold (D_c = 0) first.
-PVDER_HD inline void settle(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, int p,
+PVDER_HD PVDER_HYB_CALL inline void settle(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, int p,
                             bool trust_u, Run &R, double tnow) {
     const double K = P.KpG, wp = P.wp, lim2 = P.mlim2;
     double *f = W[A_F0];                 // (free here: a settle comes behind a committed state, never inside a step)
@@ -529,7 +536,7 @@ PVDER_HD inline void settle(const HybK &P, const Sub &S, const Arena &W, double 
 }
 
 // modes and sat from the state alone (the oracle does the same at the start of every sim time step: fil_settle)
-PVDER_HD inline void derive_modes(const HybK &P, const Sub &S, const Arena &W, const double *y, double th2t, double qref, double vdcref,
+PVDER_HD PVDER_HYB_CALL inline void derive_modes(const HybK &P, const Sub &S, const Arena &W, const double *y, double th2t, double qref, double vdcref,
                                   Run &R) {
     double *f = W[A_F0];
     Alg A;
@@ -550,7 +557,7 @@ PVDER_HD inline void derive_modes(const HybK &P, const Sub &S, const Arena &W, c
 
 // at the start of a macro step: a held axis released by a jump of the inputs; a free phase whose closed loop is heading beyond the
 // limit for good (an action near the limit, a grid-voltage event: the quasi-static duty cycle ends at or beyond it)
-PVDER_HD inline void input_jump(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, Run &R,
+PVDER_HD PVDER_HYB_CALL inline void input_jump(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, Run &R,
                                 double tnow) {
     const double K = P.KpG, jump_margin = 4e-3;
     for (int p = 0; p < 3; ++p) {
@@ -603,7 +610,7 @@ PVDER_HD inline double cubic_root(double a, double b, double sa, double sb, doub
 enum { EV_NONE = 0, EV_ENTRY, EV_IMPACT, EV_CLAMP, EV_FREEZE };
 
 // value / slope of an event function at a state (positive side = the event has happened)
-PVDER_HD inline double event_value(const HybK &P, const Sub &S, const Arena &W, int kind, int p, int c, double sg0, const double *y, double th2t,
+PVDER_HD PVDER_HYB_CALL inline double event_value(const HybK &P, const Sub &S, const Arena &W, int kind, int p, int c, double sg0, const double *y, double th2t,
                                    double qref, double vdcref, double *slope) {
     double *f = W[A_F1];                 // (the field at the end of the full step is not needed any more while an event is located)
     Alg A;
@@ -625,14 +632,14 @@ PVDER_HD inline double event_value(const HybK &P, const Sub &S, const Arena &W, 
 }
 
 // the circle constraint of saturated phases behind the slow motion of a step
-PVDER_HD inline void after_step(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, Run &R,
+PVDER_HD PVDER_HYB_CALL inline void after_step(const HybK &P, const Sub &S, const Arena &W, double *y, double th2t, double qref, double vdcref, Run &R,
                                 double tnow) {
     for (int p = 0; p < 3; ++p)
         if (((R.sat >> p) & 1) && s_of(P, y, p) < -1e-12) settle(P, S, W, y, th2t, qref, vdcref, p, true, R, tnow);
 }
 
 // from (tnow, y, th0) over h with the events inside located and resolved; tnow is only a label (seconds within the env step)
-PVDER_HD inline void advance(const HybK &P, const Sub &S, const Loop &L, const Arena &W, double *y, double th0, double h, double qref,
+PVDER_HD PVDER_HYB_CALL inline void advance(const HybK &P, const Sub &S, const Loop &L, const Arena &W, double *y, double th0, double h, double qref,
                              double vdcref, Run &R, double tnow) {
     input_jump(P, S, W, y, th0, qref, vdcref, R, tnow);
     double *f0 = W[A_F0], *f1 = W[A_F1], *y1 = W[A_Y1], *yt = W[A_YT2];

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libpvder_hip.so")
 
 EINVAL = -10001
 ETIMEOUT = -10003             # include/pvder_hip.h PVDER_ETIMEOUT: the device never wrote the host mirror's sequence word
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # every symbol include/pvder_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_masked_f32",
@@ -31,7 +31,8 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_plan_rollout", "pvder_gather_create", "pvder_gather_destroy", "pvder_gather_drain",
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
            "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch",
-           "pvder_plan_step_mirror", "pvder_plan_graph_hints", "pvder_plan_kernel_name", "pvder_plan_hybrid_active"]
+           "pvder_plan_step_mirror", "pvder_plan_graph_hints", "pvder_plan_kernel_name", "pvder_plan_hybrid_active",
+           "pvder_complete_event_tables"]
 MIRROR_WORDS = 18       # PVDER_MIRROR_WORDS (pvder_plan_step_mirror): 13 output rows + 4 counters + the sequence word, doubles
 LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
@@ -61,7 +62,8 @@ class EventSpec(C.Structure):
 class AutoReset(C.Structure):
     """``struct pvder_autoreset`` (include/pvder_hip.h)."""
     _fields_ = [("enabled", C.c_int32), ("keep_events", C.c_int32), ("seed", C.c_uint64),
-                ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double)), ("env_ids", C.c_void_p)]
+                ("env_id_base", C.c_int64), ("spec", EventSpec), ("y0", C.POINTER(C.c_double)), ("env_ids", C.c_void_p),
+                ("lazy_events", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class QAgentCfg(C.Structure):
@@ -174,6 +176,8 @@ def lib() -> C.CDLL:
     L.pvder_plan_kernel_name.argtypes = [vp]
     L.pvder_plan_hybrid_active.restype = i32
     L.pvder_plan_hybrid_active.argtypes = [vp]
+    L.pvder_complete_event_tables.restype = i32
+    L.pvder_complete_event_tables.argtypes = [C.POINTER(C.c_double), C.POINTER(StepCfg), C.POINTER(AutoReset), vp, vp, vp, i32, vp]
     L.pvder_fold_lane_params.restype = i32
     L.pvder_fold_lane_params.argtypes = [dp, vp, i32, vp]
     L.pvder_plan_lane_params.restype = i32

@@ -209,7 +209,7 @@ class BatchedDQNAgent:
             cfg.env_id_base = eval_env.env_id_base
             with eval_env._device_ctx():
                 rc = lib.pvder_plan_rollout_fused_agent(eval_env._plan, eval_env.fstate.data_ptr(), eval_env.istate.data_ptr(),
-                                                        eval_env.ev_vg.data_ptr(), eval_env.ev_si.data_ptr(), int(steps),
+                                                        eval_env._ev_vg.data_ptr(), eval_env._ev_si.data_ptr(), int(steps),
                                                         eval_env.out.data_ptr(), eval_env.stats.data_ptr(), eval_env._progress.data_ptr(),
                                                         C.byref(cfg), self.q_net.flat.data_ptr(), state.data_ptr(), action.data_ptr(),
                                                         alive.data_ptr(), ret.data_ptr(), eval_env._stream())

@@ -147,7 +147,7 @@ class BatchedQAgent:
         cfg = self._agent_cfg(False, True, counter)
         with env._device_ctx():
             rc = env._lib.pvder_plan_rollout_fused_agent(env._plan, env.fstate.data_ptr(), env.istate.data_ptr(),
-                                                         env.ev_vg.data_ptr(), env.ev_si.data_ptr(), int(steps),
+                                                         env._ev_vg.data_ptr(), env._ev_si.data_ptr(), int(steps),
                                                          env.out.data_ptr(), env.stats.data_ptr(), env._progress.data_ptr(),
                                                          C.byref(cfg), self.q_table.data_ptr(), state.data_ptr(),
                                                          action.data_ptr(), alive.data_ptr(), ep_reward.data_ptr(), env._stream())

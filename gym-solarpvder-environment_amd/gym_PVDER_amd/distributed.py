@@ -278,7 +278,7 @@ class NativeStepGather:
         with env._device_ctx():
             r0, nr = payload_rows(self.payload, 0, 1) if self.payload != "full_every_k" else (REWARD_ROW, 2)
             rc = self._lib.pvder_plan_rollout_gather_rows(plan, self._h, env.fstate.data_ptr(), env.istate.data_ptr(),
-                                                          env.ev_vg.data_ptr(), env.ev_si.data_ptr(), actions.data_ptr(), K,
+                                                          env._ev_vg.data_ptr(), env._ev_si.data_ptr(), actions.data_ptr(), K,
                                                           self.out[0].data_ptr(), self.out[1].data_ptr(),
                                                           self.recv[0].data_ptr(), self.recv[1].data_ptr(),
                                                           env.stats.data_ptr(), env._stream(), self._k & 1, 1 if sync_each else 0,

@@ -202,7 +202,7 @@ class PVDER(*_BASES):
         if self._use_mirror:
             # no copy packet, no stream wait: one small kernel behind the step writes rows, counters, the trajectory record and a
             # sequence word into pinned host memory; the call returns when the word is there
-            rc = v._lib.pvder_plan_step_mirror(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v.ev_vg.data_ptr(), v.ev_si.data_ptr(),
+            rc = v._lib.pvder_plan_step_mirror(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v._ev_vg.data_ptr(), v._ev_si.data_ptr(),
                                                self._actions[action].data_ptr(), v.out.data_ptr(),
                                                v.hstep.data_ptr() if v.hstep is not None else None, v.stats.data_ptr(), snap,
                                                v._state_and_out.data_ptr(), nbytes, self._pin_mirror.data_ptr(), self._mirror_seq + 1,
@@ -214,7 +214,7 @@ class PVDER(*_BASES):
             m = self._pin_mirror.tolist()
             self._host_out, self._host_ist = m[:13], [int(x) for x in m[13:17]]
             return
-        rc = v._lib.pvder_plan_step_fetch(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v.ev_vg.data_ptr(), v.ev_si.data_ptr(),
+        rc = v._lib.pvder_plan_step_fetch(plan, v.fstate.data_ptr(), v.istate.data_ptr(), v._ev_vg.data_ptr(), v._ev_si.data_ptr(),
                                           self._actions[action].data_ptr(), v.out.data_ptr(),
                                           v.hstep.data_ptr() if v.hstep is not None else None, v.stats.data_ptr(), snap,
                                           v._state_and_out.data_ptr(), nbytes, self._pin_out.data_ptr(), self._pin_ist.data_ptr(),

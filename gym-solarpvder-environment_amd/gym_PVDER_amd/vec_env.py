@@ -165,7 +165,7 @@ class PVDERVec(EnvSpecMixin):
                  model_type: str = 'model_2',
                  seed: int = 0, env_id_base: int = 0, rtol: float = 1e-6, atol: float = 1e-8,
                  events_spec: Optional[dict] = None, der_config: Optional[dict] = None, off_range: str = "integrate",
-                 model_options: Optional[dict] = None, lane_params: Optional[dict] = None):
+                 model_options: Optional[dict] = None, lane_params: Optional[dict] = None, lazy_events: Optional[bool] = None):
         """``der_config``: overrides of the model's config block (keys of config_der.json's derId entry, e.g.
         ``{"C_actual": 330e-6, "Kp_DC": -2.2}``) -- ONE parameter set per PVDERVec (the steady state, the
         Jacobian of the etdlin path and the coefficient tables are derived from it); for a batch spread over
@@ -191,6 +191,14 @@ class PVDERVec(EnvSpecMixin):
         if off_range not in OFF_RANGE:
             raise ValueError("off_range must be one of %s" % (sorted(OFF_RANGE),))
         self.off_range = off_range
+        # lazy_events: the generator's event tables are written as the episode advances (pvder_autoreset.lazy_events: the step that
+        # ends an episode does not stop to hash 38 rows per env -- 4.6 us that a desynchronised batch pays in EVERY launch, a batch
+        # in lockstep once per episode); ``ev_vg`` / ``ev_si`` read them whole.  None (default): on while the envs' clocks differ
+        # (a masked reset or sort_lanes() since the last full reset), off in lockstep (there the rows' share of a launch is 0.03 us
+        # whole and 0.1 us one at a time); True / False: always / never.  Same results bit for bit either way.
+        self.lazy_events = None if lazy_events is None else bool(lazy_events)
+        self._desync = False                 # the envs' clocks differ (a masked reset / sort_lanes since the last full reset)
+        self._lazy_active = bool(lazy_events) if lazy_events is not None else False
         if not isinstance(num_envs, int) or num_envs < 1:
             raise ValueError("num_envs must be a positive integer")
         if model_type not in self.env_model_spec:
@@ -283,7 +291,7 @@ class PVDERVec(EnvSpecMixin):
     _PLAN_KEYS = frozenset(("seed", "env_id_base", "rtol", "atol", "micro_steps", "micro_coarse", "graded", "env_reward_spec", "lane_steps",
                             "est_guard", "auto_reset", "_debug_knob", "_keep_events", "_n", "_max_sim_time",
                             "_goals_list", "_discrete", "max_episode_steps", "env_events_spec", "env_goal_spec", "integrator",
-                            "off_range"))
+                            "off_range", "_lazy_active"))
 
     def _lane_envelope(self, rows: np.ndarray):
         """(Krogstad steps per env step, None) for per-env sets inside the validated envelope of the etdlin lane path, else
@@ -359,6 +367,8 @@ class PVDERVec(EnvSpecMixin):
         self._cfg()                       # validate now
 
     def __setattr__(self, name, value):
+        if name == "_n" and self.__dict__.get("_ev_vg") is not None and self.__dict__.get("_n") not in (None, value):
+            self._complete_tables()       # (lazy_events: the rows a step leaves behind are its successor's AT THIS n -- whole tables first)
         object.__setattr__(self, name, value)
         if name in self._PLAN_KEYS and self.__dict__.get("_plan") is not None:
             self._drop_plan()
@@ -440,8 +450,8 @@ class PVDERVec(EnvSpecMixin):
         K, s0, ds = self._event_grid()
         self.ev_count, self.ev_s0, self.ev_ds = K, s0, ds
         N = self.num_envs
-        self.ev_vg = torch.ones((K + 1, N), dtype=torch.float32, device=self.device)
-        self.ev_si = torch.full((K + 1, N), float(self.par[der_model.IDX["SINSOL0"]]), dtype=torch.float32,
+        self._ev_vg = torch.ones((K + 1, N), dtype=torch.float32, device=self.device)
+        self._ev_si = torch.full((K + 1, N), float(self.par[der_model.IDX["SINSOL0"]]), dtype=torch.float32,
                                 device=self.device)
 
     def update_env_events(self, event_spec_list: List[dict]):
@@ -474,9 +484,9 @@ class PVDERVec(EnvSpecMixin):
     def set_event_tables(self, vgrid: torch.Tensor, sinsol: torch.Tensor):
         """Explicit per-env event tables [K+1, N] (row 0 = nominal) -- parity runs share them
         with the oracle.  Kept across resets until :meth:`clear_event_tables`."""
-        assert vgrid.shape == self.ev_vg.shape and sinsol.shape == self.ev_si.shape
-        self.ev_vg.copy_(vgrid)
-        self.ev_si.copy_(sinsol)
+        assert vgrid.shape == self._ev_vg.shape and sinsol.shape == self._ev_si.shape
+        self._ev_vg.copy_(vgrid)
+        self._ev_si.copy_(sinsol)
         self._keep_events = True
         self._drop_plan()
 
@@ -718,7 +728,7 @@ class PVDERVec(EnvSpecMixin):
             if k.shape != (N,):
                 raise ValueError("key must have shape (%d,)" % N)
             order = torch.argsort(k, stable=True)                              # lane l of the new order takes what lane order[l] holds
-            tensors = [self._state_and_out, self.istate, self.ev_vg, self.ev_si]
+            tensors = [self._state_and_out, self.istate, self._ev_vg, self._ev_si]
             if self.hstep is not None:
                 tensors.append(self.hstep)
             if self.__dict__.get("_lane_folded") is not None:
@@ -737,6 +747,7 @@ class PVDERVec(EnvSpecMixin):
             object.__setattr__(self, "_ksub_hint", -1)                         # no common clock any more
             if self._plan is not None:
                 self._lib.pvder_plan_hint(self._plan, -1)
+            self._set_desync(True)
         if lane_io is not None:
             self.lane_io = bool(lane_io)
 
@@ -778,7 +789,42 @@ class PVDERVec(EnvSpecMixin):
         a.y0 = C.cast(self._y0_c, C.POINTER(C.c_double))
         eol = self.__dict__.get("_env_of_lane")
         a.env_ids = eol.data_ptr() if eol is not None else None
+        a.lazy_events = 1 if (self._lazy_active and not self._keep_events) else 0
         return a
+
+    # -- the event tables [K+1, N] (row 0 = nominal; create_random_events, PVDER_env.py:400-411) ----------
+    def _complete_tables(self):
+        """With ``lazy_events`` the step kernels write an episode's table rows as the envs come to them (pvder_autoreset.lazy_events):
+        a READER gets them whole -- every row of the episode each env is in (pvder_complete_event_tables; idempotent)."""
+        if not (self._lazy_active and self.auto_reset) or self._keep_events or self.__dict__.get("_ev_vg") is None:
+            return
+        cfg, ar = self._cfg(), self._autoreset(True)
+        with self._device_ctx():
+            rc = self._lib.pvder_complete_event_tables(self._par_c, C.byref(cfg), C.byref(ar), self.istate.data_ptr(),
+                                                       self._ev_vg.data_ptr(), self._ev_si.data_ptr(), self.num_envs, self._stream())
+        _native.check(rc, "pvder_complete_event_tables")
+
+    def _set_desync(self, flag: bool):
+        """The envs' clocks differ / are one: with ``lazy_events=None`` the table rows go lazy / whole (a new plan; whole tables
+        first when the laziness ends)."""
+        object.__setattr__(self, "_desync", bool(flag))
+        want = bool(self.lazy_events) if self.lazy_events is not None else (bool(flag) and bool(self.auto_reset))
+        if want != self._lazy_active:
+            if not want:
+                self._complete_tables()
+            self._lazy_active = want          # (a plan key: the plan is folded anew)
+
+    @property
+    def ev_vg(self) -> torch.Tensor:
+        """Grid-voltage event table (fp32 [K+1, N], lane order): row j holds the magnitude in force from event j on."""
+        self._complete_tables()
+        return self._ev_vg
+
+    @property
+    def ev_si(self) -> torch.Tensor:
+        """Insolation event table (fp32 [K+1, N], lane order)."""
+        self._complete_tables()
+        return self._ev_si
 
     def _reset_launch(self, mask: Optional[torch.Tensor]):
         fn = self._lib.pvder_reset_masked_f32 if self.fdtype == torch.float32 else self._lib.pvder_reset_masked_f64
@@ -788,13 +834,13 @@ class PVDERVec(EnvSpecMixin):
             # per-lane parameters: every env restarts from ITS OWN steady state (PVDER_env.py:374-378) and its reset observation
             # carries its own Ppv -- the same observation the same-step auto-reset of the lane kernels returns
             rc = self._lib.pvder_reset_masked_lanes_f32(self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(),
-                                                        self.istate.data_ptr(), self.ev_vg.data_ptr(), self.ev_si.data_ptr(),
+                                                        self.istate.data_ptr(), self._ev_vg.data_ptr(), self._ev_si.data_ptr(),
                                                         mask.data_ptr() if mask is not None else None, self.out.data_ptr(),
                                                         self.num_envs, lanes.data_ptr(), self._stream())
             _native.check(rc, "pvder_reset_masked_lanes_f32")
             return
         rc = fn(self._par_c, C.byref(cfg), C.byref(ar), self.fstate.data_ptr(), self.istate.data_ptr(),
-                self.ev_vg.data_ptr(), self.ev_si.data_ptr(), mask.data_ptr() if mask is not None else None,
+                self._ev_vg.data_ptr(), self._ev_si.data_ptr(), mask.data_ptr() if mask is not None else None,
                 self.out.data_ptr(), self.num_envs, self._stream())
         _native.check(rc, "pvder_reset_masked")
 
@@ -807,6 +853,7 @@ class PVDERVec(EnvSpecMixin):
                 assert mask.shape == (self.num_envs,)
                 if self._mapped():
                     mask = self.to_lane_order(mask).contiguous()
+            self._set_desync(mask is not None or self._env_of_lane is not None)
             self._reset_launch(mask)
             # the plan is checked at every reset (never inside a graph capture): specs edited in place
             # (env_events_spec[...]['ENABLE'], env_reward_spec['reference_values'], my_spec lists) take effect here at
@@ -858,8 +905,8 @@ class PVDERVec(EnvSpecMixin):
             # ONE launch: action -> integrate -> reward/done/obs -> same-step auto-reset of finished
             # envs (their obs rows hold the reset observation, reward/done rows the ended transition);
             # statistics: every workgroup overwrites its slot (no atomics, nothing to clear)
-            rc = self._lib.pvder_plan_step(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self.ev_vg.data_ptr(),
-                                           self.ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr(),
+            rc = self._lib.pvder_plan_step(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self._ev_vg.data_ptr(),
+                                           self._ev_si.data_ptr(), actions.data_ptr(), self.out.data_ptr(),
                                            self.hstep.data_ptr() if self.hstep is not None else None,
                                            self.stats.data_ptr(), self._stream())
             if timed:
@@ -919,13 +966,13 @@ class PVDERVec(EnvSpecMixin):
                 out[0].copy_(self.out)               # stale tuples of finished envs: block k takes them from block k-1
             if fused:
                 rc = self._lib.pvder_plan_rollout_fused(plan, self.fstate.data_ptr(), self.istate.data_ptr(),
-                                                        self.ev_vg.data_ptr(), self.ev_si.data_ptr(), actions.data_ptr(), K,
+                                                        self._ev_vg.data_ptr(), self._ev_si.data_ptr(), actions.data_ptr(), K,
                                                         dst.data_ptr(), stride, self.stats.data_ptr(),
                                                         self._progress.data_ptr(), self._stream())
                 _native.check(rc, "pvder_plan_rollout_fused")
             else:
-                rc = self._lib.pvder_plan_rollout(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self.ev_vg.data_ptr(),
-                                                  self.ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
+                rc = self._lib.pvder_plan_rollout(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self._ev_vg.data_ptr(),
+                                                  self._ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
                                                   self.hstep.data_ptr() if self.hstep is not None else None,
                                                   self.stats.data_ptr(), self._stream())
                 _native.check(rc, "pvder_plan_rollout")
@@ -954,7 +1001,7 @@ class PVDERVec(EnvSpecMixin):
 
     def load_state_dict(self, d: Dict[str, torch.Tensor]):
         for k in ("fstate", "istate", "ev_vg", "ev_si", "out", "stats"):
-            t = getattr(self, k)
+            t = getattr(self, {"ev_vg": "_ev_vg", "ev_si": "_ev_si"}.get(k, k))       # (the buffers themselves: nothing to complete)
             if d[k].shape != t.shape or d[k].dtype != t.dtype:
                 raise ValueError("state_dict entry %r does not match this env (%s %s vs %s %s)"
                                  % (k, tuple(d[k].shape), d[k].dtype, tuple(t.shape), t.dtype))
@@ -974,6 +1021,7 @@ class PVDERVec(EnvSpecMixin):
         self._needs_reset = False
         with self._device_ctx():
             hint = int(self.istate[0, 0].item())                 # (PVDER_I_KSUB of env 0: where a batch in lockstep is)
+            self._set_desync(self._env_of_lane is not None or bool((self.istate[0] != hint).any().item()))
             if self._plan is None or self.__dict__.get("_plan_fp") != self._plan_fingerprint():
                 self._drop_plan()
                 self._ksub_hint = hint

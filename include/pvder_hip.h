@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVDER_ABI_VERSION 17
+#define PVDER_ABI_VERSION 18
 #define PVDER_EINVAL (-10001)
 
 /* ---- model parameter vector (host, double): per-unit constants of one DER ------------------
@@ -174,12 +174,29 @@ typedef struct pvder_autoreset {
                                 clock, so that the lanes of a wave run one schedule and read one event row
                                 (gym_PVDER_amd.PVDERVec.sort_lanes: a desynchronised batch at the lockstep rate) --; what follows an
                                 env's identity is the event generator's key (seed, env_id_base + env_ids[e], episode, k). */
+    int32_t lazy_events;     /* (ABI 18) != 0: the generator's tables are written AS THE EPISODE ADVANCES.  A same-step auto-reset writes
+                                row 0 and the rows the first env step reads; every env step leaves behind the rows its successor reads
+                                (rows <= event_row(tStop + n_sub), carried from the tStop row the step holds anyway: one hash pair, one
+                                step in four at PVDER-v0's grid).  Same rows, same values, same results bit for bit -- but the rows
+                                BEYOND an env's clock are the previous episode's until their turn comes, and every step of an episode
+                                must use the same n_sub.  Why: generating an episode's 38 rows at once is 4.6 us of serial hashing in
+                                the step that ends an episode -- once per 160 steps in lockstep, in EVERY step of a desynchronised
+                                batch (profiles/r06_desync_breakdown.txt).  pvder_reset_masked_* always write whole tables;
+                                pvder_complete_event_tables does it on request.  0 (and callers of ABI <= 17): whole tables at the
+                                auto-reset.  Ignored with keep_events. */
+    int32_t reserved0;
 } pvder_autoreset;
 
 int pvder_version(void);
 int pvder_par_count(void);
 /* Threads per workgroup of the step kernels (bench.py reports it with the roofline). */
 int pvder_block_size(void);
+
+/* (ABI 18) Every row of the generator's event tables for the episode each env is in (istate row PVDER_I_EPISODE): what
+ * pvder_autoreset.lazy_events leaves unwritten beyond an env's clock.  Idempotent; no-op with keep_events.
+ * Replaces nothing in the reference (its create_random_events, PVDER_env.py:400-411, builds the whole list at reset()). */
+int pvder_complete_event_tables(const double *par, const pvder_step_cfg *cfg, const pvder_autoreset *ar, const int32_t *istate,
+                                float *ev_vg, float *ev_si, int n_env, void *stream);
 
 /* Masked reset.  For every env with mask[e] != 0 (mask == NULL: all):
  *   fstate <- ar->y0, Q_ref <- 0, Vdc_ref <- par; istate: ksub = steps = status = 0, episode += 1;

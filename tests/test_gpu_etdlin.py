@@ -928,3 +928,67 @@ def test_sorted_lanes_are_bit_identical_per_env_id(gpu_device):
     b2 = make_vec(N, gpu_device, **kw); b2.reset(); b2.load_state_dict(d)
     o1 = b.step(acts[1])[0].clone(); o2 = b2.step(acts[1])[0]
     assert torch.equal(o1, o2)
+
+
+def test_lazy_event_tables_give_the_bits_of_whole_tables(gpu_device):
+    """pvder_autoreset.lazy_events (ABI 18; create_random_events, PVDER_env.py:400-411, builds an episode's whole event list at reset()):
+    with the rows written as the envs come to them -- an auto-reset writes row 0, every step the rows its successor reads -- every
+    output, state and counter is, bit for bit, what whole tables at the auto-reset give: per-step launches, fused rollouts, a
+    desynchronised and sorted batch, the fp64 path's follow-up reset; `ev_vg` / `ev_si` read the tables WHOLE
+    (pvder_complete_event_tables), the raw buffer shows rows of the previous episode beyond an env's clock."""
+    from helpers import both_events_spec, counter_tables
+    N, ep = 1024, 16
+    spec = both_events_spec()
+    kw = dict(seed=11, events_spec=spec, auto_reset=True, max_sim_time=4.0, env_id_base=300)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(21)
+    acts = torch.randint(0, 5, (5 * ep, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    a, b = make_vec(N, gpu_device, lazy_events=True, **kw), make_vec(N, gpu_device, lazy_events=False, **kw)
+    a.reset(); b.reset()
+    stale = False
+    for k in range(2 * ep + 5):                                   # through two episode ends, into the third episode
+        oa, ra, da, _ = a.step(acts[k]); ob, rb, db, _ = b.step(acts[k])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), k
+        stale = stale or not torch.equal(a._ev_vg, b._ev_vg)
+    assert stale                                                  # (the lazy batch's raw buffer did hold rows of an earlier episode)
+    for name in ("fstate", "istate", "out", "ev_vg", "ev_si"):    # ... and reads whole
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    vg, si = counter_tables(N, 11, episode=3, env_id_base=300, spec=spec)
+    assert np.array_equal(a.ev_vg.cpu().numpy(), vg.astype(np.float32)) and np.array_equal(a.ev_si.cpu().numpy(), si.astype(np.float32))
+    # fused rollouts (the env steps of a window inside one kernel) and per-step launches behind them
+    K = 2 * ep
+    outa = torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device); outb = torch.empty_like(outa)
+    a.rollout(acts[:K], out=outa, fused=True); b.rollout(acts[:K], out=outb, fused=True)
+    assert torch.equal(outa, outb)
+    a.rollout(acts[K:2 * K], out=outa, fused=False); b.rollout(acts[K:2 * K], out=outb, fused=False)
+    assert torch.equal(outa, outb) and torch.equal(a.istate, b.istate) and torch.equal(a.ev_si, b.ev_si)
+    # phases spread by masked resets (whole tables for the envs reset), then sorted by clock
+    phase = (torch.arange(N, device=gpu_device, dtype=torch.int64) * 7919) % ep
+    for k in range(ep):
+        a.step(acts[k], return_tensors=False); b.step(acts[k], return_tensors=False)
+        a.reset(phase == k); b.reset(phase == k)
+    a.sort_lanes()
+    for k in range(ep, 3 * ep):
+        oa, ra, da, _ = a.step(acts[k]); ob, rb, db, _ = b.step(acts[k])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), k
+    assert torch.equal(a.to_env_order(a.ev_vg), b.ev_vg) and torch.equal(a.to_env_order(a.istate), b.istate)
+    # another n_sub in mid-episode: the tables are completed first (every step of an episode leaves its successor's rows AT ITS n)
+    a._set_n(30); b._set_n(30)
+    for k in range(12):
+        oa, ra, da, _ = a.step(acts[k]); ob, rb, db, _ = b.step(acts[k])
+        assert torch.equal(oa, ob) and torch.equal(da, db), k
+    # the fp64 path: its step kernels leave the reset to a follow-up launch (whole tables), the rows in between to the steps
+    c, d = (make_vec(64, gpu_device, integrator="rk45", lazy_events=lz, **kw) for lz in (True, False))
+    c.reset(); d.reset()
+    for k in range(ep + 6):
+        oc, rc, dc, _ = c.step(acts[k, :64]); od, rd, dd, _ = d.step(acts[k, :64])
+        assert torch.equal(oc, od) and torch.equal(dc, dd), k
+    assert torch.equal(c.ev_vg, d.ev_vg)
+    # the default (lazy_events=None): whole tables in lockstep, lazy rows while the envs' clocks differ
+    e = make_vec(64, gpu_device, **kw); e.reset()
+    assert not e._lazy_active
+    e.step(acts[0, :64]); e.reset(torch.arange(64, device=gpu_device) < 3)
+    assert e._lazy_active
+    e.step(acts[1, :64]); e.reset()
+    assert not e._lazy_active
+    e.step(acts[2, :64]); e.sort_lanes()
+    assert e._lazy_active

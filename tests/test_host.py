@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol():
     assert agent == sorted(_native.AGENT_SYMBOLS)
     for sym in agent:
         assert hasattr(L, sym), sym
-    assert L.pvder_version() == _native.ABI_VERSION == 17
+    assert L.pvder_version() == _native.ABI_VERSION == 18
     from gym_PVDER_amd import der_model
     assert L.pvder_par_count() == len(der_model.PAR)
     assert L.pvder_block_size() % 64 == 0

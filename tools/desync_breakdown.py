@@ -23,11 +23,11 @@ def spec(stop):
     return s
 
 
-def run(label, max_sim_time, stop, spread, steps=300, sort=False, envvars=(), off_range="held_modes"):
+def run(label, max_sim_time, stop, spread, steps=300, sort=False, envvars=(), off_range="held_modes", lazy=None):
     for k in envvars:
         os.environ[k] = "1"
     env = PVDERVec(N, device=dev, seed=2024, events_spec=spec(stop), auto_reset=True, max_sim_time=max_sim_time,
-                   off_range=off_range)     # (held modes: 500-step random walks reach the duty-cycle limit -- not what is timed here)
+                   off_range=off_range, lazy_events=lazy)     # (held modes: 500-step random walks reach the duty-cycle limit -- not what is timed here)
     env.reset()
     gen = torch.Generator(device=dev); gen.manual_seed(77)
     acts = torch.randint(0, 5, (max(steps, 160), N), generator=gen, device=dev, dtype=torch.uint8)
@@ -61,3 +61,7 @@ run("(c) phases spread over 160 clocks, 160-step episodes (1 env in 160 ends per
 run("(d) = (b) behind sort_lanes()", 125.0, 124.0, True, sort=True)
 run("(e) = (c) behind sort_lanes()", 40.0, 39.0, True, sort=True)
 run("(f) = (a) without the clock hint (PVDER_NO_HINT)", 40.0, 39.0, False, envvars=("PVDER_NO_HINT",))
+run("(j) = (e) with whole tables at the auto-reset (lazy_events=False: rounds 1-5)", 40.0, 39.0, True, sort=True, lazy=False)
+run("(k) = (a) with the rows written as the episode advances (lazy_events=True)", 40.0, 39.0, False, lazy=True)
+run("(a) again", 40.0, 39.0, False)
+run("(k) again", 40.0, 39.0, False, lazy=True)
