@@ -966,6 +966,27 @@ def run_rank(args):
                      "kernel": "step_etdlin_rollout_kernel<3> (+ step_etdlin_finish_kernel<3> for the step that ends an episode)",
                      "note": "same envs, events and random actions as the headline; results bit-identical to one launch per "
                              "step (tests/test_gpu_etdlin.py::test_fused_rollout_equals_single_steps); NOT the headline"}
+    # ... and SERVED (pvder_plan_rollout_served, round 6): the same register-resident loop for a producer that does not have its
+    # actions ahead -- every env step waits for its row to be posted; "ahead": posted before the launch, "depth_8": row k posted by
+    # the host when every workgroup has reported step k - 8 done (the host in the loop, eight steps behind the env)
+    served_leg = None
+    if fused_leg is not None and hasattr(env, "rollout_served"):
+        try:
+            Ks = max(1, min(4 * args.fused_steps, pool))
+            served_leg = {"steps_per_call": Ks, "unit": "env-steps/s"}
+            for name, depth in (("ahead", None), ("depth_8", 8)):
+                env.rollout_served(actions[:Ks], depth=depth)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                env.rollout_served(actions[:Ks], depth=depth)
+                el_v = time.perf_counter() - t0
+                served_leg[name] = {"value": N * Ks / el_v, "us_per_step": 1e6 * el_v / Ks}
+            served_leg["kernel"] = "step_etdlin_served_kernel (+ step_etdlin_finish_kernel<3> for the step that ends an episode)"
+            served_leg["note"] = ("bit-identical to one launch per step (tests/test_gpu_fullsize.py::test_served_rollout_is_bit_identical_"
+                                  "and_waits_for_its_rows); NOT the headline: step() stays one launch per env step -- a producer one "
+                                  "step behind the env pays the PCIe round trip per step (profiles/r06_ab_served_rollout.txt)")
+        except (ValueError, RuntimeError, TimeoutError) as ex:      # (e.g. the duty-cycle-limit kernel is following the launches)
+            served_leg = {"skipped": "%s: %s" % (type(ex).__name__, ex)}
     compute_only = None
     payload_legs = {}
     if dist is not None:        # the same steps without the collective: what the gather costs
@@ -1096,6 +1117,7 @@ def run_rank(args):
                                                         if args.integrator in INSTR_PER_STEP else None)} if flops else None,
             "sustained": sustained,
             "fused_rollout": fused_leg,
+            "served_rollout": served_leg,
             "ranks_seen": ranks_seen,
             "last_step_stats": st,
         }

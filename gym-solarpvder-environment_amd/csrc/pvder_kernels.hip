@@ -1037,6 +1037,7 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
     Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
     Rk.ag = pvder_agent::AgentK{}; Rk.q = nullptr; Rk.ag_state = nullptr; Rk.ag_action = nullptr; Rk.ag_alive = nullptr; Rk.ag_ret = nullptr;
+    Rk.mailbox = nullptr; Rk.done = nullptr; Rk.sv_dev = nullptr;
     if (A.R.lazy) {
         // pvder_autoreset.lazy_events: the fused loop reads its event rows one env step AHEAD of the step that would leave them
         // behind -- it runs on whole tables (completed here, one launch per rollout), and so do the auto-resets of its finish kernel
@@ -1056,6 +1057,73 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     advance_hint(*plan, n_steps);
     return hip_rc(hipGetLastError());
 }
+
+// SERVED rollout (round 6; profiles/r06_ab_served_rollout.txt): pvder_plan_rollout_fused whose env steps wait for their action rows.
+// The caller posts "rows 0 .. p-1 are there" into a host-coherent word; ONE thread of the launch (the relay workgroup) polls it over
+// PCIe and fans it out to a device word per workgroup; a workgroup reports the steps whose outputs have left its CU to a device word
+// the relay reduces to (min, max) for the host.  4.9 us per env step at 65 536 envs with the rows posted ahead (one launch per step:
+// 8.5), bit-identical; a producer that posts row k + 1 only when step k - D is reported done pays the PCIe round trip: 5.2 us at
+// D = 8, 27 us at D = 1.  Every wait is bounded (0.2 s): a caller that stops posting gets its launch back, with `progress` short.
+// host-coherent words: [0] = the mailbox, [16] = min, [17] = max over the workgroups of the steps done; *host and *dev name the same memory; *scratch: 16 * (4 + 2 n_wg) device words
+int pvder_served_alloc(int n_env, int **host, int **dev, int **scratch) {
+    if (n_env < 1 || !host || !dev || !scratch) return PVDER_EINVAL;
+    const int n_wg = (n_env + kBlock - 1) / kBlock;
+    int *h = nullptr;
+    void *d = nullptr;
+    if (hipMalloc((void **)scratch, 64 * (size_t)(4 + 2 * n_wg)) != hipSuccess || hipMemset(*scratch, 0, 64 * (size_t)(4 + 2 * n_wg)) != hipSuccess) return hip_rc(hipErrorUnknown);
+    hipError_t e = hipHostMalloc((void **)&h, sizeof(int) * 32, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) return hip_rc(e);
+    for (int i = 0; i < 32; ++i) h[i] = 0;
+    *host = h; *dev = (int *)d;
+    return 0;
+}
+int pvder_served_free(int *host, int *scratch) {
+    const hipError_t a = host ? hipHostFree(host) : hipSuccess, b = scratch ? hipFree(scratch) : hipSuccess;
+    return hip_rc(a != hipSuccess ? a : b);
+}
+
+// pvder_plan_rollout_fused with its steps gated by the mailbox (same launches: served kernel + finish kernel once per episode end
+// the rollout can contain; the finish kernel is not gated -- the step it takes is one whose action row the served kernel had)
+int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                              const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
+                              int32_t *progress, int *words_dev, int *scratch_dev, void *stream) {
+    const int *mailbox_dev = words_dev;
+    int *done_dev = words_dev ? words_dev + 16 : nullptr;
+    if (!plan || n_steps < 0 || !actions || !out || !progress || !fstate || !istate || !ev_vg || !ev_si || !mailbox_dev || !done_dev || !scratch_dev) return PVDER_EINVAL;
+    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->lane_par) return PVDER_EINVAL;
+    if (n_steps == 0) return 0;
+    const int n_env = plan->n_env;
+    const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    RollArgs Q;
+    Q.G = plan->lin;
+    EtdArgs &A = Q.G.A;
+    RollK &Rk = Q.Rk;
+    A.fstate = fstate; A.istate = istate; A.ev_vg = ev_vg; A.ev_si = ev_si;
+    A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
+    Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
+    Rk.ag = pvder_agent::AgentK{}; Rk.q = nullptr; Rk.ag_state = nullptr; Rk.ag_action = nullptr; Rk.ag_alive = nullptr; Rk.ag_ret = nullptr;
+    Rk.mailbox = mailbox_dev; Rk.done = done_dev; Rk.sv_dev = scratch_dev;
+    if (hipMemsetAsync(scratch_dev, 0, 64 * (size_t)(4 + 2 * grid.x), st) != hipSuccess) return hip_rc(hipErrorUnknown);
+    const dim3 grid_sv(grid.x + 1);                    // + the relay workgroup
+    if (plan->hyb_hold > 0) return PVDER_EINVAL;        // (an env at the duty-cycle limit: its steps belong to the follow-up kernel -- pvder_plan_rollout)
+    if (A.R.lazy) {
+        hipLaunchKernelGGL(complete_events_kernel, grid, block, 0, st, A.R, (float)A.P.sinsol0, istate, ev_vg, ev_si, n_env);
+        A.R.lazy = 0;
+    }
+    const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
+    const int pairs = n_steps / ep + 2;
+    for (int r = 0; r < pairs; ++r) {
+        Rk.resume = r > 0 ? 1 : 0;
+        Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
+        hipLaunchKernelGGL(step_etdlin_served_kernel, grid_sv, block, 0, st, Q);
+        hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    }
+    advance_hint(*plan, n_steps);
+    return hip_rc(hipGetLastError());
+}
+
 
 // Closed-loop training episode in a handful of launches: n_steps x (env step, agent step) with the env state AND the
 // agent's registers on the chip from step to step (step_etdlin_rollout_agent_kernel); the steps a workgroup cannot carry
@@ -1093,6 +1161,7 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
     K.seed = cfg->seed; K.counter = cfg->counter; K.env_id_base = cfg->env_id_base;
     K.policy = cfg->policy; K.hidden = cfg->hidden;
     Rk.q = q_table; Rk.ag_state = (long long *)state; Rk.ag_action = action; Rk.ag_alive = alive; Rk.ag_ret = ep_reward;
+    Rk.mailbox = nullptr; Rk.done = nullptr; Rk.sv_dev = nullptr;
     const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
     const int pairs = n_steps / ep + 2;
     for (int r = 0; r < pairs; ++r) {

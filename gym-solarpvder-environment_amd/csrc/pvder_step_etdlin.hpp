@@ -71,6 +71,10 @@ struct RollK {
     uint8_t *ag_action;              // [n_env] the pending action (in: chosen behind the reset / the previous rollout)
     uint8_t *ag_alive;               // [n_env]
     double *ag_ret;                  // [n_env] return of the running episode
+    // served rollouts (rollout_body<PH, false, true>: pvder_plan_rollout_served)
+    const int *mailbox;              // [1], host-coherent: action rows 0 .. *mailbox - 1 are there to be read (polled by the RELAY only)
+    int *done;                       // [2], host-coherent: min / max over the workgroups of the steps whose outputs have left their CU (the relay's)
+    int *sv_dev;                     // device words: see served_relay (csrc/pvder_step_rollout.hpp)
 };
 
 // first segment of an env step that starts at sim time step ksub: ONE integer division gives the event

@@ -513,6 +513,18 @@ __device__ __forceinline__ float etd_switched_step3(const ModelK<float> &P, cons
     return quad_max3(fmaxf(m2a, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
 }
 
+// Which env steps the hybrid kernel takes (while it follows the launches: EtdArgs.sat_hybrid).  An env step that never comes within
+// 0.4 % of the duty-cycle limit has no anti-windup event in it and no held mode (the switched sets start at 0.998: sat2_smooth; an
+// input jump counts as an entry beyond 1 - 4e-3: hyb::input_jump) -- the 23-state tail's own result stands.  So the tail hands over
+// an env that STARTS the step within 0.4 % and, AFTER the step, one whose duty cycle came that close during it (the step is
+// discarded: nothing of it was stored); every other env near the limit costs what it cost before round 6 (42 us, not milliseconds).
+constexpr float kHybTouch2 = 0.996f * 0.996f;
+// the phase-per-lane form (etd_tail3) has no such check: a workgroup with an env beyond this takes the lane-per-env form (one env step
+// does not go from here to the limit without an event -- and an event's own step is on the held sets wherever the kernel is not yet
+// following: the same bound as EtdK.sat2_flag)
+constexpr float kHybNear2 = 0.9875f * 0.9875f;
+constexpr int kHybMaxSub = 16;                      // sim time steps per env step the hybrid kernel takes (PVDER-v0: 15)
+constexpr int kHybHoldLaunches = 256;               // auto mode: the hybrid kernel follows this many step launches behind the last sighting
 // The env transition of the quads named by (e_quad, mine) on the phase-per-lane form; Msw: the staged operator sets;
 // LP: per-lane parameters (lane_par); stats / stats_fresh as epilogue takes them; act / out: the step's action row and
 // output block.  Lane 0 of a quad is the env for everything outside the integration (epilogue).
@@ -554,6 +566,7 @@ __device__ __forceinline__ void etd_tail3(const EtdArgs &A, const float *Msw, in
         Q.rot = p3 == 0 ? mk2(1.f, 0.f) : (p3 == 1 ? mk2(-0.5f, -1.f) : mk2(-0.5f, 1.f));      // (.y: which of phases a / b / c)
         SubPk S;
         bool fail = false;
+        float m2_peak = 0.f;                              // max |m_p|^2 of the env over the env step (the lane form keeps the same)
         int prev_row = L.ksub > 0 ? event_row(L.ksub - 1, C.ev_s0, C.ev_ds, C.ev_count) : 0;
         for (int s = 0; s < C.n_sub; ++s) {
             const int row = event_row(L.ksub + s, C.ev_s0, C.ev_ds, C.ev_count);
@@ -582,6 +595,7 @@ __device__ __forceinline__ void etd_tail3(const EtdArgs &A, const float *Msw, in
                     if (lane_fine == fine) {
                         y = yn;
                         comp[0] = cn[0]; comp[1] = cn[1]; comp[2] = cn[2]; comp[3] = cn[3];
+                        m2_peak = fmaxf(m2_peak, mm2);
                         if (mm2 > guard && C.off_range == PVDER_OFF_RANGE_TERMINATE) fail = true;
                     }
                     t0 += tq;
@@ -600,6 +614,14 @@ __device__ __forceinline__ void etd_tail3(const EtdArgs &A, const float *Msw, in
             L.ksub += C.n_sub;
             L.steps += 1;
             L.fail = fail;
+            // (the same hand-over as the lane-per-env form, on the same number: see kHybTouch2)
+            if (A.sat_hybrid && m2_peak > kHybTouch2 * P.mlim2) {
+                if (ph == 0) A.istate[(size_t)PVDER_I_STATUS * (size_t)n_env + L.e] = kDeferred;
+                L.run = false;
+                L.live = false;
+            } else if (A.hyb_flag && !A.sat_hybrid && m2_peak > Ec.sat2_flag && ph == 0) {
+                *(volatile int *)A.hyb_flag = 1;
+            }
         }
     }
     L.live = L.live && ph == 0;
@@ -621,18 +643,6 @@ typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
 // those seven fields replaced (VGPRs instead of SGPRs); stats_fresh: this pass starts the step's statistics.
 // ---- envs at / near the duty-cycle limit (round 6): the hybrid scheme of pvder_sat_hybrid.hpp, in a kernel of its own behind the step
 // kernel -- fp64, 6 KB of private arrays per lane: inside the step kernels it would cost every launch their occupancy and a scratch ring.
-// Which env steps the hybrid kernel takes (while it follows the launches: EtdArgs.sat_hybrid).  An env step that never comes within
-// 0.4 % of the duty-cycle limit has no anti-windup event in it and no held mode (the switched sets start at 0.998: sat2_smooth; an
-// input jump counts as an entry beyond 1 - 4e-3: hyb::input_jump) -- the 23-state tail's own result stands.  So the tail hands over
-// an env that STARTS the step within 0.4 % and, AFTER the step, one whose duty cycle came that close during it (the step is
-// discarded: nothing of it was stored); every other env near the limit costs what it cost before round 6 (42 us, not milliseconds).
-constexpr float kHybTouch2 = 0.996f * 0.996f;
-// the phase-per-lane form (etd_tail3) has no such check: a workgroup with an env beyond this takes the lane-per-env form (one env step
-// does not go from here to the limit without an event -- and an event's own step is on the held sets wherever the kernel is not yet
-// following: the same bound as EtdK.sat2_flag)
-constexpr float kHybNear2 = 0.9875f * 0.9875f;
-constexpr int kHybMaxSub = 16;                      // sim time steps per env step the hybrid kernel takes (PVDER-v0: 15)
-constexpr int kHybHoldLaunches = 256;               // auto mode: the hybrid kernel follows this many step launches behind the last sighting
 
 template <bool LP = false, bool T3 = false>
 __device__ __forceinline__ void etdrk4_full_tail(const EtdArgs &A, bool defer, const uint8_t *act = nullptr,

@@ -36,10 +36,75 @@ __device__ __forceinline__ const RollArgs &roll_args() {
 // discretise the observation, update the table with the transition that just ended, choose the next action
 // epsilon-greedily; pvder_agent_dev.hpp) runs between env step k and k + 1 with the env state still in registers;
 // the action row of a step is what the agent chose behind the previous one.
-template <int PH, bool AG>
+// SV = true (pvder_plan_rollout_served; round 6, VERDICT r5 #5 option B -- a resident step server): the fused loop takes step k only once
+// the caller has POSTED its action row (*Rk.mailbox > k: a host-coherent word, polled one step ahead so that the poll's round trip
+// sits behind the integration), and tells the caller how far its outputs are (Rk.done[wg]).  A wait is bounded (kServedWaitTicks
+// of the 100 MHz clock): on a timeout the WORKGROUP leaves the loop as it leaves for a step it cannot carry -- its state as of the
+// last step taken -- and the kernel ends: never a hung GPU.  No agent-scope fence anywhere.
+// The mailbox is polled over PCIe by ONE thread of the launch -- a relay workgroup without envs (the last of the grid), which
+// copies what it reads into a device word (Rk.sv_dev[0]) the env workgroups poll: 1024 waves reading a host word every step are
+// 1024 PCIe reads per step, 82 us of them (measured: profiles/r06_ab_served_rollout.txt).
+constexpr unsigned long long kServedWaitTicks = 20000000ull;            // 0.2 s
+__device__ __forceinline__ int served_posted(const int *mailbox) {
+    return __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool served_wait(const int *mailbox, int need) {
+    const unsigned long long t0 = wall_clock64();
+    while (served_posted(mailbox) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > kServedWaitTicks) return false;
+    }
+    return true;
+}
+
+// sv_dev (device words, a cache line each): [1] = workgroups that left; [16 (2 + 2 wg)] = the relay's copy of *mailbox for workgroup
+// wg (1024 waves polling ONE device word every step cost 10 us per step: the same-address serialisation the statistics' atomics once
+// showed); [16 (3 + 2 wg)] = steps whose outputs have left workgroup wg's CU.  The relay reduces those to Rk.done[0] = min, [1] = max
+// (host words): a workgroup that reported to the host itself waited, every step, for its own PCIe write to be acknowledged (+9.5 us).
+__device__ __forceinline__ const int *served_word(const int *sv_dev) { return sv_dev + 16 * (2 + 2 * (int)blockIdx.x); }
+__device__ __forceinline__ int *served_done(int *sv_dev) { return sv_dev + 16 * (3 + 2 * (int)blockIdx.x); }
+__device__ __forceinline__ void served_relay(const RollK &Rk) {
+    __shared__ int relay_p, relay_stop, relay_min, relay_max;
+    unsigned long long tlast = wall_clock64();
+    int last = -1;
+    const int n_wg = (int)gridDim.x - 1;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const int p = __hip_atomic_load(Rk.mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p != last) { last = p; tlast = wall_clock64(); }
+            relay_p = p; relay_min = 0x7fffffff; relay_max = 0;
+            relay_stop = (__hip_atomic_load(&Rk.sv_dev[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= n_wg      // everyone has left
+                          || wall_clock64() - tlast > 4 * kServedWaitTicks) ? 1 : 0;  // nobody posts and somebody stays: they time out, so do we
+        }
+        __syncthreads();
+        const int p = relay_p, stop = relay_stop;
+        for (int w = (int)threadIdx.x; w < n_wg; w += kBlock) {
+            __hip_atomic_store(&Rk.sv_dev[16 * (2 + 2 * w)], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int d = __hip_atomic_load(&Rk.sv_dev[16 * (3 + 2 * w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            atomicMin(&relay_min, d); atomicMax(&relay_max, d);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&Rk.done[0], relay_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&Rk.done[1], relay_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (stop) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&Rk.sv_dev[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (the next launch counts from 0)
+}
+
+template <int PH, bool AG, bool SV = false>
 __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
     using namespace pvder;
     constexpr int NS = 6 * PH + 5;
+    if constexpr (SV) {
+        if (blockIdx.x == gridDim.x - 1) { served_relay(Q.Rk); return; }
+        if (Q.Rk.resume && Q.Rk.progress[blockIdx.x] >= Q.Rk.n_steps) {
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&Q.Rk.sv_dev[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
     if (Q.Rk.resume && Q.Rk.progress[blockIdx.x] >= Q.Rk.n_steps) return;      // (workgroup-uniform) nothing left
     const int lane = threadIdx.x & 63;
     LinRegs R;                        // tick matrix, first ETD3RK set and Krogstad block resident for the whole rollout
@@ -88,6 +153,12 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             __syncthreads();
         }
     }
+    bool sv_timeout = false;         // (SV) a wait for the caller ran out: the workgroup leaves at its next barrier
+    if constexpr (SV) {
+        // (a resumed launch: the steps before k were taken by earlier launches -- the finish kernel among them -- and are complete)
+        if (threadIdx.x == 0) __hip_atomic_store(served_done(Q.Rk.sv_dev), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (k < Q.Rk.n_steps && !served_wait(served_word(Q.Rk.sv_dev), k + 1)) bail = true;
+    }
     if (!__syncthreads_or((int)bail) && k < Q.Rk.n_steps) {
         // what a step reads from memory -- its action, the event inputs and the schedule row of its first
         // segment -- is requested ONE STEP AHEAD (the addresses only depend on the step counter): a lone wave
@@ -111,7 +182,10 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             const bool traced = k == k_first + 3;       // (trace builds: timeline of the fourth step)
             if (traced) PVDER_TRACE_AT(0);
             int a_next = 0;
-            if constexpr (!AG) {
+            int posted = 0;
+            if constexpr (SV) {
+                posted = served_posted(served_word(Q1.Rk.sv_dev));        // (asked for here, looked at behind the integration)
+            } else if constexpr (!AG) {
                 const int k_next = k + 1 < Q1.Rk.n_steps ? k + 1 : k;
                 a_next = ld(&Q1.Rk.actions[(size_t)k_next * N + ec]);
             }
@@ -140,10 +214,23 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
                         fabsf(Y[1].z) + fabsf(Y[1].w) + fabsf(Y[2].x) + fabsf(Y[2].y) + fabsf(Y[2].z);
             leave |= !(chk < 1e30f);
+            if constexpr (SV) {
+                leave |= sv_timeout;
+                __builtin_amdgcn_s_waitcnt(0);                // this wave's stores of the steps before this one have left the CU
+            }
             if (__syncthreads_or((int)leave)) {
                 Y[0] = Y0; Y[1] = Y1; Y[2] = Y2;
                 qref = qref0; vdcref = vdcref0;
                 break;
+            }
+            bool sv_wait = false;
+            if constexpr (SV) {
+                if (threadIdx.x == 0) __hip_atomic_store(served_done(Q1.Rk.sv_dev), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (k + 1 < Q1.Rk.n_steps) {
+                    // the next step's action row: there already (the caller is ahead), or waited for behind this step's outputs
+                    if (posted >= k + 2) a_next = ld(&Q1.Rk.actions[(size_t)(k + 1) * N + ec]);
+                    else sv_wait = true;
+                }
             }
             // observation and reward at (y(tStop), tStop), exactly as the per-step epilogue computes them
             if (traced) PVDER_TRACE_AT(2);
@@ -175,6 +262,13 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
                     pvder_agent::agent_step(Q2.Rk.ag, Q2.Rk.q, obs, last_reward, false, Q2.Rk.ag.env_id_base + e,
                                             Q2.Rk.ag.counter + (uint64_t)k, ag_s, ag_a, ag_alive, ag_ret, qnet);
                 a_next = ag_a;
+            }
+            if constexpr (SV) {
+                if (sv_wait) {
+                    const RollArgs &Q4 = roll_args();
+                    if (served_wait(served_word(Q4.Rk.sv_dev), k + 2)) a_next = ld(&Q4.Rk.actions[(size_t)(k + 1) * (size_t)Q4.G.A.n_env + (e < Q4.G.A.n_env ? e : Q4.G.A.n_env - 1)]);
+                    else sv_timeout = true;
+                }
             }
             a_now = a_next;
             sg = sg_next;
@@ -209,6 +303,14 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
         }
     }
     if (threadIdx.x == 0) Q3.Rk.progress[blockIdx.x] = k;
+    if constexpr (SV) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(served_done(Q3.Rk.sv_dev), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(&Q3.Rk.sv_dev[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int PH>
@@ -220,6 +322,9 @@ void step_etdlin_rollout_kernel(const RollArgs Q) { rollout_body<PH, false>(Q); 
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_agent_kernel(const RollArgs Q) { rollout_body<PH, true>(Q); }
+
+// the fused loop SERVED: every env step waits for its action row to be posted (pvder_plan_rollout_served; grid = workgroups + the relay)
+__global__ __launch_bounds__(kBlock) void step_etdlin_served_kernel(const RollArgs Q) { rollout_body<3, false, true>(Q); }
 
 // the steps the fused kernel left to a workgroup, one at a time through memory (usually: the step that
 // ends an episode, once per episode)

@@ -32,7 +32,7 @@ SYMBOLS = ["pvder_version", "pvder_par_count", "pvder_block_size", "pvder_reset_
            "pvder_plan_rollout_gather", "pvder_plan_rollout_fused", "pvder_plan_rollout_gather_rows", "pvder_plan_hint",
            "pvder_fold_lane_params", "pvder_plan_lane_params", "pvder_reset_masked_lanes_f32", "pvder_fetch_env", "pvder_plan_step_fetch",
            "pvder_plan_step_mirror", "pvder_plan_graph_hints", "pvder_plan_kernel_name", "pvder_plan_hybrid_active",
-           "pvder_complete_event_tables"]
+           "pvder_complete_event_tables", "pvder_served_alloc", "pvder_served_free", "pvder_plan_rollout_served"]
 MIRROR_WORDS = 18       # PVDER_MIRROR_WORDS (pvder_plan_step_mirror): 13 output rows + 4 counters + the sequence word, doubles
 LPF_ROWS = 11          # enum PVDER_LPF_ROWS: 7 folded constants + the env's own steady state (i_a, m_a)
 AGENT_SYMBOLS = ["pvder_qagent_step_f32", "pvder_plan_rollout_fused_agent"]            # include/pvder_agent.h
@@ -176,6 +176,13 @@ def lib() -> C.CDLL:
     L.pvder_plan_kernel_name.argtypes = [vp]
     L.pvder_plan_hybrid_active.restype = i32
     L.pvder_plan_hybrid_active.argtypes = [vp]
+    ipp = C.POINTER(C.POINTER(C.c_int))
+    L.pvder_served_alloc.restype = i32
+    L.pvder_served_alloc.argtypes = [i32, ipp, ipp, ipp]
+    L.pvder_served_free.restype = i32
+    L.pvder_served_free.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pvder_plan_rollout_served.restype = i32
+    L.pvder_plan_rollout_served.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp, vp, vp]
     L.pvder_complete_event_tables.restype = i32
     L.pvder_complete_event_tables.argtypes = [C.POINTER(C.c_double), C.POINTER(StepCfg), C.POINTER(AutoReset), vp, vp, vp, i32, vp]
     L.pvder_fold_lane_params.restype = i32

@@ -284,6 +284,9 @@ class PVDERVec(EnvSpecMixin):
     def __del__(self):
         try:
             self._drop_plan()
+            w = self.__dict__.pop("_served_words", None)
+            if w is not None:
+                self._lib.pvder_served_free(w[0], w[2])
         except Exception:          # interpreter shutdown: the library may be gone already
             pass
 
@@ -980,6 +983,86 @@ class PVDERVec(EnvSpecMixin):
                 self.out.copy_(out[K - 1])
                 if self._mapped():
                     out.copy_(out.index_select(2, self._lane_of_env))      # the caller's blocks in ENV order (self.out stays in lane order)
+
+    def _served_alloc(self):
+        """The protocol words of rollout_served (pvder_served_alloc: pinned host words + device words), once per env."""
+        w = self.__dict__.get("_served_words")
+        if w is None:
+            host, dev, scr = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_int)()
+            with self._device_ctx():
+                _native.check(self._lib.pvder_served_alloc(self.num_envs, C.byref(host), C.byref(dev), C.byref(scr)), "pvder_served_alloc")
+            w = (host, dev, scr)
+            object.__setattr__(self, "_served_words", w)
+        return w
+
+    def rollout_served(self, actions: torch.Tensor, out: Optional[torch.Tensor] = None, depth: Optional[int] = None,
+                       fill=None, timeout_s: float = 60.0):
+        """``K`` transitions with the env state resident in registers (the fused rollout's loop) for a producer that does NOT have
+        its actions ahead: env step k is taken once row k of ``actions`` ([K, N] uint8, this env's device, LANE order if the lanes
+        are sorted) has been POSTED (pvder_plan_rollout_served, include/pvder_hip.h).  Same results as ``rollout`` bit for bit.
+        ``depth=None``: every row is there already -- posted before the launch (4.9 us per env step at 65 536 envs; one launch per
+        step: 8.5).  ``depth=D >= 1``: row k is posted once step k - D is reported done by every workgroup, after ``fill(k)`` --
+        the producer's hook: it writes ``actions[k]`` (stream-ordered work on ANOTHER stream than the current one, finished
+        before it returns: the current stream holds the served launches) -- has returned.  D = 8 costs 5.2 us per step, D = 1 the
+        PCIe round trip (27 us): what a host in the loop costs whatever it launches.  Blocks until the rollout is done (host
+        sync); not capturable.  etdlin, three-phase model, one parameter set, no env at the duty-cycle limit
+        (``pvder_plan_hybrid_active``: ValueError)."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before rollout_served()")
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.dtype != torch.uint8 or actions.device != self.device \
+                or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous uint8 tensor of shape (K, %d) on %s" % (self.num_envs, self.device))
+        if depth is not None and (not isinstance(depth, int) or depth < 1):
+            raise ValueError("depth must be None (every row posted ahead) or an integer >= 1")
+        K = int(actions.shape[0])
+        stride, dst = 0, self.out
+        if out is not None:
+            if tuple(out.shape) != (K, 13, self.num_envs) or out.dtype != self.out.dtype or not out.is_contiguous() \
+                    or out.device != self.device:
+                raise ValueError("out must be a contiguous %s tensor of shape (%d, 13, %d)" % (self.out.dtype, K, self.num_envs))
+            dst, stride = out, 13 * self.num_envs
+        plan = self._plan or self._make_plan()
+        if not (self._plan_integrator == "etdlin" and self.ns == 23 and not self._timing and self.__dict__.get("_lane_folded") is None
+                and self._traj is None):
+            raise ValueError("served rollouts: integrator='etdlin', three-phase model, no per-launch timing, no per-env parameter sets")
+        if self._lib.pvder_plan_hybrid_active(plan):
+            raise ValueError("an env is at / near the duty-cycle limit: its steps belong to the follow-up kernel -- use rollout()")
+        if self._mapped():
+            raise ValueError("sorted lanes with env-order I/O: rollout_served takes and gives LANE order (sort_lanes(lane_io=True))")
+        if K == 0:
+            return
+        host, dev, scr = self._served_alloc()
+        for i in range(32):
+            host[i] = 0
+        if depth is None:
+            host[0] = K
+        with self._device_ctx():
+            if out is not None and not self.auto_reset:
+                out[0].copy_(self.out)
+            rc = self._lib.pvder_plan_rollout_served(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self._ev_vg.data_ptr(),
+                                                     self._ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
+                                                     self.stats.data_ptr(), self._progress.data_ptr(), C.cast(dev, C.c_void_p),
+                                                     C.cast(scr, C.c_void_p), self._stream())
+            _native.check(rc, "pvder_plan_rollout_served")
+            try:
+                if depth is not None:
+                    import time as _time
+                    posted, deadline = 0, _time.perf_counter() + timeout_s
+                    while posted < K:
+                        if posted <= host[16] + depth:               # (host[16]: the slowest workgroup's "steps < d are out")
+                            if fill is not None:
+                                fill(posted)
+                            posted += 1
+                            host[0] = posted
+                        elif _time.perf_counter() > deadline:
+                            raise TimeoutError("rollout_served: the launch stopped reporting (%d of %d rows posted)" % (posted, K))
+            finally:
+                host[0] = K                                          # (whatever happened: nobody is left waiting)
+                torch.cuda.synchronize(self.device)
+            if int(self._progress.min().item()) < K:
+                raise RuntimeError("rollout_served: a workgroup timed out waiting for its action rows")
+            if out is not None:
+                self.out.copy_(out[K - 1])
 
     def step_stats(self) -> Dict[str, float]:
         """Wave-reduced statistics of the last step (host sync): reward sum, #done, #non-finite,

@@ -455,6 +455,26 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
                              const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
                              int32_t *progress, void *stream);
 
+/* (ABI 18) SERVED rollout: pvder_plan_rollout_fused whose env steps wait for their action rows -- the register-resident state of the
+ * fused loop for a producer that does NOT know its actions ahead (a policy a few steps behind the env, a recorded stream read as
+ * it arrives).  Same restrictions and launches as pvder_plan_rollout_fused, same results bit for bit (PVDER_env.py:138-196 has no
+ * notion of WHEN an action arrives).  Protocol, on words pvder_served_alloc returns (host[i] and dev[i] are the same memory):
+ *   host[0]  (caller writes)  p: action rows 0 .. p-1 of `actions` are in device memory, visible to the device.  Monotonic.
+ *   host[16], host[17]  (the launch writes)  min / max over the workgroups of d = "the outputs of steps < d have left the CU"
+ *                        (a workgroup reports step k while it takes step k+1: a producer can be at most ONE step behind the env).
+ * One thread of the launch (a relay workgroup) polls host[0] over PCIe and fans it out on the device; every wait is BOUNDED
+ * (0.2 s): a caller that stops posting gets its launches back (the steps not taken are then taken by the last finish pass with
+ * whatever `actions` holds -- post n_steps when giving up on a rollout whose rows are not all there, and discard the result).
+ * MI355X, 65 536 envs: 4.9 us per env step with the rows posted ahead (one launch per step 8.5, open-loop fused 4.8), 5.2 us with
+ * row k+1 posted when step k-8 is reported, 27 us when step k-1 is (the PCIe round trip of a host in the loop):
+ * profiles/r06_ab_served_rollout.txt.  PVDER_EINVAL while the duty-cycle-limit kernel follows the plan's launches
+ * (pvder_plan_hybrid_active).  `scratch`: device words of the protocol (zeroed per call). */
+int pvder_served_alloc(int n_env, int **host, int **dev, int **scratch);
+int pvder_served_free(int *host, int *scratch);
+int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
+                              const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
+                              int32_t *progress, int *words_dev, int *scratch_dev, void *stream);
+
 /* ---- the per-step collective of the sharded env (multi-GPU) -------------------------
  * The reference has no distributed code; the build shards independent envs over ranks and collates
  * the [13, n_env] output block of every step with ONE all-gather (RCCL over xGMI).  These entry points

@@ -180,3 +180,50 @@ def test_configs2_full_size_fused_rollout_is_bit_identical_to_single_launches(gp
         assert torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate) and torch.equal(a.ev_vg, b.ev_vg)
         assert a.step_stats() == b.step_stats()
     assert int(a.istate[2].min()) >= 3                      # episodes started: every env was reset twice in flight
+
+
+def test_served_rollout_is_bit_identical_and_waits_for_its_rows(gpu_device):
+    """pvder_plan_rollout_served (ABI 18; PVDER_env.py:138-196: a step is a function of the state and the action, not of when the
+    action arrived): the fused loop with every env step gated by the caller's posts -- (1) rows posted ahead, (2) posted one at a
+    time, row k WRITTEN (by `fill`, on a side stream) only just before it is posted into a buffer that held invalid actions until
+    then: had the kernel read a row before its post, `n_bad_action` and the results would show it -- against one launch per step:
+    every output block of 400 steps (2.5 episodes, auto-reset), states, counters, statistics, bit for bit."""
+    from gym_PVDER_amd.vec_env import PVDERVec
+    from helpers import both_events_spec
+    N, K = 4096, 400
+    kw = dict(seed=31, events_spec=both_events_spec(), auto_reset=True)
+    gen = torch.Generator(device=gpu_device); gen.manual_seed(5)
+    acts = torch.randint(0, 5, (K, N), generator=gen, device=gpu_device, dtype=torch.uint8)
+    ref, a, b = (PVDERVec(N, device=gpu_device, **kw) for _ in range(3))
+    outs = [torch.empty((K, 13, N), dtype=torch.float32, device=gpu_device) for _ in range(3)]
+    for e in (ref, a, b):
+        e.reset()
+    ref.rollout(acts, out=outs[0], fused=False)
+    a.rollout_served(acts, out=outs[1])                                  # every row there, posted before the launch
+    late = torch.full_like(acts, 255)                                    # (255: not an action -- counted by the kernels, changes nothing)
+    side = torch.cuda.Stream(device=gpu_device)
+    filled = []
+
+    def fill(k):
+        with torch.cuda.stream(side):
+            late[k].copy_(acts[k])
+        side.synchronize()
+        filled.append(k)
+    b.rollout_served(late, out=outs[2], depth=2, fill=fill)
+    assert filled == list(range(K))
+    for e, o in ((a, outs[1]), (b, outs[2])):
+        assert torch.equal(o, outs[0])
+        for name in ("fstate", "istate", "out", "stats", "ev_vg", "ev_si"):
+            assert torch.equal(getattr(e, name), getattr(ref, name)), name
+        assert e.step_stats()["n_bad_action"] == 0
+    assert int(ref.istate[2].min()) >= 3                                  # two episode ends inside the rollout
+    # a producer that stops: the launch comes back (bounded waits), the caller is told
+    c = PVDERVec(N, device=gpu_device, **kw); c.reset()
+
+    def stuck(k):
+        if k == 5:
+            raise KeyError("producer died")
+    with pytest.raises(KeyError):
+        c.rollout_served(late, depth=1, fill=stuck)
+    c.reset()
+    c.rollout_served(acts[:8])                                            # ... and the env is usable afterwards
