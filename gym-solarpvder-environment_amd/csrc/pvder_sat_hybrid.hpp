@@ -262,18 +262,6 @@ PVDER_HD inline void masked(const HybK &P, const Sub &S, const double *y, double
     }
 }
 
-// phi_k(hh L) v  for the whole 23-vector: the closed pairs through (c1, c2), everything else through 1, 1, 1/2, 1/6
-PVDER_HD inline void apply_phi(const Loop &L, const Phi &F, int k, int modes, const double *v, double *out) {
-    const double s = k == 0 ? 1.0 : (k == 1 ? 1.0 : (k == 2 ? 0.5 : 1.0 / 6.0));
-    for (int j = 0; j < 23; ++j) out[j] = s * v[j];
-    for (int q = 0; q < 6; ++q) {
-        if ((modes >> q) & 1) continue;
-        const int p = q >> 1, c = q & 1, i0 = 6 * p + c, i1 = 6 * p + 4 + c;
-        out[i0] = F.c1[k] * v[i0] + F.c2[k] * (L.a * v[i0] + L.b * v[i1]);
-        out[i1] = F.c1[k] * v[i1] + F.c2[k] * (L.c * v[i0] + L.d * v[i1]);
-    }
-}
-
 // one Hochbruck-Ostermann ETDRK4 step of length h from (y, th0 = 2 theta in turns at its start) with the modes held.
 // yn may be any slot but the eight this function works in (A_N1 .. A_TMP); y must not be one of them either.
 PVDER_HD PVDER_HYB_CALL inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const Arena &W, const double *y, double th0, double h, double qref,

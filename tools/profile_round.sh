@@ -13,6 +13,7 @@ echo "[profile] pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --out
 echo "[profile] pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py $BARGS > $out/write.log 2>&1
 python3 tools/reduce_pmc.py $tag $out/fetch $out/write $out/stats "$BARGS" > $out/reduce.log 2>&1
 mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_* gpurun_out/profiles_$tag/
+if [ -n "$PROFILE_SKIP_BENCH" ]; then cat $out/reduce.log | head -30; exit 0; fi
 echo "[profile] full bench"; python3 bench.py > $out/bench_full.log 2>&1
 tail -1 $out/bench_full.log > gpurun_out/profiles_$tag/${tag}_bench.json.log
 python3 bench.py --steps 20 --warmup 5 > $out/bench_20.log 2>&1
