@@ -31,6 +31,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <time.h>
+#include <chrono>
 #include <complex>
 #include <new>
 
@@ -410,16 +411,14 @@ struct pvder_plan {
     // auto: the host must SEE the flag before the duty cycle gets from 0.9875 to its limit (14 env steps of the reference's ramp):
     // never more than 16 step launches of this plan in flight (an event every 8 launches; the one recorded 16 launches ago is
     // waited for -- by polling, the queue holds 8 launches of work meanwhile)
-    mutable hipEvent_t thr_ev[2] = {nullptr, nullptr};
-    mutable bool thr_set[2] = {false, false};
-    mutable unsigned thr_n = 0;
+    mutable unsigned thr_n = 0;      // auto: step launches numbered (EtdArgs.hyb_seq; hyb_flag_host[1] = the last one that started)
+    mutable bool thr_off = false;
     bool graph_hints = false;        // pvder_plan_graph_hints: a CAPTURED pvder_plan_rollout keeps the clock hints it was captured with
     mutable int ksub_hint;           // etdlin: the clock (ksub) most envs of the batch are at when the NEXT step starts, -1 = unknown
                                      // (pvder_plan_hint; advanced by every step this plan enqueues: a prefetch hint, never a result)
     int n_sub;
     ~pvder_plan() {
         if (hyb_flag_host) (void)hipHostFree(hyb_flag_host);
-        for (int k = 0; k < 2; ++k) if (thr_ev[k]) (void)hipEventDestroy(thr_ev[k]);
     }
 };
 
@@ -485,7 +484,7 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
         void *dev = nullptr;
         if (hipHostMalloc((void **)&p.hyb_flag_host, 64, hipHostMallocMapped) == hipSuccess && p.hyb_flag_host
             && hipHostGetDevicePointer(&dev, p.hyb_flag_host, 0) == hipSuccess && dev) {
-            *p.hyb_flag_host = 0;
+            p.hyb_flag_host[0] = 0; p.hyb_flag_host[1] = 0;
             A.hyb_flag = (int *)dev;
         } else {
             // (no device: plans are still folded and validated -- tests/test_host.py; nothing can be launched there anyway)
@@ -566,6 +565,9 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
     const int n_env = p.n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
+    // (ONE query per launch: the clock hint and the launch throttle below both want to know)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusActive;
     if (out_prev && out_prev != out && !p.R.enabled) {       // stale tuples of finished envs follow the output block
         if (p.integrator >= PVDER_INT_RK45)
             hipLaunchKernelGGL(carry_stale_kernel<double>, grid, block, 0, st, istate, (const double *)out_prev, (double *)out, n_env);
@@ -594,6 +596,26 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             }
         }
         A.sat_hybrid = hyb ? 1 : 0;
+        // auto mode: at most 16 step launches in flight (the flag of an env that comes near the limit is seen within 16 steps of its
+        // being raised; hyb_progress): the word the kernels write as they start, no packet on the stream
+        A.hyb_seq = 0;
+        if (p.hyb_mode == 0 && p.hyb_flag_host && !capturing && !p.thr_off) {
+            if (++p.thr_n == 0u) ++p.thr_n;                    // (0 = "do not report")
+            const int seq = (int)p.thr_n;
+            volatile int *const started = p.hyb_flag_host + 1;
+            auto ahead = [&]() { const unsigned d = p.thr_n - (unsigned)*started; return d > 16u && d < 0x80000000u; };
+            if (ahead()) {
+                const auto t0 = std::chrono::steady_clock::now();
+                unsigned spins = 0;
+                while (ahead()) {
+                    if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                        p.thr_off = true;          // (the word does not move: a kernel that does not report -- never wait again)
+                        break;
+                    }
+                }
+            }
+            A.hyb_seq = seq;
+        }
         // ONE launch -- the fast path, whose workgroups themselves run the 23-state path (three-phase) / classic RK4
         // micro-steps, 8192 per 1/60 s (single phase: the "balanced" kernel IS the model) for the envs they must defer
         // (none in PVDER-v0 rollouts).
@@ -605,8 +627,6 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             // therefore taken with the hint cleared, and leaves the plan's clock alone -- per-step launches and rollouts
             // alike.  A caller that replays its K-step rollout graph exactly where it was captured (bench.py's window)
             // opts in with pvder_plan_graph_hints (hint_in_graphs).
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
             const int hint = (capturing && !hint_in_graphs) ? -1 : hint_word(p);
             if (p.ph == 3 && p.lane_par)
                 hipLaunchKernelGGL(step_etdlin_lane_kernel, grid, block, 0, st, G, p.lane_par, p.k4lane, p.lane_steps);
@@ -693,18 +713,6 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
                                    ev_vg, ev_si, (const uint8_t *)nullptr, (double *)out, n_env);
         }
     }
-    }
-    if (p.hyb_mode == 0 && p.hyb_flag_host) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
-        if (!capturing && ((++p.thr_n) & 7u) == 0u) {
-            const int slot = (int)((p.thr_n >> 3) & 1u);
-            if (!p.thr_ev[slot] && hipEventCreateWithFlags(&p.thr_ev[slot], hipEventDisableTiming) != hipSuccess) p.thr_ev[slot] = nullptr;
-            if (p.thr_ev[slot]) {
-                if (p.thr_set[slot]) while (hipEventQuery(p.thr_ev[slot]) == hipErrorNotReady) { }
-                p.thr_set[slot] = hipEventRecord(p.thr_ev[slot], st) == hipSuccess;
-            }
-        }
     }
     return hip_rc(hipGetLastError());
 }

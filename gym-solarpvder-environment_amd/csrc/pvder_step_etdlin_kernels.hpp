@@ -566,6 +566,7 @@ template <int PH, bool T3>
 __device__ __forceinline__ void step_etdlin_entry(float *fstate, int32_t *istate, const uint8_t *action, const float *lcoef, int n_env,
                                                   int ksub_word, const float *k4coef, const LinArgs &G) {
     using namespace pvder;
+    hyb_progress<kLinHeadBytes>();
     PVDER_TRACE_AT(0);
     // ---- A operands of the matrix-core products (pvder_etdlin.hpp): the tick matrix and the launch's
     // first ETD3RK set stay in registers for the whole launch; another set replaces the latter only when
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdlin_lane_kernel(const LinArgs G, const float *__restrict__ lane_par,
                                                                                                           const float *__restrict__ k4lane, int n_k4) {
     using namespace pvder;
+    hyb_progress<0>();
     const EtdArgs &A = G.A;
     constexpr int NS = 23;
     const size_t N = (size_t)A.n_env;

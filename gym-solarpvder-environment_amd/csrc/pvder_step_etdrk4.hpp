@@ -83,7 +83,9 @@ struct EtdArgs {
     int rk4_fallback;        // A/B and tests: steps at the duty-cycle limit by classic RK4 micro-steps (round 2's way)
     int sat_hybrid;          // 1 (set per launch): step_sat_hybrid_kernel follows this launch -- the 23-state tail hands it the envs at /
                              // near the duty-cycle limit (status kDeferred) instead of stepping them on the held operator sets
-    int *hyb_flag;           // device-addressable HOST word: written 1 by a workgroup that meets an env beyond kHybFlag2 (auto mode)
+    int *hyb_flag;           // device-addressable HOST words: [0] written 1 by a workgroup that meets an env beyond kHybFlag2 (auto mode);
+                             // [1] the sequence number of the last step launch that STARTED (hyb_progress: the host keeps <= 16 in flight)
+    int hyb_seq;             // this launch's sequence number (0: do not report -- a captured launch)
     int ph1_micro;           // single phase: classic RK4 micro-steps per sim time step of the envs the fast path hands over
                              // (8192: poles at 1.0e6 rad/s) -- the tail of the step kernel (rk4_tail_1ph)
 };
@@ -638,6 +640,20 @@ __device__ __forceinline__ void etd_tail3(const EtdArgs &A, const float *Msw, in
 // a scratch allocation -- AMDGPU callees save callee-saved VGPRs even when they never return -- and
 // with scratch enabled the workgroups start ~2 us later).
 typedef __attribute__((address_space(4))) const EtdArgs *KernargPtr;
+// Auto mode of the duty-cycle-limit kernel (launch_plan): the host must see an env's flag within a few launches of its being raised,
+// so it keeps at most 16 step launches in flight -- by this word, which workgroup 0 of every step launch writes as it STARTS (one
+// posted store behind two scalar loads, while the wave waits for its state rows anyway).  Round 6's first form, a stream marker
+// (hipEventRecord) every 8 launches, cost the headline 0.4-0.5 us per launch on the GPU's side of the queue.
+template <int KOFF>
+__device__ __forceinline__ void hyb_progress() {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    typedef __attribute__((address_space(4))) const char *KernargBytes;
+    KernargPtr ka = (KernargPtr)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + KOFF);
+    asm volatile("" : "+s"(ka));
+    int *const w = ka->hyb_flag;
+    const int seq = ka->hyb_seq;
+    if (w != nullptr && seq != 0) __hip_atomic_store(w + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // LP (step_etdrk4_lane_kernel): every env with its OWN values of the parameters that stay outside the exponential operator
 // (lane_par: [PVDER_LPF_ROWS][n_env] folded constants, pvder_fold_lane_params) -- the lane's ModelK is the launch's with
 // those seven fields replaced (VGPRs instead of SGPRs); stats_fresh: this pass starts the step's statistics.
@@ -1098,6 +1114,7 @@ __device__ __forceinline__ float unbalance2(v2 za, v2 zb, v2 zc) {
 
 template <int PH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void step_etdrk4_bal_kernel(const EtdArgs A) {
+    hyb_progress<0>();
     const ModelK<float> &P = A.P;
     const StepK<float> &C = A.C;
     const ResetK &R = A.R;
@@ -1297,6 +1314,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
 // balanced reduction here: an env with its own PV array is not at the group's operating point, and the reduction's guards
 // are folded for that one.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1))) void step_etdrk4_lane_kernel(const EtdArgs A, const float *lane_par) {
+    hyb_progress<0>();
     etdrk4_full_tail<true>(A, true, nullptr, 0, lane_par, A.stats_fresh);
 }
 
@@ -1307,6 +1325,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1))) voi
 // wins a lone wave's latency loses the batch's throughput: launch_plan picks by batch size.
 constexpr int kLane3MaxEnvs = 32768;
 __global__ __launch_bounds__(kBlock) void step_etdrk4_lane3_kernel(const EtdArgs A, const float *lane_par) {
+    hyb_progress<0>();
     __shared__ __attribute__((aligned(16))) float Msw[kSwFloats];          // (as etdrk4_full_tail stages them)
     __shared__ __attribute__((aligned(16))) float wstats[4 * (kBlock / 64)];
     for (int k = threadIdx.x; k < kSwFloats; k += kBlock) {
