@@ -974,6 +974,10 @@ def run_rank(args):
         try:
             Ks = max(1, min(4 * args.fused_steps, pool))
             served_leg = {"steps_per_call": Ks, "unit": "env-steps/s"}
+            for _ in range(4):       # (the duty-cycle-limit kernel follows 256 launches behind a sighting of an env near the limit --
+                if not env._lib.pvder_plan_hybrid_active(env._plan or env._make_plan()):      # once in ~15 000 random-action steps)
+                    break
+                env.rollout(actions[:min(300, pool)], fused=False)
             for name, depth in (("ahead", None), ("depth_8", 8)):
                 env.rollout_served(actions[:Ks], depth=depth)
                 torch.cuda.synchronize(dev)

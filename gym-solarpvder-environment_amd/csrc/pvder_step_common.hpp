@@ -73,11 +73,6 @@ using pvder::v2;
 #define PVDER_BLOCK 256
 #endif
 constexpr int kBlock = PVDER_BLOCK;   // 4 waves: one per SIMD of a CU
-#ifdef PVDER_NO_HYB_FLAG            // (A/B: the lean pass without the hybrid flag's term)
-#define PVDER_HYB_LEAN(x)
-#else
-#define PVDER_HYB_LEAN(x) x
-#endif
 constexpr int kDeferred = -1; // transient istate status (etdlin64 only): "advance me in the follow-up launch" (step_rk45_kernel)
 
 template <typename T>

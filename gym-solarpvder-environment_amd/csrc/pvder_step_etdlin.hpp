@@ -271,9 +271,7 @@ __device__ __forceinline__ bool lin_etd3rk(const LinArgs &G, const pvder::LinSet
     // (msc: 1, or the (1 + r)^2 of an env carried by its positive-sequence component, lin_seq_split)
     const float mmax = msc * fmaxf(fmaxf(m2a, m2x), fmaxf(m2b, __builtin_fmaf(mn.y, mn.y, mn.x * mn.x)));
     // the current reference or the duty cycle comes near its limit: the careful pass redoes the env step
-    // (LEAN: the duty cycle at the START of the step beyond 97 % of its limit sends the env to the second pass, which raises the plan's
-    //  hybrid flag -- not the peak, which every action's transient lifts)
-    near_ilim = ir2a > irg || mmax > Ec.sat2_smooth PVDER_HYB_LEAN(|| (LEAN && msc * m2a > Ec.sat2_flag));
+    near_ilim = ir2a > irg || mmax > Ec.sat2_smooth;
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -336,7 +334,7 @@ __device__ __forceinline__ bool lin_k4(const LinArgs &G, const pvder::LinK4Regs 
                             fabsf(Yn[1].z - acc2[0][1].z));
     const v2 mn = fma2(bc2(P.KpG), mk2(Yn[1].x, Yn[1].y), mk2(Yn[0].z, Yn[0].w));
     const float mmax = msc * fmaxf(fmaxf(fmaxf(m2a, m2x), fmaxf(m2y, m2b)), __builtin_fmaf(mn.y, mn.y, mn.x * mn.x));
-    near_ilim = ir2a > irg || ir2y > irg || mmax > Ec.sat2_smooth PVDER_HYB_LEAN(|| (!EARLY && msc * m2a > Ec.sat2_flag));     // (EARLY = the second pass)
+    near_ilim = ir2a > irg || ir2y > irg || mmax > Ec.sat2_smooth;     // (EARLY = the second pass)
     return mmax > G.Lk.sat2_hard || est > G.Lk.est_guard;
 }
 
@@ -474,7 +472,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
             bool trip = pk2 > G.Lk.sat2_hard;
             if (run) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
-                else defer |= pk2 > Ec.sat2_smooth PVDER_HYB_LEAN(|| msc * m2a > Ec.sat2_flag) || ir2a > irg;
+                else defer |= pk2 > Ec.sat2_smooth || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
             }
             // (a wave whose envs all sit at the current limit -- a policy that holds one Q_ref action -- goes
@@ -527,7 +525,7 @@ __device__ __forceinline__ bool lin_integrate(const LinArgs &G, int lane, LinReg
             const bool trip = pk2 > G.Lk.sat2_hard;
             if (start && !done) {
                 if constexpr (SPLIT) { careful |= ir2a > irg || pk2 > Ec.sat2_smooth; defer |= trip && !careful; }
-                else defer |= pk2 > Ec.sat2_smooth PVDER_HYB_LEAN(|| msc * m2a > Ec.sat2_flag) || ir2a > irg;
+                else defer |= pk2 > Ec.sat2_smooth || ir2a > irg;
                 Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 start = false;
             }

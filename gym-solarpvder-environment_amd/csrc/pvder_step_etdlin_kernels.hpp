@@ -523,6 +523,14 @@ __device__ __forceinline__ bool lin_step_lean(const LinArgs &G, int lane, LinReg
     };
     if (hinted) rows_to_leave(sg, ec0);
     prologue<float, NS>(A.C, fstate, istate, act, n_env, L, ys);
+    if constexpr (PH == 3) {
+        // auto mode of the duty-cycle-limit kernel: an env that STARTS a step beyond 98.75 % of the limit is reported (EtdK.sat2_flag;
+        // the host lets step_sat_hybrid_kernel follow the launches from there on).  The env itself stays here: it leaves this pass
+        // when its duty cycle PEAKS beyond 99.8 % (sat2_smooth), as ever -- the 23-state tail decides about the hand-over (kHybTouch2).
+        // (the first form sent every env beyond 98.75 % to the tail: 83 -> 141 us per step at 1 048 576 envs, where some always are)
+        const float mr = __builtin_fmaf(A.P.KpG, ys[4], ys[2]), mi = __builtin_fmaf(A.P.KpG, ys[5], ys[3]);
+        if (L.run && __builtin_fmaf(mi, mi, mr * mr) > A.Ec.sat2_flag && A.hyb_flag != nullptr) *(volatile int *)A.hyb_flag = 1;
+    }
     if (__builtin_amdgcn_readfirstlane(__any((int)(!hinted || (L.run && L.ksub != ksub_hint))))) {
         sg = lin_first_segment(A.C, G.Lk, L.ksub, A.ev_vg, A.ev_si, N, L.ec);
         int row_stop = sg.row;
@@ -650,6 +658,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     Lane<float> L;
     float ys[NS];
     prologue<float, NS>(A.C, A.fstate, A.istate, A.action, A.n_env, L, ys);
+    {   // (auto mode of the duty-cycle-limit kernel: as lin_step_lean)
+        const float mr = __builtin_fmaf(A.P.KpG, ys[4], ys[2]), mi = __builtin_fmaf(A.P.KpG, ys[5], ys[3]);
+        if (L.run && __builtin_fmaf(mi, mi, mr * mr) > A.Ec.sat2_flag && A.hyb_flag != nullptr) *(volatile int *)A.hyb_flag = 1;
+    }
     ModelK<float> Pl = A.P;
     {
         const float *__restrict__ lp = lane_par + L.ec;
@@ -690,7 +702,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
                 lin_mfma1(At, F, acc);
                 const float pk2 = lin_tick_peak2(Pl, Y, acc, m2a);
                 if (mine) {
-                    leave |= pk2 > A.Ec.sat2_smooth PVDER_HYB_LEAN(|| m2a > A.Ec.sat2_flag) || ir2a > irg;
+                    leave |= pk2 > A.Ec.sat2_smooth || ir2a > irg;
                     Y[0] = acc[0]; Y[1] = acc[1]; Y[2] = acc[2];
                 }
             }

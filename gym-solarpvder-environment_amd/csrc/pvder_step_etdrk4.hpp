@@ -996,20 +996,34 @@ __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const
 // rows), then the same epilogue as every step kernel (reward, done, observation, same-step auto-reset, statistics added to the
 // step's).  64 lanes per workgroup, ONE env per lane, the scheme's twelve 23-vectors + the state in the lane's own 2.4 KB of LDS
 // (153 KB of the CU's 160: as private arrays they make a 6 KB scratch frame per lane, which the runtime serves by allocating scratch
-// per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  A workgroup without such an env returns at once.
+// per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  Its workgroups take the blocks hybrid_scan_kernel listed.
 constexpr int kHybBlock = 64;
+constexpr int kHybGrid = 512;                                                     // workgroups of the step kernel: they loop over the list
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
 constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
-__global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par) {
+// WHICH 64-env blocks hold an env marked kDeferred: one wave per block, no LDS -- whole-chip occupancy.  (The step kernel below
+// reserves 153 KB of LDS per workgroup: launched over every block it ran ONE workgroup per CU at a time, and a batch of 1 048 576 envs
+// paid 60 us per step for 16 384 workgroups that found nothing.)  list[parity] = number of blocks found, list[16 + i] = their indices;
+// the OTHER parity's counter is cleared here for the next launch (nobody reads or writes it during this one).
+__global__ __launch_bounds__(kBlock) void hybrid_scan_kernel(const int32_t *__restrict__ istate, int n_env, int *__restrict__ list, int parity) {
+    const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (e == 0) list[1 - parity] = 0;
+    const bool mine = e < n_env && istate[(size_t)PVDER_I_STATUS * (size_t)n_env + (size_t)e] == kDeferred;
+    if (__any((int)mine) && (threadIdx.x & 63) == 0) {
+        const int i = atomicAdd(&list[parity], 1);
+        list[16 + i] = e >> 6;
+    }
+}
+__global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par,
+                                                                                                              const int *__restrict__ list, int parity) {
     using namespace pvder::hyb;
     extern __shared__ __attribute__((aligned(16))) double hyb_lds[];
     const int n_env = A.n_env;
     const size_t N = (size_t)n_env;
-    const int e_mine = (int)(blockIdx.x * kHybBlock + threadIdx.x);
-    {
-        const bool mine = e_mine < n_env && A.istate[(size_t)PVDER_I_STATUS * N + (size_t)e_mine] == kDeferred;
-        if (!__syncthreads_or((int)mine)) return;
-    }
+    const int n_found = list[parity];
+    for (int it = (int)blockIdx.x; it < n_found; it += (int)gridDim.x) {
+    const int blk = list[16 + it];
+    const int e_mine = blk * kHybBlock + (int)threadIdx.x;
     Lane<float> L;
     float ys[23];
     prologue<float, 23>(A.C, A.fstate, A.istate, A.action, n_env, L, ys, kDeferred, e_mine < n_env ? e_mine : n_env - 1);
@@ -1044,9 +1058,10 @@ __global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1)
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    // (this workgroup IS wave e / 64 of the step kernels' numbering: its statistics slot)
-    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats ? A.stats + 4 * (size_t)blockIdx.x : nullptr,
+    // (block blk IS wave e / 64 of the step kernels' numbering: its statistics slot)
+    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats ? A.stats + 4 * (size_t)blk : nullptr,
                        n_env, 0, false, 0.f, 0.f, lane_par, true);
+    }
 }
 
 // =============================================================================================
