@@ -697,7 +697,9 @@ def test_momentary_duty_cycle_saturation_on_the_q_ref_ramp(gpu_device):
     assert per[:ev].max() < TIGHT * 2, per[:ev].max()               # (2.6e-5: the careful pass from step ~100)
     assert unbalanced[:ev].max() < 1e-6 and unbalanced[ev].max() > 2e-4          # the event knocks the envs off balance ...
     assert unbalanced[ev + 20].max() > 0.1 * unbalanced[ev].max()                 # ... for seconds
-    assert per[ev:ev + 10].max() < 2.5e-3, per[ev:ev + 10].max()
+    # (round 6, VERDICT r5 #1: the event's step is the duty-cycle-limit kernel's -- the tail kept the peak of |m|^2 and handed the step
+    #  over: 3.6e-4 in the worst env, 1.7e-4 in the nine steps behind it; held modes, rounds 3-5: 1.3e-3 / 1.0e-3; profiles/r06_touch_numbers.txt)
+    assert per[ev:ev + 10].max() < 5e-4, per[ev:ev + 10].max()
     assert per[ev + 10:].max() < 1.5e-4, (int(per[ev + 10:].max(axis=1).argmax()) + ev + 10, per[ev + 10:].max())
     traj = rel_l2(got.transpose(1, 0, 2).reshape(c["N"], -1), want.transpose(1, 0, 2).reshape(c["N"], -1), axis=1)
     assert traj.max() < 2e-4, traj.max()
