@@ -997,3 +997,31 @@ def test_lazy_event_tables_give_the_bits_of_whole_tables(gpu_device):
     assert not e._lazy_active
     e.step(acts[2, :64]); e.sort_lanes()
     assert e._lazy_active
+
+
+def test_duty_cycle_limit_kernel_on_more_blocks_than_its_grid(gpu_device):
+    """step_sat_hybrid_kernel takes the 64-env blocks hybrid_scan_kernel lists, its 512 workgroups looping over them: the four envs
+    of the action-4 episode (PVDER_env.py:218-221, :229, :480-487) TILED over 32 832 envs (513 blocks, every one holding envs at the
+    duty-cycle limit from step 116) give, env by env, the very bits of the four -- outputs, states, counters and the per-wave
+    statistics -- through the first saturated steps (which kernel form and which workgroup advanced an env is a question of time
+    only); the hybrid kernel behind every launch in both batches (off_range="integrate_always": deterministic whatever the host's timing)."""
+    import bridge_cases
+    name = "ramp_a4"
+    c = bridge_cases.CASES[name]
+    vg, si, acts, cc = bridge_cases.case_inputs(name)
+    reps = 8208                                                       # 4 x 8208 = 32 832 envs = 513 blocks of 64
+    kw = dict(seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], off_range="integrate_always")
+    small, big = make_vec(4, gpu_device, **kw), make_vec(4 * reps, gpu_device, **kw)
+    tv = torch.from_numpy(vg.astype(np.float32)).to(gpu_device); ts = torch.from_numpy(si.astype(np.float32)).to(gpu_device)
+    small.reset(); small.set_event_tables(tv, ts); small.reset()
+    big.reset(); big.set_event_tables(tv.repeat(1, reps), ts.repeat(1, reps)); big.reset()        # (env e of the big batch = env e % 4)
+    a4, A4 = torch.full((4,), 4, dtype=torch.uint8, device=gpu_device), torch.full((4 * reps,), 4, dtype=torch.uint8, device=gpu_device)
+    for t in range(121):
+        small.step(a4, return_tensors=False); big.step(A4, return_tensors=False)
+        if t in (60, 115, 116, 118, 120):
+            assert torch.equal(big.out, small.out.repeat(1, reps)) and torch.equal(big.fstate, small.fstate.repeat(1, reps)) \
+                and torch.equal(big.istate, small.istate.repeat(1, reps)), t
+    m = (torch.complex(small.fstate[2], small.fstate[3]) + 6000.0 * torch.complex(small.fstate[4], small.fstate[5])).abs()
+    assert float(m.max()) > 0.999                                     # (at the limit: the last steps were the hybrid kernel's)
+    assert big.step_stats()["n_nonfinite"] == 0
+    assert abs(big.step_stats()["reward_sum"] - reps * small.step_stats()["reward_sum"]) < 1e-3 * reps
