@@ -672,9 +672,11 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             }
             const int n_blk = (n_env + kHybBlock - 1) / kHybBlock;
             const int parity = (int)(p.hyb_launches++ & 1u);
-            hipLaunchKernelGGL(hybrid_scan_kernel, grid, block, 0, st, (const int32_t *)istate, n_env, p.hyb_list, parity);
+            // (a captured launch is replayed with THIS parity every time: its counter is cleared inside the graph)
+            if (capturing && hipMemsetAsync(p.hyb_list + parity, 0, sizeof(int), st) != hipSuccess) return hip_rc(hipGetLastError());
+            hipLaunchKernelGGL(hybrid_scan_kernel, grid, block, 0, st, (const int32_t *)istate, n_env, p.hyb_list, parity, n_blk);
             hipLaunchKernelGGL(step_sat_hybrid_kernel, dim3(n_blk < kHybGrid ? n_blk : kHybGrid), dim3(kHybBlock), kHybLdsBytes, st, A, p.lane_par,
-                               (const int *)p.hyb_list, parity);
+                               (const int *)p.hyb_list, parity, n_blk);
         }
         break;
     }
@@ -1130,7 +1132,7 @@ int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *is
     Rk.mailbox = mailbox_dev; Rk.done = done_dev; Rk.sv_dev = scratch_dev;
     if (hipMemsetAsync(scratch_dev, 0, 64 * (size_t)(4 + 2 * grid.x), st) != hipSuccess) return hip_rc(hipErrorUnknown);
     const dim3 grid_sv(grid.x + 1);                    // + the relay workgroup
-    if (plan->hyb_hold > 0) return PVDER_EINVAL;        // (an env at the duty-cycle limit: its steps belong to the follow-up kernel -- pvder_plan_rollout)
+    if (pvder_plan_hybrid_active(plan)) return PVDER_EINVAL;        // (an env at the duty-cycle limit: its steps belong to the follow-up kernel -- pvder_plan_rollout)
     if (A.R.lazy) {
         hipLaunchKernelGGL(complete_events_kernel, grid, block, 0, st, A.R, (float)A.P.sinsol0, istate, ev_vg, ev_si, n_env);
         A.R.lazy = 0;

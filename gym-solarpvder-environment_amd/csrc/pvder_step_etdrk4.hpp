@@ -1005,22 +1005,24 @@ constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(do
 // reserves 153 KB of LDS per workgroup: launched over every block it ran ONE workgroup per CU at a time, and a batch of 1 048 576 envs
 // paid 60 us per step for 16 384 workgroups that found nothing.)  list[parity] = number of blocks found, list[16 + i] = their indices;
 // the OTHER parity's counter is cleared here for the next launch (nobody reads or writes it during this one).
-__global__ __launch_bounds__(kBlock) void hybrid_scan_kernel(const int32_t *__restrict__ istate, int n_env, int *__restrict__ list, int parity) {
+// (n_blk: the list's capacity.  A HIP graph that captured these launches replays them with ONE parity: its counter is then cleared by a
+//  memset node in front of the scan -- launch_plan -- and, whatever a caller does, no index beyond the capacity is written or read.)
+__global__ __launch_bounds__(kBlock) void hybrid_scan_kernel(const int32_t *__restrict__ istate, int n_env, int *__restrict__ list, int parity, int n_blk) {
     const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
     if (e == 0) list[1 - parity] = 0;
     const bool mine = e < n_env && istate[(size_t)PVDER_I_STATUS * (size_t)n_env + (size_t)e] == kDeferred;
     if (__any((int)mine) && (threadIdx.x & 63) == 0) {
         const int i = atomicAdd(&list[parity], 1);
-        list[16 + i] = e >> 6;
+        if (i < n_blk) list[16 + i] = e >> 6;
     }
 }
 __global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par,
-                                                                                                              const int *__restrict__ list, int parity) {
+                                                                                                              const int *__restrict__ list, int parity, int n_blk) {
     using namespace pvder::hyb;
     extern __shared__ __attribute__((aligned(16))) double hyb_lds[];
     const int n_env = A.n_env;
     const size_t N = (size_t)n_env;
-    const int n_found = list[parity];
+    const int n_found = list[parity] < n_blk ? list[parity] : n_blk;
     for (int it = (int)blockIdx.x; it < n_found; it += (int)gridDim.x) {
     const int blk = list[16 + it];
     const int e_mine = blk * kHybBlock + (int)threadIdx.x;

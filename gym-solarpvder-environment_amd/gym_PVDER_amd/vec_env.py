@@ -1005,7 +1005,8 @@ class PVDERVec(EnvSpecMixin):
         the producer's hook: it writes ``actions[k]`` (stream-ordered work on ANOTHER stream than the current one, finished
         before it returns: the current stream holds the served launches) -- has returned.  D = 8 costs 5.2 us per step, D = 1 the
         PCIe round trip (27 us): what a host in the loop costs whatever it launches.  Blocks until the rollout is done (host
-        sync); not capturable.  etdlin, three-phase model, one parameter set, no env at the duty-cycle limit
+        sync); not capturable.  If ``fill`` raises, the launch is let go on whatever ``actions`` holds (codes that are not actions
+        are no-ops the statistics count) and the exception propagates: ``reset()`` the env before using it again.  etdlin, three-phase model, one parameter set, no env at the duty-cycle limit
         (``pvder_plan_hybrid_active``: ValueError)."""
         if self._needs_reset:
             raise RuntimeError("call reset() before rollout_served()")

@@ -1025,3 +1025,36 @@ def test_duty_cycle_limit_kernel_on_more_blocks_than_its_grid(gpu_device):
     assert float(m.max()) > 0.999                                     # (at the limit: the last steps were the hybrid kernel's)
     assert big.step_stats()["n_nonfinite"] == 0
     assert abs(big.step_stats()["reward_sum"] - reps * small.step_stats()["reward_sum"]) < 1e-3 * reps
+
+
+def test_launches_with_the_duty_cycle_limit_kernel_behind_them_replay_from_a_graph(gpu_device):
+    """A HIP graph that captured per-step launches WITH the scan + hybrid kernels behind them (off_range="integrate_always") replays
+    bit-identically to eager launches, as often as one likes: the list of 64-env blocks the hybrid kernel works through is counted
+    per launch parity, a captured launch keeps ITS parity in every replay -- the graph clears the counter itself (a memset node),
+    and neither kernel touches an index beyond the list whatever the counter holds.  (Four saturated envs of the action-4 episode,
+    PVDER_env.py:480-487, tiled; eight replays of a three-step graph across steps 100-123: before, into and at the limit.)"""
+    import bridge_cases
+    c = bridge_cases.CASES["ramp_a4"]
+    vg, si, acts, cc = bridge_cases.case_inputs("ramp_a4")
+    reps = 64
+    kw = dict(seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], off_range="integrate_always")
+    tv = torch.from_numpy(vg.astype(np.float32)).to(gpu_device).repeat(1, reps); ts = torch.from_numpy(si.astype(np.float32)).to(gpu_device).repeat(1, reps)
+    a, b = make_vec(4 * reps, gpu_device, **kw), make_vec(4 * reps, gpu_device, **kw)
+    A4 = torch.full((3, 4 * reps), 4, dtype=torch.uint8, device=gpu_device)
+    for e in (a, b):
+        e.reset(); e.set_event_tables(tv, ts); e.reset()
+        for t in range(100):
+            e.step(A4[0], return_tensors=False)
+    state = b.state_dict()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        b.rollout(A4, fused=False)
+    b.load_state_dict(state)                           # (capture does not execute)
+    for r in range(8):
+        a.rollout(A4, fused=False)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(a.fstate, b.fstate) and torch.equal(a.istate, b.istate) and torch.equal(a.out, b.out), r
+    m = (torch.complex(a.fstate[2], a.fstate[3]) + 6000.0 * torch.complex(a.fstate[4], a.fstate[5])).abs()
+    assert float(m.max()) > 0.999 and a.step_stats()["n_nonfinite"] == 0
