@@ -1062,7 +1062,7 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
     Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
     Rk.ag = pvder_agent::AgentK{}; Rk.q = nullptr; Rk.ag_state = nullptr; Rk.ag_action = nullptr; Rk.ag_alive = nullptr; Rk.ag_ret = nullptr;
-    Rk.mailbox = nullptr; Rk.done = nullptr; Rk.sv_dev = nullptr;
+    Rk.mailbox = nullptr; Rk.done = nullptr; Rk.sv_dev = nullptr; Rk.sv_paced = 0;
     if (A.R.lazy) {
         // pvder_autoreset.lazy_events: the fused loop reads its event rows one env step AHEAD of the step that would leave them
         // behind -- it runs on whole tables (completed here, one launch per rollout), and so do the auto-resets of its finish kernel
@@ -1112,11 +1112,11 @@ int pvder_served_free(int *host, int *scratch) {
 // the rollout can contain; the finish kernel is not gated -- the step it takes is one whose action row the served kernel had)
 int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                               const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
-                              int32_t *progress, int *words_dev, int *scratch_dev, void *stream) {
+                              int32_t *progress, int *words_dev, int *scratch_dev, int paced, int resume, void *stream) {
     const int *mailbox_dev = words_dev;
     int *done_dev = words_dev ? words_dev + 16 : nullptr;
     if (!plan || n_steps < 0 || !actions || !out || !progress || !fstate || !istate || !ev_vg || !ev_si || !mailbox_dev || !done_dev || !scratch_dev) return PVDER_EINVAL;
-    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->lane_par) return PVDER_EINVAL;
+    if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->lane_par || (resume && !paced)) return PVDER_EINVAL;
     if (n_steps == 0) return 0;
     const int n_env = plan->n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);
@@ -1129,26 +1129,37 @@ int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *is
     A.action = actions; A.out = out; A.stats = stats; A.stats_fresh = 1;
     Rk.actions = actions; Rk.n_steps = n_steps; Rk.out_stride = (long long)out_step_stride; Rk.progress = progress;
     Rk.ag = pvder_agent::AgentK{}; Rk.q = nullptr; Rk.ag_state = nullptr; Rk.ag_action = nullptr; Rk.ag_alive = nullptr; Rk.ag_ret = nullptr;
-    Rk.mailbox = mailbox_dev; Rk.done = done_dev; Rk.sv_dev = scratch_dev;
-    if (hipMemsetAsync(scratch_dev, 0, 64 * (size_t)(4 + 2 * grid.x), st) != hipSuccess) return hip_rc(hipErrorUnknown);
+    Rk.mailbox = mailbox_dev; Rk.done = done_dev; Rk.sv_dev = scratch_dev; Rk.sv_paced = paced ? 1 : 0;
     const dim3 grid_sv(grid.x + 1);                    // + the relay workgroup
-    if (pvder_plan_hybrid_active(plan)) return PVDER_EINVAL;        // (an env at the duty-cycle limit: its steps belong to the follow-up kernel -- pvder_plan_rollout)
-    if (A.R.lazy) {
-        hipLaunchKernelGGL(complete_events_kernel, grid, block, 0, st, A.R, (float)A.P.sinsol0, istate, ev_vg, ev_si, n_env);
-        A.R.lazy = 0;
+    if (!resume) {
+        if (pvder_plan_hybrid_active(plan)) return PVDER_EINVAL;        // (an env at the duty-cycle limit: its steps belong to the follow-up kernel -- pvder_plan_rollout)
+        if (hipMemsetAsync(scratch_dev, 0, 64 * (size_t)(4 + 2 * grid.x), st) != hipSuccess) return hip_rc(hipErrorUnknown);
+        if (A.R.lazy)
+            hipLaunchKernelGGL(complete_events_kernel, grid, block, 0, st, A.R, (float)A.P.sinsol0, istate, ev_vg, ev_si, n_env);
     }
-    const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
-    const int pairs = n_steps / ep + 2;
-    for (int r = 0; r < pairs; ++r) {
-        Rk.resume = r > 0 ? 1 : 0;
-        Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
+    A.R.lazy = 0;                                      // (whole tables: see pvder_plan_rollout_fused)
+    if (paced) {
+        // ONE pair: the served loop until a workgroup meets a step it cannot carry (then every workgroup leaves: kServedStop), the
+        // finish kernel for that one step of every workgroup that has steps left.  The caller looks at `progress` and calls again.
+        Rk.resume = resume ? 1 : 0;
+        Rk.max_finish = 1;
         hipLaunchKernelGGL(step_etdlin_served_kernel, grid_sv, block, 0, st, Q);
         hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+    } else {
+        // every row is posted already (the caller's word says n_steps): the pairs of pvder_plan_rollout_fused, nobody asks anybody to
+        // leave, and the last finish pass -- which does not wait for rows -- takes what is left
+        const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
+        const int pairs = n_steps / ep + 2;
+        for (int r = 0; r < pairs; ++r) {
+            Rk.resume = r > 0 ? 1 : 0;
+            Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
+            hipLaunchKernelGGL(step_etdlin_served_kernel, grid_sv, block, 0, st, Q);
+            hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
+        }
     }
-    advance_hint(*plan, n_steps);
+    if (!resume) advance_hint(*plan, n_steps);
     return hip_rc(hipGetLastError());
 }
-
 
 // Closed-loop training episode in a handful of launches: n_steps x (env step, agent step) with the env state AND the
 // agent's registers on the chip from step to step (step_etdlin_rollout_agent_kernel); the steps a workgroup cannot carry
@@ -1186,7 +1197,7 @@ int pvder_plan_rollout_fused_agent(const pvder_plan *plan, float *fstate, int32_
     K.seed = cfg->seed; K.counter = cfg->counter; K.env_id_base = cfg->env_id_base;
     K.policy = cfg->policy; K.hidden = cfg->hidden;
     Rk.q = q_table; Rk.ag_state = (long long *)state; Rk.ag_action = action; Rk.ag_alive = alive; Rk.ag_ret = ep_reward;
-    Rk.mailbox = nullptr; Rk.done = nullptr; Rk.sv_dev = nullptr;
+    Rk.mailbox = nullptr; Rk.done = nullptr; Rk.sv_dev = nullptr; Rk.sv_paced = 0;
     const int ep = plan->episode_steps > 0 ? plan->episode_steps : 1;
     const int pairs = n_steps / ep + 2;
     for (int r = 0; r < pairs; ++r) {

@@ -304,15 +304,23 @@ __device__ __forceinline__ void lane_steady_state(const float *__restrict__ lane
     y[6 * PH + 1] = iR; y[6 * PH + 2] = iI;
 }
 
+// a store that is THROUGH the XCD's L2 when it is acknowledged (agent scope): what a kernel still running publishes to kernels that
+// start on other streams meanwhile -- the served rollout's output rows (a launch boundary does it for every other kernel)
 template <typename T>
+__device__ __forceinline__ void st_through(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T, bool THROUGH = false>
+__device__ __forceinline__ void st_out(T *p, T v) {
+    if constexpr (THROUGH) st_through(p, v); else st(p, v);
+}
+template <typename T, bool THROUGH = false>
 __device__ __forceinline__ void write_obs(T *__restrict__ out, size_t N, int e, T iaR, T iaI, T vaR, T vaI,
                                           T Ppcc, T Qpcc, T Vdc, T ppv, T vdcref, T qref, T tfrac) {
-    st(&out[0 * N + e], iaR);   st(&out[1 * N + e], iaI);
-    st(&out[2 * N + e], vaR);   st(&out[3 * N + e], vaI);
-    st(&out[4 * N + e], Ppcc);  st(&out[5 * N + e], Qpcc);
-    st(&out[6 * N + e], Vdc);   st(&out[7 * N + e], ppv);
-    st(&out[8 * N + e], vdcref); st(&out[9 * N + e], qref);
-    st(&out[10 * N + e], tfrac);                   // tStart/max_sim_time (:540)
+    st_out<T, THROUGH>(&out[0 * N + e], iaR);   st_out<T, THROUGH>(&out[1 * N + e], iaI);
+    st_out<T, THROUGH>(&out[2 * N + e], vaR);   st_out<T, THROUGH>(&out[3 * N + e], vaI);
+    st_out<T, THROUGH>(&out[4 * N + e], Ppcc);  st_out<T, THROUGH>(&out[5 * N + e], Qpcc);
+    st_out<T, THROUGH>(&out[6 * N + e], Vdc);   st_out<T, THROUGH>(&out[7 * N + e], ppv);
+    st_out<T, THROUGH>(&out[8 * N + e], vdcref); st_out<T, THROUGH>(&out[9 * N + e], qref);
+    st_out<T, THROUGH>(&out[10 * N + e], tfrac);                   // tStart/max_sim_time (:540)
 }
 
 // epilogue: reward_calc / done / state at (y(tStop), tStop); optional same-step auto-reset of the

@@ -75,6 +75,7 @@ struct RollK {
     const int *mailbox;              // [1], host-coherent: action rows 0 .. *mailbox - 1 are there to be read (polled by the RELAY only)
     int *done;                       // [2], host-coherent: min / max over the workgroups of the steps whose outputs have left their CU (the relay's)
     int *sv_dev;                     // device words: see served_relay (csrc/pvder_step_rollout.hpp)
+    int sv_paced;                    // 1: a workgroup that leaves the loop for the finish kernel asks every workgroup to leave (kServedStop)
 };
 
 // first segment of an env step that starts at sim time step ksub: ONE integer division gives the event

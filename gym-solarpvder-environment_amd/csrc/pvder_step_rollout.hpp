@@ -44,17 +44,25 @@ __device__ __forceinline__ const RollArgs &roll_args() {
 // The mailbox is polled over PCIe by ONE thread of the launch -- a relay workgroup without envs (the last of the grid), which
 // copies what it reads into a device word (Rk.sv_dev[0]) the env workgroups poll: 1024 waves reading a host word every step are
 // 1024 PCIe reads per step, 82 us of them (measured: profiles/r06_ab_served_rollout.txt).
+// STOP (Rk.sv_paced: a caller that posts row by row, against the reports): a workgroup that leaves the loop for a step it cannot
+// carry (an episode end, an env off the standard path) needs the finish kernel, which runs when THIS launch has ended -- and the
+// other workgroups would sit in their waits for rows the caller posts only when EVERY workgroup has reported.  So it says so (Rk.sv_dev[2]), the relay passes it on in bit 30 of every workgroup's word, and everybody leaves at
+// their next barrier: the launch ends, the finish kernel takes each workgroup through ONE step, the caller launches the pair again.
 constexpr unsigned long long kServedWaitTicks = 20000000ull;            // 0.2 s
-__device__ __forceinline__ int served_posted(const int *mailbox) {
-    return __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+constexpr int kServedStop = 1 << 30;
+__device__ __forceinline__ int served_posted(const int *word) {
+    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool served_wait(const int *mailbox, int need) {
+// true: rows 0 .. need - 1 are there; false: a stop was asked for, or the wait ran out
+__device__ __forceinline__ bool served_wait(const int *word, int need) {
     const unsigned long long t0 = wall_clock64();
-    while (served_posted(mailbox) < need) {
+    for (;;) {
+        const int w = served_posted(word);
+        if (w & kServedStop) return false;
+        if (w >= need) return true;
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > kServedWaitTicks) return false;
     }
-    return true;
 }
 
 // sv_dev (device words, a cache line each): [1] = workgroups that left; [16 (2 + 2 wg)] = the relay's copy of *mailbox for workgroup
@@ -64,7 +72,7 @@ __device__ __forceinline__ bool served_wait(const int *mailbox, int need) {
 __device__ __forceinline__ const int *served_word(const int *sv_dev) { return sv_dev + 16 * (2 + 2 * (int)blockIdx.x); }
 __device__ __forceinline__ int *served_done(int *sv_dev) { return sv_dev + 16 * (3 + 2 * (int)blockIdx.x); }
 __device__ __forceinline__ void served_relay(const RollK &Rk) {
-    __shared__ int relay_p, relay_stop, relay_min, relay_max;
+    __shared__ int relay_p, relay_stop, relay_min, relay_max, relay_ask;
     unsigned long long tlast = wall_clock64();
     int last = -1;
     const int n_wg = (int)gridDim.x - 1;
@@ -72,14 +80,15 @@ __device__ __forceinline__ void served_relay(const RollK &Rk) {
         if (threadIdx.x == 0) {
             const int p = __hip_atomic_load(Rk.mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (p != last) { last = p; tlast = wall_clock64(); }
-            relay_p = p; relay_min = 0x7fffffff; relay_max = 0;
+            relay_p = p < kServedStop ? p : kServedStop - 1; relay_min = 0x7fffffff; relay_max = 0;
+            relay_ask = __hip_atomic_load(&Rk.sv_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 ? kServedStop : 0;
             relay_stop = (__hip_atomic_load(&Rk.sv_dev[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= n_wg      // everyone has left
                           || wall_clock64() - tlast > 4 * kServedWaitTicks) ? 1 : 0;  // nobody posts and somebody stays: they time out, so do we
         }
         __syncthreads();
         const int p = relay_p, stop = relay_stop;
         for (int w = (int)threadIdx.x; w < n_wg; w += kBlock) {
-            __hip_atomic_store(&Rk.sv_dev[16 * (2 + 2 * w)], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&Rk.sv_dev[16 * (2 + 2 * w)], p | relay_ask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const int d = __hip_atomic_load(&Rk.sv_dev[16 * (3 + 2 * w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             atomicMin(&relay_min, d); atomicMax(&relay_max, d);
         }
@@ -91,7 +100,12 @@ __device__ __forceinline__ void served_relay(const RollK &Rk) {
         if (stop) break;
         __builtin_amdgcn_s_sleep(2);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&Rk.sv_dev[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (the next launch counts from 0)
+    if (threadIdx.x == 0) {          // (the next launch counts from 0, and nobody has asked it to stop)
+        __hip_atomic_store(&Rk.sv_dev[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&Rk.sv_dev[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int w = (int)threadIdx.x; w < n_wg; w += kBlock)
+        __hip_atomic_store(&Rk.sv_dev[16 * (2 + 2 * w)], relay_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int PH, bool AG, bool SV = false>
@@ -157,7 +171,13 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
     if constexpr (SV) {
         // (a resumed launch: the steps before k were taken by earlier launches -- the finish kernel among them -- and are complete)
         if (threadIdx.x == 0) __hip_atomic_store(served_done(Q.Rk.sv_dev), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (k < Q.Rk.n_steps && !served_wait(served_word(Q.Rk.sv_dev), k + 1)) bail = true;
+        if (k < Q.Rk.n_steps) {
+            if (bail) {                  // (this workgroup needs the finish kernel before anything else: everybody out)
+                if (threadIdx.x == 0 && Q.Rk.sv_paced) __hip_atomic_store(&Q.Rk.sv_dev[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (!served_wait(served_word(Q.Rk.sv_dev), k + 1)) {
+                bail = true;
+            }
+        }
     }
     if (!__syncthreads_or((int)bail) && k < Q.Rk.n_steps) {
         // what a step reads from memory -- its action, the event inputs and the schedule row of its first
@@ -214,11 +234,17 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
                         fabsf(Y[1].z) + fabsf(Y[1].w) + fabsf(Y[2].x) + fabsf(Y[2].y) + fabsf(Y[2].z);
             leave |= !(chk < 1e30f);
+            bool asked = false;              // (SV) this workgroup leaves because ANOTHER one asked, or because the caller is gone
             if constexpr (SV) {
-                leave |= sv_timeout;
+                asked = sv_timeout || (posted & kServedStop) != 0;
+                posted &= kServedStop - 1;
                 __builtin_amdgcn_s_waitcnt(0);                // this wave's stores of the steps before this one have left the CU
             }
-            if (__syncthreads_or((int)leave)) {
+            if (__syncthreads_or((int)(leave || asked))) {
+                if constexpr (SV) {              // its OWN reason: the others must let the finish kernel run
+                    if (__syncthreads_or((int)leave) && threadIdx.x == 0 && roll_args().Rk.sv_paced)
+                        __hip_atomic_store(&roll_args().Rk.sv_dev[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 Y[0] = Y0; Y[1] = Y1; Y[2] = Y2;
                 qref = qref0; vdcref = vdcref0;
                 break;
@@ -248,10 +274,11 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             if (traced) PVDER_TRACE_DEP(22, last_reward + ppv);
             if (e < B.n_env) {
                 float *o = B.out + k * Q2.Rk.out_stride;
-                write_obs<float>(o, N, e, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ys[6 * PH], ppv, vdcref, qref,
-                                 (float)ksub * (float)(1.0 / 60.0) * B.C.inv_tmax);
-                st(&o[PVDER_O_REWARD * N + e], last_reward);
-                st(&o[PVDER_O_DONE * N + e], 0.f);
+                // (SV: written THROUGH the L2 -- the report that follows says "a kernel that starts now, on any stream, reads them")
+                write_obs<float, SV>(o, N, e, iaR, iaI, vaR, vaI, Ppcc, Qpcc, ys[6 * PH], ppv, vdcref, qref,
+                                     (float)ksub * (float)(1.0 / 60.0) * B.C.inv_tmax);
+                st_out<float, SV>(&o[PVDER_O_REWARD * N + e], last_reward);
+                st_out<float, SV>(&o[PVDER_O_DONE * N + e], 0.f);
             }
             if (traced) PVDER_TRACE_AT(21);
             if constexpr (AG) {

@@ -182,7 +182,7 @@ def lib() -> C.CDLL:
     L.pvder_served_free.restype = i32
     L.pvder_served_free.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pvder_plan_rollout_served.restype = i32
-    L.pvder_plan_rollout_served.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp, vp, vp]
+    L.pvder_plan_rollout_served.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp, vp, vp, vp, i32, i32, vp]
     L.pvder_complete_event_tables.restype = i32
     L.pvder_complete_event_tables.argtypes = [C.POINTER(C.c_double), C.POINTER(StepCfg), C.POINTER(AutoReset), vp, vp, vp, i32, vp]
     L.pvder_fold_lane_params.restype = i32

@@ -1037,31 +1037,41 @@ class PVDERVec(EnvSpecMixin):
             host[i] = 0
         if depth is None:
             host[0] = K
+        import time as _time
         with self._device_ctx():
             if out is not None and not self.auto_reset:
                 out[0].copy_(self.out)
-            rc = self._lib.pvder_plan_rollout_served(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self._ev_vg.data_ptr(),
-                                                     self._ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
-                                                     self.stats.data_ptr(), self._progress.data_ptr(), C.cast(dev, C.c_void_p),
-                                                     C.cast(scr, C.c_void_p), self._stream())
-            _native.check(rc, "pvder_plan_rollout_served")
+            pair_done = torch.cuda.Event()
+            posted, resume, deadline = (K if depth is None else 0), 0, _time.perf_counter() + timeout_s
             try:
-                if depth is not None:
-                    import time as _time
-                    posted, deadline = 0, _time.perf_counter() + timeout_s
-                    while posted < K:
-                        if posted <= host[16] + depth:               # (host[16]: the slowest workgroup's "steps < d are out")
+                while True:
+                    # ONE pair of launches (the served loop until a workgroup meets a step it cannot carry, the finish kernel for that
+                    # step), the rows posted while it runs; then `progress` says whether there is another pair to launch
+                    rc = self._lib.pvder_plan_rollout_served(plan, self.fstate.data_ptr(), self.istate.data_ptr(), self._ev_vg.data_ptr(),
+                                                             self._ev_si.data_ptr(), actions.data_ptr(), K, dst.data_ptr(), stride,
+                                                             self.stats.data_ptr(), self._progress.data_ptr(), C.cast(dev, C.c_void_p),
+                                                             C.cast(scr, C.c_void_p), 0 if depth is None else 1, resume, self._stream())
+                    _native.check(rc, "pvder_plan_rollout_served")
+                    pair_done.record()
+                    while not pair_done.query():
+                        if posted < K and posted <= host[16] + depth:        # (host[16]: the slowest workgroup's "steps < d are out")
                             if fill is not None:
                                 fill(posted)
                             posted += 1
                             host[0] = posted
                         elif _time.perf_counter() > deadline:
                             raise TimeoutError("rollout_served: the launch stopped reporting (%d of %d rows posted)" % (posted, K))
+                    behind = int(self._progress.min().item())
+                    if behind >= K or depth is None:                         # (every row posted ahead: ONE call enqueued the whole rollout)
+                        if behind < K:
+                            raise RuntimeError("rollout_served: %d of %d steps taken" % (behind, K))
+                        break
+                    if _time.perf_counter() > deadline:
+                        raise TimeoutError("rollout_served: %d of %d steps taken, %d rows posted" % (behind, K, posted))
+                    resume = 1
             finally:
-                host[0] = K                                          # (whatever happened: nobody is left waiting)
+                host[0] = K                                                  # (whatever happened: nobody is left waiting)
                 torch.cuda.synchronize(self.device)
-            if int(self._progress.min().item()) < K:
-                raise RuntimeError("rollout_served: a workgroup timed out waiting for its action rows")
             if out is not None:
                 self.out.copy_(out[K - 1])
 

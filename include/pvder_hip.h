@@ -463,17 +463,27 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
  *   host[16], host[17]  (the launch writes)  min / max over the workgroups of d = "the outputs of steps < d have left the CU"
  *                        (a workgroup reports step k while it takes step k+1: a producer can be at most ONE step behind the env).
  * One thread of the launch (a relay workgroup) polls host[0] over PCIe and fans it out on the device; every wait is BOUNDED
- * (0.2 s): a caller that stops posting gets its launches back (the steps not taken are then taken by the last finish pass with
- * whatever `actions` holds -- post n_steps when giving up on a rollout whose rows are not all there, and discard the result).
- * MI355X, 65 536 envs: 4.9 us per env step with the rows posted ahead (one launch per step 8.5, open-loop fused 4.8), 5.2 us with
+ * (0.2 s): a caller that stops posting gets its launches back, `progress` short.
+ * paced = 0: the caller has posted EVERY row already (host[0] = n_steps before the call): one call enqueues the whole rollout, as
+ * pvder_plan_rollout_fused does (its last finish pass does not wait for rows).
+ * paced = 1: rows are posted against the reports.  ONE call = ONE pair of launches: the served loop until a workgroup meets a step
+ * it cannot carry (an episode end, an env off the standard path: that workgroup asks EVERY workgroup to leave, so that the launch
+ * ends), then the finish kernel, which takes every workgroup that has steps left through one step (whose action row the served loop
+ * had).  The caller reads `progress` (device, int32 per workgroup of 256 envs: steps behind it) when the pair is complete and calls
+ * again with resume = 1 until every entry is n_steps -- posting meanwhile; PVDERVec.rollout_served is that loop.  A batch with an
+ * env that stays off the standard path for many steps pays a pair (and a host round trip) per step, like a fused rollout does.
+ * resume = 0 starts a rollout (clears `scratch`, completes lazy event tables; PVDER_EINVAL while the duty-cycle-limit kernel follows
+ * the plan's launches: pvder_plan_hybrid_active).
+ * The served loop writes its output rows THROUGH the L2 (agent scope) before it reports them: a kernel that starts on another
+ * stream once host[16] says so reads them whole.
+ * MI355X, 65 536 envs: 4.9 us per env step with the rows posted ahead (one launch per step 8.1, open-loop fused 4.8), 5.5 us with
  * row k+1 posted when step k-8 is reported, 27 us when step k-1 is (the PCIe round trip of a host in the loop):
- * profiles/r06_ab_served_rollout.txt.  PVDER_EINVAL while the duty-cycle-limit kernel follows the plan's launches
- * (pvder_plan_hybrid_active).  `scratch`: device words of the protocol (zeroed per call). */
+ * profiles/r06_ab_served_rollout.txt.  `scratch`: device words of the protocol. */
 int pvder_served_alloc(int n_env, int **host, int **dev, int **scratch);
 int pvder_served_free(int *host, int *scratch);
 int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *istate, float *ev_vg, float *ev_si,
                               const uint8_t *actions, int n_steps, float *out, size_t out_step_stride, float *stats,
-                              int32_t *progress, int *words_dev, int *scratch_dev, void *stream);
+                              int32_t *progress, int *words_dev, int *scratch_dev, int paced, int resume, void *stream);
 
 /* ---- the per-step collective of the sharded env (multi-GPU) -------------------------
  * The reference has no distributed code; the build shards independent envs over ranks and collates

@@ -204,13 +204,18 @@ def test_served_rollout_is_bit_identical_and_waits_for_its_rows(gpu_device):
     side = torch.cuda.Stream(device=gpu_device)
     filled = []
 
+    seen = torch.zeros_like(outs[2])
+
     def fill(k):
         with torch.cuda.stream(side):
             late[k].copy_(acts[k])
+            if k >= 3:                                                   # row k is posted once step k - 3 is reported done by every workgroup:
+                seen[k - 3].copy_(outs[2][k - 3])                        # a kernel that starts NOW, on another stream, reads that block whole
         side.synchronize()
         filled.append(k)
     b.rollout_served(late, out=outs[2], depth=2, fill=fill)
     assert filled == list(range(K))
+    assert torch.equal(seen[:K - 3], outs[0][:K - 3])                    # (the served loop writes its output rows through the L2)
     for e, o in ((a, outs[1]), (b, outs[2])):
         assert torch.equal(o, outs[0])
         for name in ("fstate", "istate", "out", "stats", "ev_vg", "ev_si"):
