@@ -1003,8 +1003,11 @@ class PVDERVec(EnvSpecMixin):
         ``depth=None``: every row is there already -- posted before the launch (4.9 us per env step at 65 536 envs; one launch per
         step: 8.5).  ``depth=D >= 1``: row k is posted once step k - D is reported done by every workgroup, after ``fill(k)`` --
         the producer's hook: it writes ``actions[k]`` (stream-ordered work on ANOTHER stream than the current one, finished
-        before it returns: the current stream holds the served launches) -- has returned.  D = 8 costs 5.2 us per step, D = 1 the
-        PCIe round trip (27 us): what a host in the loop costs whatever it launches.  Blocks until the rollout is done (host
+        before it returns: the current stream holds the served launches) -- has returned; the output rows of the steps reported
+        done are in memory for a kernel that starts on that other stream (``out[k - D - 1]`` and earlier, inside ``fill(k)``).  D = 8
+        costs 5.5 us per step, D = 1 the PCIe round trip (27 us): what a host in the loop costs whatever it launches; an env that
+        leaves the standard path (current limit, off balance) or ends its episode ends the resident launch for ONE step of the
+        per-step body -- a launch pair and a host round trip, as often as that happens.  Blocks until the rollout is done (host
         sync); not capturable.  If ``fill`` raises, the launch is let go on whatever ``actions`` holds (codes that are not actions
         are no-ops the statistics count) and the exception propagates: ``reset()`` the env before using it again.  etdlin, three-phase model, one parameter set, no env at the duty-cycle limit
         (``pvder_plan_hybrid_active``: ValueError)."""
