@@ -1076,7 +1076,9 @@ int pvder_plan_rollout_fused(const pvder_plan *plan, float *fstate, int32_t *ist
     for (int r = 0; r < pairs; ++r) {
         Rk.resume = r > 0 ? 1 : 0;
         Rk.max_finish = r + 1 < pairs ? 1 : n_steps;
-        hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
+        static const bool no_cp = []() { const char *v = getenv("PVDER_NO_CP"); return v && v[0] == '1'; }();      // (A/B)
+        if (n_env <= kOneWavePerSimdEnvs && !no_cp) hipLaunchKernelGGL(step_etdlin_rollout_cp_kernel, grid, block, 0, st, Q);
+        else hipLaunchKernelGGL(step_etdlin_rollout_kernel<3>, grid, block, 0, st, Q);
         hipLaunchKernelGGL(step_etdlin_finish_kernel<3>, grid, block, 0, st, Q);
     }
     advance_hint(*plan, n_steps);
@@ -1117,6 +1119,7 @@ int pvder_plan_rollout_served(const pvder_plan *plan, float *fstate, int32_t *is
     int *done_dev = words_dev ? words_dev + 16 : nullptr;
     if (!plan || n_steps < 0 || !actions || !out || !progress || !fstate || !istate || !ev_vg || !ev_si || !mailbox_dev || !done_dev || !scratch_dev) return PVDER_EINVAL;
     if (plan->integrator != PVDER_INT_ETDLIN || plan->ph != 3 || plan->lane_par || (resume && !paced)) return PVDER_EINVAL;
+    if (plan->n_env > kOneWavePerSimdEnvs) return PVDER_EINVAL;       // (every workgroup must be RESIDENT while it waits: one wave per SIMD)
     if (n_steps == 0) return 0;
     const int n_env = plan->n_env;
     const dim3 grid((n_env + kBlock - 1) / kBlock), block(kBlock);

@@ -108,7 +108,12 @@ __device__ __forceinline__ void served_relay(const RollK &Rk) {
         __hip_atomic_store(&Rk.sv_dev[16 * (2 + 2 * w)], relay_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int PH, bool AG, bool SV = false>
+// CP = true (round 6, VERDICT r5 #2b): an env at the CURRENT limit stays in the loop -- its env step is redone from the state it started
+// with by the careful pass (lin_integrate_careful: the very call of the per-step body, same inputs, same bits) instead of sending its
+// whole workgroup through the finish kernel, step after step, for as long as the env sits there (a held Q_ref action: the last 60
+// steps of the episode).  The careful pass's registers make this a one-wave-per-SIMD kernel: batches up to 65 536 envs
+// (step_etdlin_rollout_cp_kernel; beyond that the two-wave kernel without it).
+template <int PH, bool AG, bool SV = false, bool CP = false>
 __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
     using namespace pvder;
     constexpr int NS = 6 * PH + 5;
@@ -227,8 +232,36 @@ __device__ __forceinline__ void rollout_body(const RollArgs &Q) {
             else if (a == 4) vdcref -= A.C.dv;
             else if (a != 0) bad = 1.f;
             if (!__builtin_amdgcn_readfirstlane(__any((int)leave))) {
-                bool careful;          // (an env at the current limit leaves too: its step belongs to the per-step body's careful pass)
-                leave = lin_integrate<PH, false>(Q1.G, lane, R, Y, qref, vdcref, ec, sg, true, false, careful, traced ? 0 : 1);
+                bool careful;
+                if constexpr (CP) {
+                    // the standard pass as the plain loop runs it (one flag, wave-level early outs) ...
+                    leave = lin_integrate<PH, false>(Q1.G, lane, R, Y, qref, vdcref, ec, sg, true, false, careful, traced ? 0 : 1);
+                }
+                // (a lane that leaves with its duty cycle beyond 95 % of its limit at the START of the step will most likely trip the careful
+                //  pass's own guard too -- the Q_ref-up ramp from step 110 --: its workgroup leaves at once, nothing is spent on it here.
+                //  Time only: the per-step body redoes the step from the same state either way.)
+                bool crowded = false;
+                if constexpr (CP) {
+                    const v2 m0 = fma2(bc2(Q1.G.A.P.KpG), mk2(Y1.x, Y1.y), mk2(Y0.z, Y0.w));
+                    crowded = leave && __builtin_fmaf(m0.y, m0.y, m0.x * m0.x) > 0.9025f * Q1.G.A.P.mlim2;
+                }
+                if (CP && __builtin_amdgcn_readfirstlane(__any((int)leave)) && !__builtin_amdgcn_readfirstlane(__any((int)crowded))) {
+                    // ... and, where a lane leaves, once more from the state the step started with, as lin_step_body runs it: it
+                    // names the lanes for the 23-state path and the lanes for the careful pass (same arithmetic for everybody else)
+                    Y[0] = Y0; Y[1] = Y1; Y[2] = Y2;
+                    bool defer = lin_integrate<PH, true>(Q1.G, lane, R, Y, qref, vdcref, ec, sg, true, false, careful, 1);
+                    defer = defer && !careful;
+                    if (__builtin_amdgcn_readfirstlane(__any((int)careful))) {
+                        if (careful) { Y[0] = Y0; Y[1] = Y1; Y[2] = Y2; }
+                        const bool dc = lin_integrate_careful<PH>(Q1.G, lane, R, Y, qref, vdcref, ec, sg, careful, false, 1.f);
+                        defer |= careful && dc;
+                    }
+                    leave = defer;
+                }
+                if constexpr (!CP) {
+                    // (an env at the current limit leaves too: its step belongs to the per-step body's careful pass)
+                    leave = lin_integrate<PH, false>(Q1.G, lane, R, Y, qref, vdcref, ec, sg, true, false, careful, traced ? 0 : 1);
+                }
             }
             if (traced) PVDER_TRACE_DEP(20, Y[0].x + Y[2].z);
             float chk = fabsf(Y[0].x) + fabsf(Y[0].y) + fabsf(Y[0].z) + fabsf(Y[0].w) + fabsf(Y[1].x) + fabsf(Y[1].y) +
@@ -350,8 +383,15 @@ void step_etdlin_rollout_kernel(const RollArgs Q) { rollout_body<PH, false>(Q); 
 template <int PH>
 __global__ __launch_bounds__(kBlock) void step_etdlin_rollout_agent_kernel(const RollArgs Q) { rollout_body<PH, true>(Q); }
 
+// ... with the careful pass inside the loop (batches up to 65 536 envs: one wave per SIMD is all they give the chip anyway)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_etdlin_rollout_cp_kernel(const RollArgs Q) {
+    rollout_body<3, false, false, true>(Q);
+}
+
 // the fused loop SERVED: every env step waits for its action row to be posted (pvder_plan_rollout_served; grid = workgroups + the relay)
-__global__ __launch_bounds__(kBlock) void step_etdlin_served_kernel(const RollArgs Q) { rollout_body<3, false, true>(Q); }
+// (WITHOUT the careful pass: its registers would make this a one-wave-per-SIMD kernel, and the relay workgroup needs a place next to
+//  256 resident env workgroups)
+__global__ __launch_bounds__(kBlock) void step_etdlin_served_kernel(const RollArgs Q) { rollout_body<3, false, true, false>(Q); }
 
 // the steps the fused kernel left to a workgroup, one at a time through memory (usually: the step that
 // ends an episode, once per episode)
