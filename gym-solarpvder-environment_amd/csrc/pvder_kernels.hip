@@ -1097,12 +1097,18 @@ int pvder_served_alloc(int n_env, int **host, int **dev, int **scratch) {
     const int n_wg = (n_env + kBlock - 1) / kBlock;
     int *h = nullptr;
     void *d = nullptr;
-    if (hipMalloc((void **)scratch, 64 * (size_t)(4 + 2 * n_wg)) != hipSuccess || hipMemset(*scratch, 0, 64 * (size_t)(4 + 2 * n_wg)) != hipSuccess) return hip_rc(hipErrorUnknown);
-    hipError_t e = hipHostMalloc((void **)&h, sizeof(int) * 32, hipHostMallocMapped | hipHostMallocCoherent);
+    int *s = nullptr;
+    hipError_t e = hipMalloc((void **)&s, 64 * (size_t)(4 + 2 * n_wg));
+    if (e == hipSuccess) e = hipMemset(s, 0, 64 * (size_t)(4 + 2 * n_wg));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h, sizeof(int) * 32, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
-    if (e != hipSuccess) return hip_rc(e);
+    if (e != hipSuccess) {           // (nothing is handed out, nothing is kept)
+        if (h) (void)hipHostFree(h);
+        if (s) (void)hipFree(s);
+        return hip_rc(e);
+    }
     for (int i = 0; i < 32; ++i) h[i] = 0;
-    *host = h; *dev = (int *)d;
+    *host = h; *dev = (int *)d; *scratch = s;
     return 0;
 }
 int pvder_served_free(int *host, int *scratch) {
