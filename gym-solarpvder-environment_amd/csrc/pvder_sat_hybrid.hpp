@@ -45,6 +45,14 @@
 namespace pvder {
 namespace hyb {
 
+// (host builds of tools/hybrid_cost_model.py count calls: what an env step costs a lane is the number of these)
+#if defined(PVDER_HYB_COUNT) && !defined(__HIP_DEVICE_COMPILE__)
+extern long g_count[8];
+#define PVDER_HYB_CNT(i) (++::pvder::hyb::g_count[i])
+#else
+#define PVDER_HYB_CNT(i) ((void)0)
+#endif
+
 // the model's constants (pvder_model.hpp::ModelK; pvK in the exp2 form).  TK = float on the device: they ARE the step kernels' fp32
 // constants, and 23 doubles that every function reads are 184 bytes of private memory the kernel cannot afford (see Arena)
 template <typename TK>
@@ -92,6 +100,7 @@ struct Alg {
     double vR[3], vI[3], iarR, iarI;
 };
 PVDER_HD PVDER_HYB_CALL inline void field(const HybK &P, const Sub &S, const double *y, double th2t, double qref, double vdcref, double *dy, Alg &A) {
+    PVDER_HYB_CNT(1);
     const double Vdc = y[18], xDC = y[19], xQ = y[20], xPLL = y[21], delta = y[22];
     const double hV = 0.5 * Vdc;
     double mR[3], mI[3], Pt = 0.0, Qp = 0.0;
@@ -266,6 +275,7 @@ PVDER_HD inline void masked(const HybK &P, const Sub &S, const double *y, double
 // yn may be any slot but the eight this function works in (A_N1 .. A_TMP); y must not be one of them either.
 PVDER_HD PVDER_HYB_CALL inline void etd_step(const HybK &P, const Sub &S, const Loop &L, const Arena &W, const double *y, double th0, double h, double qref,
                               double vdcref, int modes, int xmask, double *yn) {
+    PVDER_HYB_CNT(0);
     Phi Fh, Fg;
     make_phi(L, h, Fh);
     make_phi(L, 0.5 * h, Fg);
@@ -697,6 +707,7 @@ PVDER_HD PVDER_HYB_CALL inline void advance(const HybK &P, const Sub &S, const L
             continue;
         }
         R.st.events += 1;
+        PVDER_HYB_CNT(3 + ek);            // (4: entry, 5: impact, 6: clamp, 7: freeze)
         double th = eth;
         const double sg0 = ec >= 0 ? sgn(y[6 * ep + 4 + ec]) : 0.0;
         if (ek == EV_IMPACT && th > 0.0) {

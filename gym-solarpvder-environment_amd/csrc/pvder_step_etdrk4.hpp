@@ -997,7 +997,18 @@ __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const
 // step's).  64 lanes per workgroup, ONE env per lane, the scheme's twelve 23-vectors + the state in the lane's own 2.4 KB of LDS
 // (153 KB of the CU's 160: as private arrays they make a 6 KB scratch frame per lane, which the runtime serves by allocating scratch
 // per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  Its workgroups take the blocks hybrid_scan_kernel listed.
-constexpr int kHybBlock = 64;
+constexpr int kHybBlock = 64;                                                     // envs per listed block
+#ifndef PVDER_HYB_SUB
+#define PVDER_HYB_SUB 16
+#endif
+// ... of which every WAVE of the workgroup takes kHybSub, in its first lanes (round 6, second session): the block's 64 arenas fill the
+// CU's LDS whatever the shape of the workgroup, so ONE 64-lane wave kept one SIMD of four busy and diverged over 64 event sequences;
+// 64 / kHybSub waves of kHybSub active lanes run on the CU's four SIMDs side by side and each diverges over kHybSub sequences only.
+constexpr int kHybSub = PVDER_HYB_SUB;
+constexpr int kHybWaves = kHybBlock / kHybSub;
+constexpr int kHybThreads = 64 * kHybWaves;
+static_assert(kHybSub * kHybWaves == kHybBlock && kHybWaves <= 16, "a workgroup is at most 1024 threads");
+constexpr int kHybWavesPerSimd = kHybWaves > 4 ? kHybWaves / 4 : 1;
 constexpr int kHybGrid = 512;                                                     // workgroups of the step kernel: they loop over the list
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
 constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
@@ -1016,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void hybrid_scan_kernel(const int32_t *__re
         if (i < n_blk) list[16 + i] = e >> 6;
     }
 }
-__global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par,
+__global__ __launch_bounds__(kHybThreads) __attribute__((amdgpu_waves_per_eu(kHybWavesPerSimd, kHybWavesPerSimd))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par,
                                                                                                               const int *__restrict__ list, int parity, int n_blk) {
     using namespace pvder::hyb;
     extern __shared__ __attribute__((aligned(16))) double hyb_lds[];
@@ -1025,7 +1036,9 @@ __global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1)
     const int n_found = list[parity] < n_blk ? list[parity] : n_blk;
     for (int it = (int)blockIdx.x; it < n_found; it += (int)gridDim.x) {
     const int blk = list[16 + it];
-    const int e_mine = blk * kHybBlock + (int)threadIdx.x;
+    const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+    const int slot = wv * kHybSub + (ln < kHybSub ? ln : 0);                     // the env's place in its block (and its arena)
+    const int e_mine = ln < kHybSub ? blk * kHybBlock + slot : n_env;
     Lane<float> L;
     float ys[23];
     prologue<float, 23>(A.C, A.fstate, A.istate, A.action, n_env, L, ys, kDeferred, e_mine < n_env ? e_mine : n_env - 1);
@@ -1045,9 +1058,9 @@ __global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1)
         H.Rf = P.Rf; H.iLf = P.iLf; H.iC = P.iC; H.kviR = P.kviR; H.kviI = P.kviI; H.GR = P.GR; H.GI = P.GI; H.KpG = P.KpG; H.KiG = P.KiG;
         H.KpDC = P.KpDC; H.KiDC = P.KiDC; H.KpQ = P.KpQ; H.KiQ = P.KiQ; H.wp = P.wp; H.KpP = P.KpP; H.KiP = P.KiP; H.mlim2 = P.mlim2;
         H.ilim2 = P.ilim2; H.iwb = P.iwb; H.pvA = P.pvA; H.pvB = P.pvB; H.pvK = P.pvK; H.vdc_ref0 = P.vdc_ref0;
-        double *arena = hyb_lds + (size_t)threadIdx.x * kHybLaneDoubles;
+        double *arena = hyb_lds + (size_t)slot * kHybLaneDoubles;
         double *y = arena + kArenaDoubles;
-        float *vg = (float *)(hyb_lds + (size_t)kHybBlock * kHybLaneDoubles) + (size_t)threadIdx.x * (2 * kHybMaxSub), *si = vg + kHybMaxSub;
+        float *vg = (float *)(hyb_lds + (size_t)kHybBlock * kHybLaneDoubles) + (size_t)slot * (2 * kHybMaxSub), *si = vg + kHybMaxSub;
         for (int k = 0; k < 23; ++k) y[k] = (double)ys[k];
         const int n_sub = C.n_sub < kHybMaxSub ? C.n_sub : kHybMaxSub;      // (plans with longer env steps never set sat_hybrid)
         for (int s = 0; s < n_sub; ++s) {
@@ -1060,9 +1073,15 @@ __global__ __launch_bounds__(kHybBlock) __attribute__((amdgpu_waves_per_eu(1, 1)
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    // (block blk IS wave e / 64 of the step kernels' numbering: its statistics slot)
-    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats ? A.stats + 4 * (size_t)blk : nullptr,
-                       n_env, 0, false, 0.f, 0.f, lane_par, true);
+    // (block blk IS wave e / 64 of the step kernels' numbering: its statistics slot -- which the block's waves add to one after the
+    //  other: the epilogue's read-modify-write of the slot is a wave's own business everywhere else)
+    for (int w = 0; w < kHybWaves; ++w) {
+        if (w == wv)
+            epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out,
+                               A.stats ? A.stats + 4 * ((ptrdiff_t)blk - wv) : nullptr,     // (stats_local adds the wave's index)
+                               n_env, 0, false, 0.f, 0.f, lane_par, true);
+        if (kHybWaves > 1) __syncthreads();
+    }
     }
 }
 
