@@ -74,7 +74,7 @@ struct Stats {                 // what an env step did (tests, counters)
 };
 
 // Every 23-vector the scheme needs at one time, as slots of ONE block the caller provides: on the device a lane's own stretch of LDS
-// (step_sat_hybrid_kernel: 64 lanes per workgroup, 2.4 KB each -- private arrays of this size would give the kernel a 6 KB scratch
+// (step_sat_hybrid_kernel: the 64 envs of a block per workgroup -- on four 16-lane waves --, 2.4 KB each -- private arrays of this size would give the kernel a 6 KB scratch
 // frame per lane, which the runtime can only serve by allocating scratch per dispatch: 0.2 ms per LAUNCH), on the host an array.
 enum { A_N1 = 0, A_N2, A_N4, A_N5, A_YT, A_E2Y, A_EY, A_TMP, A_F0, A_F1, A_Y1, A_YT2, A_COUNT };
 constexpr int kArenaDoubles = A_COUNT * 23;

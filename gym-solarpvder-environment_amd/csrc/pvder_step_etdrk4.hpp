@@ -994,7 +994,7 @@ __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const
 // The follow-up launch of the step kernels (etdlin, ETDRK4; three-phase): advances the envs their 23-state tail marked kDeferred --
 // envs at / near the duty-cycle limit -- by ONE env step of the hybrid scheme (pvder_sat_hybrid.hpp::env_step: fp64 between the fp32
 // rows), then the same epilogue as every step kernel (reward, done, observation, same-step auto-reset, statistics added to the
-// step's).  64 lanes per workgroup, ONE env per lane, the scheme's twelve 23-vectors + the state in the lane's own 2.4 KB of LDS
+// step's).  A 64-env block per workgroup (kHybSub active lanes in each of its waves), ONE env per lane, the scheme's twelve 23-vectors + the state in the lane's own 2.4 KB of LDS
 // (153 KB of the CU's 160: as private arrays they make a 6 KB scratch frame per lane, which the runtime serves by allocating scratch
 // per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  Its workgroups take the blocks hybrid_scan_kernel listed.
 constexpr int kHybBlock = 64;                                                     // envs per listed block
@@ -1008,6 +1008,8 @@ constexpr int kHybSub = PVDER_HYB_SUB;
 constexpr int kHybWaves = kHybBlock / kHybSub;
 constexpr int kHybThreads = 64 * kHybWaves;
 static_assert(kHybSub * kHybWaves == kHybBlock && kHybWaves <= 16, "a workgroup is at most 1024 threads");
+// (measured, profiles/r06_hybrid_sub_wave.txt: 8 / 16 waves -- two / four per SIMD at 256 / 128 registers, 1.6 / 2.2 KB of spills per
+//  lane -- buy nothing over four: a batch waits for its slowest ENV, not for a wave's divergence)
 constexpr int kHybWavesPerSimd = kHybWaves > 4 ? kHybWaves / 4 : 1;
 constexpr int kHybGrid = 512;                                                     // workgroups of the step kernel: they loop over the list
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
