@@ -714,7 +714,9 @@ def run_rank(args):
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     total = args.warmup + args.steps
-    pool = max(total, 4096) if args.sustained_seconds > 0 else total + args.steps   # the sustained leg cycles through the pool
+    # (the pre-roll cycles through the pool too: a pool of a few dozen rows, repeated, is a RAMP -- every env drifts by the pattern's net
+    #  action count per cycle, and a 20-step window behind it was measured with the duty-cycle-limit kernel following every launch)
+    pool = max(total + args.steps, 4096) if (args.sustained_seconds > 0 or args.preroll_steps > 0) else total + args.steps   # the sustained leg cycles through the pool
     #                                                                                  (+ steps: the window graph's warm twin)
     actions = torch.randint(0, 5, (pool, N), generator=gen, device=dev, dtype=torch.uint8)
     # ONE collective per step (RCCL over xGMI): all-gather of the [13, N_local] output block.  It is
@@ -910,6 +912,12 @@ def run_rank(args):
     elapsed, host_enqueue, kern_ms, region_ms = timed(args.warmup + graph_warm_steps, args.steps, every, graph=window_graph)
     total += graph_warm_steps
     st = env.step_stats()
+    # was the duty-cycle-limit kernel following the step launches of this window?  (It does for 256 launches behind a sighting of an env
+    # beyond 98.75 % of the limit -- once in ~15 000 steps of a random-action batch -- at +5-6 us per launch: a short window is in or out.)
+    try:
+        hyb_following = bool(env._lib.pvder_plan_hybrid_active(env._plan)) if getattr(env, "_plan", None) else False
+    except Exception:
+        hyb_following = None
     post_note = ""
     if n_post and dist is None:
         env.kernel_timing(True, 1)
@@ -1123,7 +1131,7 @@ def run_rank(args):
             "fused_rollout": fused_leg,
             "served_rollout": served_leg,
             "ranks_seen": ranks_seen,
-            "last_step_stats": st,
+            "last_step_stats": st, "duty_cycle_limit_kernel_following": hyb_following,
         }
         if dist is not None:
             blk = 13 * N * 4
