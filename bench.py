@@ -716,7 +716,7 @@ def run_rank(args):
     total = args.warmup + args.steps
     # (the pre-roll cycles through the pool too: a pool of a few dozen rows, repeated, is a RAMP -- every env drifts by the pattern's net
     #  action count per cycle, and a 20-step window behind it was measured with the duty-cycle-limit kernel following every launch)
-    pool = max(total + args.steps, 4096) if (args.sustained_seconds > 0 or args.preroll_steps > 0) else total + args.steps   # the sustained leg cycles through the pool
+    pool = max(total, 4096) if (args.sustained_seconds > 0 or args.preroll_steps > 0) else total + args.steps   # the sustained leg cycles through the pool
     #                                                                                  (+ steps: the window graph's warm twin)
     actions = torch.randint(0, 5, (pool, N), generator=gen, device=dev, dtype=torch.uint8)
     # ONE collective per step (RCCL over xGMI): all-gather of the [13, N_local] output block.  It is
