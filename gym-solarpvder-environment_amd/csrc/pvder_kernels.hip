@@ -411,7 +411,8 @@ struct pvder_plan {
     // auto: the host must SEE the flag before the duty cycle gets from 0.9875 to its limit (14 env steps of the reference's ramp):
     // never more than 16 step launches of this plan in flight (an event every 8 launches; the one recorded 16 launches ago is
     // waited for -- by polling, the queue holds 8 launches of work meanwhile)
-    bool hyb_ready = false;          // the plan's shape admits the hybrid kernel (three-phase, n_sub <= kHybMaxSub, off_range integrate)
+    int *hyb_list = nullptr;         // device: [0], [1] = blocks found (by launch parity), [16 + i] = 64-env blocks with an env for the hybrid kernel
+    mutable unsigned hyb_launches = 0;
     mutable unsigned thr_n = 0;      // auto: step launches numbered (EtdArgs.hyb_seq; hyb_flag_host[1] = the last one that started)
     mutable bool thr_off = false;
     bool graph_hints = false;        // pvder_plan_graph_hints: a CAPTURED pvder_plan_rollout keeps the clock hints it was captured with
@@ -420,6 +421,7 @@ struct pvder_plan {
     int n_sub;
     ~pvder_plan() {
         if (hyb_flag_host) (void)hipHostFree(hyb_flag_host);
+        if (hyb_list) (void)hipFree(hyb_list);
     }
 };
 
@@ -494,7 +496,14 @@ int fill_plan(pvder_plan &p, int integrator, const double *par, const pvder_step
             p.hyb_flag_host = nullptr;
         }
     }
-    p.hyb_ready = (p.hyb_mode == 0 || p.hyb_mode == 3) && p.ph == 3 && cfg->n_sub <= kHybMaxSub;
+    if ((p.hyb_mode == 0 || p.hyb_mode == 3) && p.ph == 3 && cfg->n_sub <= kHybMaxSub) {
+        const size_t words = 16 + (size_t)((n_env + kHybBlock - 1) / kHybBlock);
+        if (hipMalloc((void **)&p.hyb_list, words * sizeof(int)) != hipSuccess || hipMemset(p.hyb_list, 0, words * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();         // (no device: see above -- without the list the hybrid kernel is never launched)
+            if (p.hyb_list) (void)hipFree(p.hyb_list);
+            p.hyb_list = nullptr;
+        }
+    }
     static const bool full_env = []() { const char *v = getenv("PVDER_ETD_VARIANT"); return v && v[0] == 'f'; }();
     A.force_full = (p.ph == 3 && (full_env || (cfg->reserved & 1))) ? 1 : 0;
     A.rk4_fallback = (cfg->reserved & 2) ? 1 : 0;
@@ -586,7 +595,7 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
         A.action = action; A.out = (float *)out; A.stats = stats; A.stats_fresh = fresh;
         // the hybrid kernel behind this launch? (hyb_mode 3: always; 0: while an env is, or lately was, near the duty-cycle limit)
         bool hyb = false;
-        if (p.hyb_ready) {
+        if (p.ph == 3 && p.n_sub <= kHybMaxSub && p.hyb_list && (p.hyb_mode == 0 || p.hyb_mode == 3)) {
             if (p.hyb_mode == 3) hyb = true;
             else {
                 if (p.hyb_flag_host && __atomic_load_n(p.hyb_flag_host, __ATOMIC_RELAXED) != 0) {
@@ -662,10 +671,12 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
                 lds_ok[dev] = kHybLdsBytes;
             }
             const int n_blk = (n_env + kHybBlock - 1) / kHybBlock;
-            // (a workgroup looks at ceil(n_blk / grid) blocks and can keep kHybFoundMax of them)
-            int hgrid = n_blk < kHybGrid ? n_blk : kHybGrid;
-            if ((n_blk + hgrid - 1) / hgrid > kHybFoundMax) hgrid = (n_blk + kHybFoundMax - 1) / kHybFoundMax;
-            hipLaunchKernelGGL(step_sat_hybrid_kernel, dim3(hgrid), dim3(kHybThreads), kHybLdsBytes, st, A, p.lane_par, n_blk);
+            const int parity = (int)(p.hyb_launches++ & 1u);
+            // (a captured launch is replayed with THIS parity every time: its counter is cleared inside the graph)
+            if (capturing && hipMemsetAsync(p.hyb_list + parity, 0, sizeof(int), st) != hipSuccess) return hip_rc(hipGetLastError());
+            hipLaunchKernelGGL(hybrid_scan_kernel, grid, block, 0, st, (const int32_t *)istate, n_env, p.hyb_list, parity, n_blk);
+            hipLaunchKernelGGL(step_sat_hybrid_kernel, dim3(n_blk < kHybGrid ? n_blk : kHybGrid), dim3(kHybThreads), kHybLdsBytes, st, A, p.lane_par,
+                               (const int *)p.hyb_list, parity, n_blk);
         }
         break;
     }

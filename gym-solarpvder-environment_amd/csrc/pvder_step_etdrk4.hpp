@@ -996,7 +996,7 @@ __device__ __forceinline__ void rk4_tail_1ph(const EtdArgs &A, bool defer, const
 // rows), then the same epilogue as every step kernel (reward, done, observation, same-step auto-reset, statistics added to the
 // step's).  A 64-env block per workgroup (kHybSub active lanes in each of its waves), ONE env per lane, the scheme's twelve 23-vectors + the state in the lane's own 2.4 KB of LDS
 // (153 KB of the CU's 160: as private arrays they make a 6 KB scratch frame per lane, which the runtime serves by allocating scratch
-// per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  Its workgroups find the blocks that hold such an env themselves (below).
+// per DISPATCH -- 0.2 ms per launch, measured -- and every access a memory round trip).  Its workgroups take the blocks hybrid_scan_kernel listed.
 constexpr int kHybBlock = 64;                                                     // envs per listed block
 #ifndef PVDER_HYB_SUB
 #define PVDER_HYB_SUB 16
@@ -1011,50 +1011,34 @@ static_assert(kHybSub * kHybWaves == kHybBlock && kHybWaves <= 16, "a workgroup 
 // (measured, profiles/r06_hybrid_sub_wave.txt: 8 / 16 waves -- two / four per SIMD at 256 / 128 registers, 1.6 / 2.2 KB of spills per
 //  lane -- buy nothing over four: a batch waits for its slowest ENV, not for a wave's divergence)
 constexpr int kHybWavesPerSimd = kHybWaves > 4 ? kHybWaves / 4 : 1;
-constexpr int kHybGrid = 256;                                                     // workgroups of the kernel: ONE per CU is resident (its LDS), and MI355X has 256
+constexpr int kHybGrid = 512;                                                     // workgroups of the step kernel: they loop over the list
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
 constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
-// WHICH 64-env blocks hold an env marked kDeferred is found by the kernel itself (round 6, second session): wave w of workgroup g reads
-// the status words of blocks g + G (w + W k) (G workgroups, W waves each), the workgroup collects what its waves found in LDS and takes
-// those blocks one after the other.  The first form of this -- a scan kernel at whole-chip occupancy writing a list (a counter per
-// launch parity, cleared by a memset node inside captured graphs) for this kernel's workgroups to loop over -- was a launch of its own:
-// +5.7 us per step launch while the kernel follows and finds nothing (two launch floors), now +2.9.  (Before that: one workgroup per
-// block, 153 KB of LDS each, ONE per CU at a time: a batch of 1 048 576 envs paid 60 us per step for 16 384 workgroups that found nothing.)
-constexpr int kHybFoundMax = 256;                                                 // blocks a workgroup can find: launch_plan sizes the grid for it
-__global__ __launch_bounds__(kHybThreads) __attribute__((amdgpu_waves_per_eu(kHybWavesPerSimd, kHybWavesPerSimd))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par, int n_blk) {
+// WHICH 64-env blocks hold an env marked kDeferred: one wave per block, no LDS -- whole-chip occupancy.  (The step kernel below
+// reserves 153 KB of LDS per workgroup: launched over every block it ran ONE workgroup per CU at a time, and a batch of 1 048 576 envs
+// paid 60 us per step for 16 384 workgroups that found nothing.)  list[parity] = number of blocks found, list[16 + i] = their indices;
+// the OTHER parity's counter is cleared here for the next launch (nobody reads or writes it during this one).
+// (n_blk: the list's capacity.  A HIP graph that captured these launches replays them with ONE parity: its counter is then cleared by a
+//  memset node in front of the scan -- launch_plan -- and, whatever a caller does, no index beyond the capacity is written or read.)
+__global__ __launch_bounds__(kBlock) void hybrid_scan_kernel(const int32_t *__restrict__ istate, int n_env, int *__restrict__ list, int parity, int n_blk) {
+    const int e = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (e == 0) list[1 - parity] = 0;
+    const bool mine = e < n_env && istate[(size_t)PVDER_I_STATUS * (size_t)n_env + (size_t)e] == kDeferred;
+    if (__any((int)mine) && (threadIdx.x & 63) == 0) {
+        const int i = atomicAdd(&list[parity], 1);
+        if (i < n_blk) list[16 + i] = e >> 6;
+    }
+}
+__global__ __launch_bounds__(kHybThreads) __attribute__((amdgpu_waves_per_eu(kHybWavesPerSimd, kHybWavesPerSimd))) void step_sat_hybrid_kernel(const EtdArgs A, const float *__restrict__ lane_par,
+                                                                                                              const int *__restrict__ list, int parity, int n_blk) {
     using namespace pvder::hyb;
     extern __shared__ __attribute__((aligned(16))) double hyb_lds[];
-    __shared__ int found[kHybFoundMax], found_n;
     const int n_env = A.n_env;
     const size_t N = (size_t)n_env;
+    const int n_found = list[parity] < n_blk ? list[parity] : n_blk;
+    for (int it = (int)blockIdx.x; it < n_found; it += (int)gridDim.x) {
+    const int blk = list[16 + it];
     const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
-    if (threadIdx.x == 0) found_n = 0;
-    __syncthreads();
-    {   // (sixteen blocks' status words in flight per wave: what a wave looks at when the batch is 1 048 576 envs -- one round trip)
-        constexpr int kU = 16;
-        const int stride = (int)gridDim.x * kHybWaves;
-        const int32_t *__restrict__ status = A.istate + (size_t)PVDER_I_STATUS * N;
-        for (int b0 = (int)blockIdx.x + (int)gridDim.x * wv; b0 < n_blk; b0 += kU * stride) {
-            int32_t w[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                // (an unconditional load of a clamped index: a load under a condition is a branch, and sixteen of them wait one by one)
-                const long long e = ((long long)b0 + (long long)u * stride) * kHybBlock + ln;
-                w[u] = status[e < (long long)n_env ? e : (long long)n_env - 1];
-                if (e >= (long long)n_env) w[u] = kDeferred + 1;
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u)
-                if (__any((int)(w[u] == kDeferred)) && ln == 0) {
-                    const int i = atomicAdd(&found_n, 1);
-                    if (i < kHybFoundMax) found[i] = b0 + u * stride;
-                }
-        }
-    }
-    __syncthreads();
-    const int n_found = found_n < kHybFoundMax ? found_n : kHybFoundMax;
-    for (int it = 0; it < n_found; ++it) {
-    const int blk = found[it];
     const int slot = wv * kHybSub + (ln < kHybSub ? ln : 0);                     // the env's place in its block (and its arena)
     const int e_mine = ln < kHybSub ? blk * kHybBlock + slot : n_env;
     Lane<float> L;

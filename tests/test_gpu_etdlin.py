@@ -1000,8 +1000,7 @@ def test_lazy_event_tables_give_the_bits_of_whole_tables(gpu_device):
 
 
 def test_duty_cycle_limit_kernel_on_more_blocks_than_its_grid(gpu_device):
-    """step_sat_hybrid_kernel finds the 64-env blocks that hold a handed-over env itself (every wave of its 256 workgroups looks through the
-    status words of the blocks that fall to it) and a workgroup takes its blocks one after the other: the four envs
+    """step_sat_hybrid_kernel takes the 64-env blocks hybrid_scan_kernel lists, its 512 workgroups looping over them: the four envs
     of the action-4 episode (PVDER_env.py:218-221, :229, :480-487) TILED over 32 832 envs (513 blocks, every one holding envs at the
     duty-cycle limit from step 116) give, env by env, the very bits of the four -- outputs, states, counters and the per-wave
     statistics -- through the first saturated steps (which kernel form and which workgroup advanced an env is a question of time
@@ -1029,10 +1028,10 @@ def test_duty_cycle_limit_kernel_on_more_blocks_than_its_grid(gpu_device):
 
 
 def test_launches_with_the_duty_cycle_limit_kernel_behind_them_replay_from_a_graph(gpu_device):
-    """A HIP graph that captured per-step launches WITH the duty-cycle-limit kernel behind them (off_range="integrate_always") replays
-    bit-identically to eager launches, as often as one likes: which 64-env blocks the kernel works through is found inside the launch
-    (LDS of the workgroup that finds them: nothing of it outlives a launch -- the kernel's first form kept a list in device memory with a
-    counter per launch parity, which a captured graph had to clear itself).  (Four saturated envs of the action-4 episode,
+    """A HIP graph that captured per-step launches WITH the scan + hybrid kernels behind them (off_range="integrate_always") replays
+    bit-identically to eager launches, as often as one likes: the list of 64-env blocks the hybrid kernel works through is counted
+    per launch parity, a captured launch keeps ITS parity in every replay -- the graph clears the counter itself (a memset node),
+    and neither kernel touches an index beyond the list whatever the counter holds.  (Four saturated envs of the action-4 episode,
     PVDER_env.py:480-487, tiled; eight replays of a three-step graph across steps 100-123: before, into and at the limit.)"""
     import bridge_cases
     c = bridge_cases.CASES["ramp_a4"]
