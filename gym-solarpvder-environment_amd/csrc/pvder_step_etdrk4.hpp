@@ -1011,7 +1011,14 @@ static_assert(kHybSub * kHybWaves == kHybBlock && kHybWaves <= 16, "a workgroup 
 // (measured, profiles/r06_hybrid_sub_wave.txt: 8 / 16 waves -- two / four per SIMD at 256 / 128 registers, 1.6 / 2.2 KB of spills per
 //  lane -- buy nothing over four: a batch waits for its slowest ENV, not for a wave's divergence)
 constexpr int kHybWavesPerSimd = kHybWaves > 4 ? kHybWaves / 4 : 1;
-constexpr int kHybGrid = 512;                                                     // workgroups of the step kernel: they loop over the list
+// workgroups of the step kernel (they loop over the list).  ONE is resident per CU (its LDS) and the hardware hands a CU its next
+// workgroup when one ends: with one listed block per workgroup a batch of 65 536 saturated envs (1024 blocks of very unequal length) is dealt
+// greedily -- 279-394 ms per batched step with 512 workgroups of two blocks each, 240-350 with 1024, 253-344 with 2048; a followed launch
+// that finds nothing: 15.7-15.9 / 15.9-16.4 / 16.0 us (profiles/r06_hybrid_sub_wave.txt)
+#ifndef PVDER_HYB_GRID
+#define PVDER_HYB_GRID 1024
+#endif
+constexpr int kHybGrid = PVDER_HYB_GRID;
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
 constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
 // WHICH 64-env blocks hold an env marked kDeferred: one wave per block, no LDS -- whole-chip occupancy.  (The step kernel below

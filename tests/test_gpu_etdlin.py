@@ -1000,8 +1000,8 @@ def test_lazy_event_tables_give_the_bits_of_whole_tables(gpu_device):
 
 
 def test_duty_cycle_limit_kernel_on_more_blocks_than_its_grid(gpu_device):
-    """step_sat_hybrid_kernel takes the 64-env blocks hybrid_scan_kernel lists, its 512 workgroups looping over them: the four envs
-    of the action-4 episode (PVDER_env.py:218-221, :229, :480-487) TILED over 32 832 envs (513 blocks, every one holding envs at the
+    """step_sat_hybrid_kernel takes the 64-env blocks hybrid_scan_kernel lists, its 1024 workgroups looping over them: the four envs
+    of the action-4 episode (PVDER_env.py:218-221, :229, :480-487) TILED over 65 664 envs (1026 blocks, every one holding envs at the
     duty-cycle limit from step 116) give, env by env, the very bits of the four -- outputs, states, counters and the per-wave
     statistics -- through the first saturated steps (which kernel form and which workgroup advanced an env is a question of time
     only); the hybrid kernel behind every launch in both batches (off_range="integrate_always": deterministic whatever the host's timing)."""
@@ -1009,7 +1009,7 @@ def test_duty_cycle_limit_kernel_on_more_blocks_than_its_grid(gpu_device):
     name = "ramp_a4"
     c = bridge_cases.CASES[name]
     vg, si, acts, cc = bridge_cases.case_inputs(name)
-    reps = 8208                                                       # 4 x 8208 = 32 832 envs = 513 blocks of 64
+    reps = 16416                                                      # 4 x 16 416 = 65 664 envs = 1026 blocks of 64 (the kernel's grid: 1024)
     kw = dict(seed=c["seed"], auto_reset=False, events_spec=cc["spec_dict"], off_range="integrate_always")
     small, big = make_vec(4, gpu_device, **kw), make_vec(4 * reps, gpu_device, **kw)
     tv = torch.from_numpy(vg.astype(np.float32)).to(gpu_device); ts = torch.from_numpy(si.astype(np.float32)).to(gpu_device)
