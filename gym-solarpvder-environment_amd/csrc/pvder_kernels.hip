@@ -675,7 +675,7 @@ int launch_plan(const pvder_plan &p, void *fstate, int32_t *istate, float *ev_vg
             // (a captured launch is replayed with THIS parity every time: its counter is cleared inside the graph)
             if (capturing && hipMemsetAsync(p.hyb_list + parity, 0, sizeof(int), st) != hipSuccess) return hip_rc(hipGetLastError());
             hipLaunchKernelGGL(hybrid_scan_kernel, grid, block, 0, st, (const int32_t *)istate, n_env, p.hyb_list, parity, n_blk);
-            hipLaunchKernelGGL(step_sat_hybrid_kernel, dim3(n_blk < kHybGrid ? n_blk : kHybGrid), dim3(kHybThreads), kHybLdsBytes, st, A, p.lane_par,
+            hipLaunchKernelGGL(step_sat_hybrid_kernel, dim3(n_blk * kHybQuarters < kHybGrid ? n_blk * kHybQuarters : kHybGrid), dim3(kHybThreads), kHybLdsBytes, st, A, p.lane_par,
                                (const int *)p.hyb_list, parity, n_blk);
         }
         break;

@@ -332,7 +332,8 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
                                          T *__restrict__ out, float *__restrict__ stats, int n_env,
                                          int stats_fresh = 0, bool have_inputs = false, float vg_stop = 0.f,
                                          float si_stop = 0.f, const float *__restrict__ lane_par = nullptr,
-                                         bool stats_local = false, int gen_j0 = -1, int gen_j1 = -1, int episode_now = -1) {
+                                         bool stats_local = false, int gen_j0 = -1, int gen_j1 = -1, int episode_now = -1,
+                                         bool stats_atomic = false) {
     // have_inputs: the caller fetched the event inputs in force at tStop ahead of the integration (same table
     // entries; a lone wave per SIMD would otherwise sit out a memory round trip right here)
     constexpr int NS = 6 * PH + 5;
@@ -441,8 +442,15 @@ __device__ __forceinline__ void epilogue(const ModelK<T> &P, const StepK<T> &C, 
             // (stats_local: `stats` IS this workgroup's own block of kBlock / 64 slots -- LDS of step_etdrk4_lane3_kernel)
             v4 *slot = (v4 *)stats + ((stats_local ? (size_t)0 : (size_t)blockIdx.x * (kBlock / 64)) + (threadIdx.x >> 6));
             v4 t = {r, d, nf, ba};
-            if (!stats_fresh) t += *slot;
-            *slot = t;
+            if (stats_atomic) {
+                // (step_sat_hybrid_kernel only: the four quarters of a 64-env block are workgroups of their own and add to the block's
+                //  slot as they finish -- the three counters are exact whatever the order, the reward sum to the last bit of a float)
+                float *f = (float *)slot;
+                atomicAdd(f, r); atomicAdd(f + 1, d); atomicAdd(f + 2, nf); atomicAdd(f + 3, ba);
+            } else {
+                if (!stats_fresh) t += *slot;
+                *slot = t;
+            }
         }
     }
 }

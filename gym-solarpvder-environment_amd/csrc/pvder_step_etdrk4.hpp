@@ -1001,26 +1001,28 @@ constexpr int kHybBlock = 64;                                                   
 #ifndef PVDER_HYB_SUB
 #define PVDER_HYB_SUB 16
 #endif
-// ... of which every WAVE of the workgroup takes kHybSub, in its first lanes (round 6, second session): the block's 64 arenas fill the
-// CU's LDS whatever the shape of the workgroup, so ONE 64-lane wave kept one SIMD of four busy and diverged over 64 event sequences;
-// 64 / kHybSub waves of kHybSub active lanes run on the CU's four SIMDs side by side and each diverges over kHybSub sequences only.
+// A listed block is taken in QUARTERS: kHybSub = 16 envs, in the first lanes of ONE wave that is a workgroup of its own, with 16 arenas
+// (39 KB of LDS: four such workgroups per CU, one per SIMD -- the kernel holds 416 registers per lane).  Round 6, second session, in
+// three steps (profiles/r06_hybrid_sub_wave.txt): one 64-lane wave per block kept one SIMD of four busy; four 16-lane waves in ONE
+// workgroup used the four SIMDs but ended together -- and a batch at the limit waits for its slowest ENV (the cost of an env step is
+// heavy-tailed: tools/hybrid_cost_model.py), so a block cost what the slowest of its 64 envs did; as workgroups of their own the
+// quarters end by themselves and the hardware hands the SIMD its next quarter.  (8 / 4 envs per wave -- two / four waves per SIMD at
+// 256 / 128 registers, 1.6 / 2.2 KB of spills per lane -- were measured in the one-workgroup form and bought nothing there.)
 constexpr int kHybSub = PVDER_HYB_SUB;
-constexpr int kHybWaves = kHybBlock / kHybSub;
-constexpr int kHybThreads = 64 * kHybWaves;
-static_assert(kHybSub * kHybWaves == kHybBlock && kHybWaves <= 16, "a workgroup is at most 1024 threads");
-// (measured, profiles/r06_hybrid_sub_wave.txt: 8 / 16 waves -- two / four per SIMD at 256 / 128 registers, 1.6 / 2.2 KB of spills per
-//  lane -- buy nothing over four: a batch waits for its slowest ENV, not for a wave's divergence)
-constexpr int kHybWavesPerSimd = kHybWaves > 4 ? kHybWaves / 4 : 1;
-// workgroups of the step kernel (they loop over the list).  ONE is resident per CU (its LDS) and the hardware hands a CU its next
-// workgroup when one ends: with one listed block per workgroup a batch of 65 536 saturated envs (1024 blocks of very unequal length) is dealt
-// greedily -- 279-394 ms per batched step with 512 workgroups of two blocks each, 240-350 with 1024, 253-344 with 2048; a followed launch
-// that finds nothing: 15.7-15.9 / 15.9-16.4 / 16.0 us (profiles/r06_hybrid_sub_wave.txt)
+constexpr int kHybQuarters = kHybBlock / kHybSub;                                 // items per listed block
+constexpr int kHybThreads = 64;
+static_assert(kHybSub * kHybQuarters == kHybBlock && kHybSub <= 64, "a quarter is one wave");
+constexpr int kHybWavesPerSimd = kHybQuarters > 4 ? kHybQuarters / 4 : 1;
+// workgroups of the kernel (they loop over the items of the list).  The hardware hands a SIMD its next workgroup when one ends: with
+// one item per workgroup a batch of 65 536 saturated envs (items of very unequal length) is dealt greedily (measured in the one-workgroup-
+// per-block form: 279-394 ms per batched step with 512 workgroups of two blocks each, 240-350 with 1024, 253-344 with 2048; a followed
+// launch that finds nothing: 15.7-15.9 / 15.9-16.4 / 16.0 us)
 #ifndef PVDER_HYB_GRID
-#define PVDER_HYB_GRID 1024
+#define PVDER_HYB_GRID 4096
 #endif
 constexpr int kHybGrid = PVDER_HYB_GRID;
 constexpr int kHybLaneDoubles = pvder::hyb::kArenaDoubles + 23;                   // odd: lanes on distinct LDS banks at the same index
-constexpr size_t kHybLdsBytes = (size_t)kHybBlock * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
+constexpr size_t kHybLdsBytes = (size_t)kHybSub * (kHybLaneDoubles * sizeof(double) + 2 * kHybMaxSub * sizeof(float));
 // WHICH 64-env blocks hold an env marked kDeferred: one wave per block, no LDS -- whole-chip occupancy.  (The step kernel below
 // reserves 153 KB of LDS per workgroup: launched over every block it ran ONE workgroup per CU at a time, and a batch of 1 048 576 envs
 // paid 60 us per step for 16 384 workgroups that found nothing.)  list[parity] = number of blocks found, list[16 + i] = their indices;
@@ -1043,10 +1045,10 @@ __global__ __launch_bounds__(kHybThreads) __attribute__((amdgpu_waves_per_eu(kHy
     const int n_env = A.n_env;
     const size_t N = (size_t)n_env;
     const int n_found = list[parity] < n_blk ? list[parity] : n_blk;
-    for (int it = (int)blockIdx.x; it < n_found; it += (int)gridDim.x) {
-    const int blk = list[16 + it];
-    const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
-    const int slot = wv * kHybSub + (ln < kHybSub ? ln : 0);                     // the env's place in its block (and its arena)
+    for (int it = (int)blockIdx.x; it < n_found * kHybQuarters; it += (int)gridDim.x) {
+    const int blk = list[16 + it / kHybQuarters];
+    const int ln = (int)threadIdx.x, al = ln < kHybSub ? ln : 0;                 // (al: the lane's arena)
+    const int slot = (it % kHybQuarters) * kHybSub + al;                         // the env's place in its block
     const int e_mine = ln < kHybSub ? blk * kHybBlock + slot : n_env;
     Lane<float> L;
     float ys[23];
@@ -1067,9 +1069,9 @@ __global__ __launch_bounds__(kHybThreads) __attribute__((amdgpu_waves_per_eu(kHy
         H.Rf = P.Rf; H.iLf = P.iLf; H.iC = P.iC; H.kviR = P.kviR; H.kviI = P.kviI; H.GR = P.GR; H.GI = P.GI; H.KpG = P.KpG; H.KiG = P.KiG;
         H.KpDC = P.KpDC; H.KiDC = P.KiDC; H.KpQ = P.KpQ; H.KiQ = P.KiQ; H.wp = P.wp; H.KpP = P.KpP; H.KiP = P.KiP; H.mlim2 = P.mlim2;
         H.ilim2 = P.ilim2; H.iwb = P.iwb; H.pvA = P.pvA; H.pvB = P.pvB; H.pvK = P.pvK; H.vdc_ref0 = P.vdc_ref0;
-        double *arena = hyb_lds + (size_t)slot * kHybLaneDoubles;
+        double *arena = hyb_lds + (size_t)al * kHybLaneDoubles;
         double *y = arena + kArenaDoubles;
-        float *vg = (float *)(hyb_lds + (size_t)kHybBlock * kHybLaneDoubles) + (size_t)slot * (2 * kHybMaxSub), *si = vg + kHybMaxSub;
+        float *vg = (float *)(hyb_lds + (size_t)kHybSub * kHybLaneDoubles) + (size_t)al * (2 * kHybMaxSub), *si = vg + kHybMaxSub;
         for (int k = 0; k < 23; ++k) y[k] = (double)ys[k];
         const int n_sub = C.n_sub < kHybMaxSub ? C.n_sub : kHybMaxSub;      // (plans with longer env steps never set sat_hybrid)
         for (int s = 0; s < n_sub; ++s) {
@@ -1082,15 +1084,9 @@ __global__ __launch_bounds__(kHybThreads) __attribute__((amdgpu_waves_per_eu(kHy
         L.ksub += C.n_sub;
         L.steps += 1;
     }
-    // (block blk IS wave e / 64 of the step kernels' numbering: its statistics slot -- which the block's waves add to one after the
-    //  other: the epilogue's read-modify-write of the slot is a wave's own business everywhere else)
-    for (int w = 0; w < kHybWaves; ++w) {
-        if (w == wv)
-            epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out,
-                               A.stats ? A.stats + 4 * ((ptrdiff_t)blk - wv) : nullptr,     // (stats_local adds the wave's index)
-                               n_env, 0, false, 0.f, 0.f, lane_par, true);
-        if (kHybWaves > 1) __syncthreads();
-    }
+    // (block blk IS wave e / 64 of the step kernels' numbering: its statistics slot -- which the block's quarters add to as they finish)
+    epilogue<float, 3>(P, A.C, A.R, L, ys, A.fstate, A.istate, A.ev_vg, A.ev_si, A.out, A.stats ? A.stats + 4 * (size_t)blk : nullptr,
+                       n_env, 0, false, 0.f, 0.f, lane_par, true, -1, -1, -1, true);
     }
 }
 
